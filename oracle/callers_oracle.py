@@ -1,0 +1,152 @@
+"""Callers of the detection ops on the hot path (CPU, numpy) -- TEST INFRASTRUCTURE ONLY.
+
+Restated from the reference's source text (the modules themselves need mmcv
+and cannot be imported here):
+  anchors          mmdet/core/anchor/anchor_generator.py:161-185, 255-270
+  delta2bbox       mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:133-237
+  rpn_get_bboxes   mmdet/models/dense_heads/rpn_head.py:82-236
+  map_roi_levels   mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py:32-51
+  roi_extract      .../single_level_roi_extractor.py:53-108
+  multiclass_nms   mmdet/core/post_processing/bbox_nms.py:7-93
+  bbox2roi         mmdet/core/bbox/transforms.py:69-77
+Pinned by the reference's own known-answer test for delta2bbox
+(tests/test_utils/test_coder.py:26-60, docstring example at
+delta_xywh_bbox_coder.py:172-182); the rest: PARITY UNPINNED (shape-only tests
+upstream), cross-checked by properties in tests/test_oracle_callers.py.
+"""
+import numpy as np
+
+from . import det_ops_oracle as D
+
+
+def base_anchors(stride, scales=(8,), ratios=(0.5, 1.0, 2.0)):
+    """anchor_generator.py:161-185 (scale_major=True, center_offset=0)."""
+    ratios = np.asarray(ratios, dtype=np.float32)
+    scales = np.asarray(scales, dtype=np.float32)
+    h_r = np.sqrt(ratios)
+    w_r = np.float32(1) / h_r
+    ws = (np.float32(stride) * w_r[:, None] * scales[None, :]).reshape(-1)
+    hs = (np.float32(stride) * h_r[:, None] * scales[None, :]).reshape(-1)
+    return np.stack([-0.5 * ws, -0.5 * hs, 0.5 * ws, 0.5 * hs], -1).astype(np.float32)
+
+
+def grid_anchors(H, W, stride, **kw):
+    """anchor_generator.py:255-270 -- index (y*W + x)*A + a."""
+    ba = base_anchors(stride, **kw)
+    sx = np.arange(W, dtype=np.float32) * stride
+    sy = np.arange(H, dtype=np.float32) * stride
+    xx, yy = np.meshgrid(sx, sy)  # row-major (y, x)
+    shifts = np.stack([xx.ravel(), yy.ravel(), xx.ravel(), yy.ravel()], -1)
+    return (shifts[:, None, :] + ba[None, :, :]).reshape(-1, 4).astype(np.float32)
+
+
+def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None,
+               wh_ratio_clip=16 / 1000):
+    """delta_xywh_bbox_coder.py:189-237, (N,4) rois and (N,4) deltas, fp32."""
+    f = np.float32
+    rois = np.asarray(rois, f)
+    d = np.asarray(deltas, f) * np.asarray(stds, f) + np.asarray(means, f)
+    dx, dy, dw, dh = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+    mr = f(np.abs(np.log(wh_ratio_clip)))
+    dw = np.clip(dw, -mr, mr)
+    dh = np.clip(dh, -mr, mr)
+    px = (rois[:, 0] + rois[:, 2]) * f(0.5)
+    py = (rois[:, 1] + rois[:, 3]) * f(0.5)
+    pw = rois[:, 2] - rois[:, 0]
+    ph = rois[:, 3] - rois[:, 1]
+    gw = pw * np.exp(dw)
+    gh = ph * np.exp(dh)
+    gx = px + pw * dx
+    gy = py + ph * dy
+    b = np.stack([gx - gw * f(.5), gy - gh * f(.5), gx + gw * f(.5), gy + gh * f(.5)], -1).astype(f)
+    if max_shape is not None:
+        Hm, Wm = f(max_shape[0]), f(max_shape[1])
+        b[:, 0::2] = np.clip(b[:, 0::2], 0, Wm)   # clamp to W / H, not W-1 (:222-235)
+        b[:, 1::2] = np.clip(b[:, 1::2], 0, Hm)
+    return b
+
+
+def sigmoid(x):
+    x = np.asarray(x, np.float32)
+    return (np.float32(1) / (np.float32(1) + np.exp(-x))).astype(np.float32)
+
+
+def rpn_get_bboxes(cls_scores, bbox_preds, img_shape, strides=(4, 8, 16, 32, 64), nms_pre=2000,
+                   max_per_img=1000, iou_threshold=0.7, nms_fn=None):
+    """rpn_head.py:82-236 for ONE image.
+
+    cls_scores[l]: (A, H, W) logits; bbox_preds[l]: (A*4, H, W).  Returns dets (<=max,5).
+    Also returns the (boxes, scores, level_ids) fed to batched_nms, for op-level tests."""
+    sc_l, bp_l, an_l, id_l = [], [], [], []
+    for l, (cs, bp) in enumerate(zip(cls_scores, bbox_preds)):
+        A, H, W = cs.shape
+        s = sigmoid(np.transpose(cs, (1, 2, 0)).reshape(-1))                 # :130-133
+        d = np.transpose(bp, (1, 2, 0)).reshape(-1, 4)                        # :141-142
+        an = grid_anchors(H, W, strides[l])
+        if s.shape[0] > nms_pre:                                              # :162-169
+            order = np.argsort(-s, kind="stable")[:nms_pre]
+            s, d, an = s[order], d[order], an[order]
+        sc_l.append(s); bp_l.append(d); an_l.append(an)
+        id_l.append(np.full(s.shape[0], l, dtype=np.int64))                  # :174-180
+    scores = np.concatenate(sc_l); deltas = np.concatenate(bp_l)
+    anchors = np.concatenate(an_l); ids = np.concatenate(id_l)
+    props = delta2bbox(anchors, deltas, max_shape=img_shape)                  # :185-186
+    dets, keep = D.batched_nms(props, scores, ids, dict(type="nms", iou_threshold=iou_threshold),
+                               nms_fn=nms_fn)                                 # :233
+    return dets[:max_per_img], (props, scores, ids)                           # :235
+
+
+def bbox2roi(bbox_list):
+    """transforms.py:69-77."""
+    out = []
+    for i, b in enumerate(bbox_list):
+        b = np.asarray(b, np.float32)[:, :4]
+        out.append(np.concatenate([np.full((b.shape[0], 1), i, np.float32), b], 1))
+    return np.concatenate(out, 0)
+
+
+def map_roi_levels(rois, num_levels, finest_scale=56):
+    """single_level_roi_extractor.py:47-51."""
+    f = np.float32
+    rois = np.asarray(rois, f)
+    scale = np.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+    lv = np.floor(np.log2(scale / f(finest_scale) + f(1e-6)))
+    return np.clip(lv, 0, num_levels - 1).astype(np.int64)
+
+
+def roi_extract(feats, rois, output_size, strides=(4, 8, 16, 32), sampling_ratio=0, finest_scale=56):
+    """single_level_roi_extractor.py:53-108: per-level RoIAlign gathered back in roi order."""
+    rois = np.asarray(rois, np.float32).reshape(-1, 5)
+    C = feats[0].shape[1]
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    out = np.zeros((rois.shape[0], C, ph, pw), np.float32)
+    if rois.shape[0] == 0:
+        return out
+    lv = map_roi_levels(rois, len(feats), finest_scale)
+    for i, f in enumerate(feats):
+        inds = np.nonzero(lv == i)[0]
+        if inds.size:
+            out[inds] = D.roi_align_c(f, rois[inds], (ph, pw), 1.0 / strides[i], sampling_ratio, True)
+    return out
+
+
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, nms_fn=None):
+    """bbox_nms.py:7-93 -> (dets (k,5), labels (k,))."""
+    multi_bboxes = np.asarray(multi_bboxes, np.float32)
+    multi_scores = np.asarray(multi_scores, np.float32)
+    n, nc = multi_scores.shape[0], multi_scores.shape[1] - 1
+    if multi_bboxes.shape[1] > 4:
+        bboxes = multi_bboxes.reshape(n, -1, 4)
+    else:
+        bboxes = np.broadcast_to(multi_bboxes[:, None], (n, nc, 4))
+    scores = multi_scores[:, :-1]
+    labels = np.broadcast_to(np.arange(nc, dtype=np.int64)[None], scores.shape)
+    bboxes, scores, labels = bboxes.reshape(-1, 4), scores.reshape(-1), labels.reshape(-1)
+    inds = np.nonzero(scores > np.float32(score_thr))[0]                      # :54,66-67
+    bboxes, scores, labels = bboxes[inds], scores[inds], labels[inds]
+    if bboxes.size == 0:
+        return np.zeros((0, 5), np.float32), labels
+    dets, keep = D.batched_nms(bboxes, scores, labels, nms_cfg, nms_fn=nms_fn)  # :84
+    if max_num > 0:
+        dets, keep = dets[:max_num], keep[:max_num]
+    return dets, labels[keep]
