@@ -1,0 +1,168 @@
+/* swin_hip.h -- C ABI of the MI355X (gfx950) Swin detection hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own: its
+ * hot path calls torch ATen ops and the third-party mmcv-full extension from Python.
+ * Every entry point below cites the reference call site(s) (file:line under the
+ * upstream repository root) whose device work it replaces; INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless
+ *     stated; the caller owns every buffer (no allocation, no host sync in here);
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call
+ *     returns immediately;
+ *   - `dtype` selects the activation element type: SWIN_F32 (parity path, fp32 math)
+ *     or SWIN_BF16 (bf16 storage, MFMA bf16 products, fp32 accumulation/softmax/LN
+ *     statistics).  Parameters (weights, biases, LN affine, bias table) are fp32;
+ *   - activations are token-major: (B, H, W, C) row-major == (B*H*W, C);
+ *   - return value: SWIN_OK or a SWIN_ERR_* code (nothing was launched on error).
+ */
+#ifndef SWIN_HIP_H
+#define SWIN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWIN_OK 0
+#define SWIN_ERR_BAD_ARG 1      /* null pointer / non-positive size */
+#define SWIN_ERR_UNSUPPORTED 2  /* shape outside what the kernels implement */
+#define SWIN_ERR_LAUNCH 3       /* hipGetLastError() after launch != hipSuccess */
+
+#define SWIN_F32 0
+#define SWIN_BF16 1
+
+#define SWIN_WINDOW 7           /* window_size of every config under configs/swin/ */
+#define SWIN_HEAD_DIM 32        /* C / num_heads in Swin-T/S/B */
+#define SWIN_ATTN_TILE 64       /* 49 tokens padded to the MFMA tile */
+
+/* ABI version, bumped on any signature change. */
+int swin_hip_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the channel dim.   Replaces nn.LayerNorm at
+ * swin_transformer.py:211 (norm1), :253 (norm2), :295 (PatchMerging.norm),
+ * :442 (PatchEmbed.norm), :620 (norm{i}).
+ * x,y: (rows, C) dtype; gamma,beta: (C) f32; mean,rstd: (rows) f32 (saved for bwd; may be NULL).
+ * ---------------------------------------------------------------------------------- */
+int swin_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                       float* mean, float* rstd, int64_t rows, int C, float eps, int dtype, void* stream);
+/* dx = LN'(dy) [+ dres]  : (rows,C) dtype.  dres (nullable) is the gradient arriving at x directly
+ * (the residual branch), folded in here.  dx_scaled (nullable) = scale[b] * dx: the gradient of the
+ * `y` operand of swin_add_layernorm_fwd.  dgamma/dbeta: (C) f32, ACCUMULATED (fp32 atomics). */
+int swin_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, const void* dres, void* dx, void* dx_scaled, const float* scale,
+                       int64_t rows_per_sample, float* dgamma, float* dbeta,
+                       int64_t rows, int C, int dtype, void* stream);
+
+/* Fused residual + LayerNorm:  xo = x + scale[b] * y ;  n = LN(xo).
+ * Replaces swin_transformer.py:252 (`shortcut + drop_path(x)`) followed by :253's norm2, and
+ * :253's residual followed by the next block's :211 norm1.  scale: (B) f32 DropPath factors
+ * (NULL = 1), rows_per_sample = H*W.  n/mean/rstd may be NULL (residual only). */
+int swin_add_layernorm_fwd(const void* x, const void* y, const float* scale, int64_t rows_per_sample,
+                           const float* gamma, const float* beta, void* xo, void* n,
+                           float* mean, float* rstd, int64_t rows, int C, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Window attention core with cyclic shift, padding, window partition/reverse, relative
+ * position bias and shift mask fused.   Replaces swin_transformer.py:214-231 (pad, roll,
+ * window_partition), :129-150 (q*scale, q@k^T, +bias, +mask, softmax, @v), :237-247
+ * (window_reverse, roll back, crop) and BasicLayer's mask construction :371-389.
+ *
+ *   qkv   : (B, H, W, 3C) dtype -- output of the qkv Linear on the UN-padded, UN-shifted
+ *           token grid (channel = which*C + head*32 + d, swin_transformer.py:129)
+ *   qkv_bias : (3C) f32 -- value of a padded token's q|k|v (pad is applied after LN1 so a
+ *           padded token is 0 before the Linear, :211-218); may be NULL iff H%7==0 && W%7==0
+ *   bias_exp : (nH, 64, 64) f32 expanded relative-position bias from swin_rel_bias_expand
+ *   out   : (B, H, W, C) dtype, channel = head*32 + d (:150)
+ *   lse   : (B*nW*nH, 64) f32 log-sum-exp per query (saved for bwd; may be NULL)
+ *   shift : 0 or 3 (window_size//2, :346)
+ * ---------------------------------------------------------------------------------- */
+int swin_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bias_exp, void* out,
+                         float* lse, int B, int H, int W, int C, int nH, int shift, float scale,
+                         int dtype, void* stream);
+
+/* Backward of the above.
+ *   dout  : (B,H,W,C) dtype;  dqkv: (B,H,W,3C) dtype (fully written)
+ *   dbias_exp : (nH,64,64) f32, ACCUMULATED (atomics) -- reduce with swin_rel_bias_reduce
+ *   dqkv_bias_pad : (3C) f32, ACCUMULATED: gradient reaching qkv.bias through padded tokens
+ *                   (may be NULL iff no padding) */
+int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_exp, const float* lse,
+                         const void* dout, void* dqkv, float* dbias_exp, float* dqkv_bias_pad,
+                         int B, int H, int W, int C, int nH, int shift, float scale,
+                         int dtype, void* stream);
+
+/* table (169, nH) f32  ->  bias_exp (nH, 64, 64) f32 laid out [head][key][query] with
+ * -30000 for key >= 49 (folds the 49->64 padding mask into the bias).  Index rule of
+ * swin_transformer.py:101-110.  */
+int swin_rel_bias_expand(const float* table, float* bias_exp, int nH, void* stream);
+/* dbias_exp (nH,64,64) -> dtable (169,nH), ACCUMULATED. */
+int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int nH, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Elementwise pieces of the block.
+ * ---------------------------------------------------------------------------------- */
+/* y = gelu_erf(x + bias)  (nn.GELU, swin_transformer.py:34; bias = fc1.bias, may be NULL). */
+int swin_bias_gelu_fwd(const void* x, const float* bias, void* y, int64_t rows, int C, int dtype, void* stream);
+/* dx = dy * gelu'(x + bias) */
+int swin_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, int64_t rows, int C,
+                       int dtype, void* stream);
+
+/* PatchMerging gather + LayerNorm: swin_transformer.py:284-295.
+ * x (B,H,W,C) -> y (B,ceil(H/2),ceil(W/2),4C) normalised; concat order x0(even,even), x1(odd,even),
+ * x2(even,odd), x3(odd,odd); zero pad for odd H/W.  mean/rstd (rows_out) saved for bwd. */
+int swin_patch_merge_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                            float* rstd, int B, int H, int W, int C, float eps, int dtype, void* stream);
+int swin_patch_merge_ln_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                            const float* rstd, void* dx, float* dgamma, float* dbeta,
+                            int B, int H, int W, int C, int dtype, void* stream);
+
+/* PatchEmbed im2row: img (B,3,Hi,Wi) f32 NCHW -> rows (B*ceil(Hi/4)*ceil(Wi/4), 48) dtype, zero pad
+ * right/bottom (swin_transformer.py:433-438; column index = c*16 + ky*4 + kx = conv weight layout). */
+int swin_patch_im2row(const float* img, void* rows, int B, int Hi, int Wi, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * FPN top-down step: lat_fine += nearest_upsample(lat_coarse)   (fpn.py:188-191), arbitrary target
+ * size (F.interpolate(size=..., mode='nearest')).  channels_last = 0: (N,C,H,W) memory;
+ * 1: (N,H,W,C) memory (the token-major layout the backbone produces).
+ * ---------------------------------------------------------------------------------- */
+int fpn_upsample_add_fwd(void* fine, const void* coarse, int N, int C, int Hf, int Wf, int Hc, int Wc,
+                         int channels_last, int dtype, void* stream);
+/* dcoarse += sum of dfine over each coarse cell's footprint */
+int fpn_upsample_add_bwd(const void* dfine, void* dcoarse, int N, int C, int Hf, int Wf, int Hc, int Wc,
+                         int channels_last, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * mmcv.ops.RoIAlign / roi_align ('avg', aligned flag) -- call sites
+ * base_roi_extractor.py:49-55, single_level_roi_extractor.py:93-97, structures.py:353-354.
+ * rois (K,5) f32 [batch_idx,x1,y1,x2,y2]; arithmetic and output fp32.
+ *   channels_last = 0: input (N,C,H,W), output (K,C,ph,pw)      (mmcv's memory layout)
+ *   channels_last = 1: input (N,H,W,C), output (K,ph,pw,C)      (coalesced along C)
+ *   in_dtype: element type of `input` (SWIN_F32 or SWIN_BF16, converted on load -- the
+ *             reference's force_fp32 at single_level_roi_extractor.py:53).
+ * ---------------------------------------------------------------------------------- */
+int roi_align_fwd(const void* input, const float* rois, float* output, int N, int C, int H, int W,
+                  int K, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
+                  int channels_last, int in_dtype, void* stream);
+/* grad_input f32 in the same memory layout as the input, zeroed by the caller; fp32 atomics. */
+int roi_align_bwd(const float* grad_output, const float* rois, float* grad_input, int N, int C, int H, int W,
+                  int K, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
+                  int channels_last, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * mmcv.ops.nms device part -- call sites rpn_head.py:233, bbox_nms.py:84 (through batched_nms).
+ * boxes_sorted (n,4) f32 ALREADY in descending-score order (stable sort done by the host
+ * layer).  Writes keep_flags (n) uint8 (1 = kept) and *num_kept (device int32).
+ * workspace: >= swin_nms_workspace_bytes(n) bytes of device memory.
+ * The whole greedy reduction runs on the device (mmcv copies the bitmask to the host).
+ * ---------------------------------------------------------------------------------- */
+int64_t swin_nms_workspace_bytes(int64_t n);
+int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int offset, uint8_t* keep_flags,
+               int32_t* num_kept, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWIN_HIP_H */

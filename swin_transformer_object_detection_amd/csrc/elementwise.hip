@@ -1,0 +1,248 @@
+// HBM-bound elementwise / gather kernels of the Swin block and the FPN top-down path.
+// All of them move 16 bytes per lane per access (coalesced dwordx4).
+#include "common.h"
+
+static inline int ew_blocks(int64_t n_items) {
+    int64_t b = (n_items + 255) / 256;
+    return (int)(b < 4096 ? (b > 0 ? b : 1) : 4096);
+}
+
+// ---------------------------------------------------------------- bias + GELU(erf)
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+    float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+    return cdf + v * pdf;
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void bias_gelu_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                        const T* __restrict__ dy, T* __restrict__ out, int64_t nvec,
+                                                        int vec_per_row) {
+    constexpr int VEC = Vec16<T>::N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        int col = (int)(i % vec_per_row) * VEC;
+        Vec16<T> v, o, g;
+        v.load(x + i * VEC);
+        if (BWD) g.load(dy + i * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float a = v.get(e) + (bias ? bias[col + e] : 0.f);
+            o.set(e, BWD ? g.get(e) * gelu_grad_f(a) : gelu_f(a));
+        }
+        o.store(out + i * VEC);
+    }
+}
+
+template <bool BWD>
+static int bias_gelu_launch(const void* x, const float* bias, const void* dy, void* out, int64_t rows, int C, int dtype,
+                            void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || (BWD && !dy)) return SWIN_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SWIN_BF16) {
+        if (C % 8) return SWIN_ERR_UNSUPPORTED;
+        int64_t nvec = rows * (C / 8);
+        bias_gelu_kernel<bf16, BWD><<<ew_blocks(nvec), 256, 0, s>>>((const bf16*)x, bias, (const bf16*)dy, (bf16*)out, nvec,
+                                                                   C / 8);
+    } else if (dtype == SWIN_F32) {
+        if (C % 4) return SWIN_ERR_UNSUPPORTED;
+        int64_t nvec = rows * (C / 4);
+        bias_gelu_kernel<float, BWD><<<ew_blocks(nvec), 256, 0, s>>>((const float*)x, bias, (const float*)dy, (float*)out,
+                                                                    nvec, C / 4);
+    } else return SWIN_ERR_UNSUPPORTED;
+    return swin_launch_status();
+}
+
+extern "C" int swin_bias_gelu_fwd(const void* x, const float* bias, void* y, int64_t rows, int C, int dtype, void* stream) {
+    return bias_gelu_launch<false>(x, bias, nullptr, y, rows, C, dtype, stream);
+}
+extern "C" int swin_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, int64_t rows, int C,
+                                  int dtype, void* stream) {
+    return bias_gelu_launch<true>(x, bias, dy, dx, rows, C, dtype, stream);
+}
+
+// ---------------------------------------------------------------- PatchEmbed im2row (k=4, s=4, 3 channels)
+// one thread per (row, c, ky): 4 consecutive pixels -> 4 consecutive row elements
+template <typename T>
+__global__ __launch_bounds__(256) void patch_im2row_kernel(const float* __restrict__ img, T* __restrict__ rows, int B, int Hi,
+                                                           int Wi, int Ho, int Wo) {
+    int64_t n = (int64_t)B * Ho * Wo * 12;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int sub = (int)(i % 12);
+        int64_t r = i / 12;
+        int c = sub >> 2, ky = sub & 3;
+        int xo = (int)(r % Wo);
+        int64_t t = r / Wo;
+        int yo = (int)(t % Ho);
+        int b = (int)(t / Ho);
+        int y = yo * 4 + ky;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (y < Hi) {
+            const float* p = img + (((int64_t)b * 3 + c) * Hi + y) * Wi + xo * 4;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx)
+                if (xo * 4 + kx < Wi) v[kx] = p[kx];
+        }
+        T* o = rows + r * 48 + c * 16 + ky * 4;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) Elt<T>::st(o + kx, v[kx]);
+    }
+}
+
+extern "C" int swin_patch_im2row(const float* img, void* rows, int B, int Hi, int Wi, int dtype, void* stream) {
+    if (!img || !rows || B <= 0 || Hi <= 0 || Wi <= 0) return SWIN_ERR_BAD_ARG;
+    int Ho = (Hi + 3) / 4, Wo = (Wi + 3) / 4;
+    int64_t n = (int64_t)B * Ho * Wo * 12;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SWIN_BF16) patch_im2row_kernel<bf16><<<ew_blocks(n), 256, 0, s>>>(img, (bf16*)rows, B, Hi, Wi, Ho, Wo);
+    else if (dtype == SWIN_F32) patch_im2row_kernel<float><<<ew_blocks(n), 256, 0, s>>>(img, (float*)rows, B, Hi, Wi, Ho, Wo);
+    else return SWIN_ERR_UNSUPPORTED;
+    return swin_launch_status();
+}
+
+// ---------------------------------------------------------------- FPN top-down: fine += nearest_up(coarse)
+// torch 'nearest' with an explicit size: src = min(floor(dst * (float)in/out), in-1)   (fpn.py:188-191)
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+    int s = (int)floorf((float)dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+
+// channels-last memory (N,H,W,C): one thread per 16-byte channel vector
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_nhwc_kernel(T* __restrict__ fine, const T* __restrict__ coarse, int N, int C,
+                                                                int Hf, int Wf, int Hc, int Wc, float sh, float sw) {
+    constexpr int VEC = Vec16<T>::N;
+    const int vpc = C / VEC;
+    int64_t n = (int64_t)N * Hf * Wf * vpc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int cv = (int)(i % vpc);
+        int64_t t = i / vpc;
+        int x = (int)(t % Wf); t /= Wf;
+        int y = (int)(t % Hf);
+        int b = (int)(t / Hf);
+        int ys = nearest_src(y, sh, Hc), xs = nearest_src(x, sw, Wc);
+        Vec16<T> f, c;
+        f.load(fine + i * VEC);
+        c.load(coarse + ((((int64_t)b * Hc + ys) * Wc + xs) * vpc + cv) * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f.set(e, f.get(e) + c.get(e));
+        f.store(fine + i * VEC);
+    }
+}
+
+// contiguous NCHW memory: one thread per element
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_nchw_kernel(T* __restrict__ fine, const T* __restrict__ coarse, int64_t NC,
+                                                                int Hf, int Wf, int Hc, int Wc, float sh, float sw) {
+    int64_t n = NC * Hf * Wf;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int x = (int)(i % Wf);
+        int64_t t = i / Wf;
+        int y = (int)(t % Hf);
+        int64_t nc = t / Hf;
+        int ys = nearest_src(y, sh, Hc), xs = nearest_src(x, sw, Wc);
+        Elt<T>::st(fine + i, Elt<T>::ld(fine + i) + Elt<T>::ld(coarse + (nc * Hc + ys) * Wc + xs));
+    }
+}
+
+// backward: dcoarse[yc,xc] += sum of dfine over the fine cells that read (yc,xc)
+__device__ __forceinline__ void footprint(int c, float scale, int fine_size, int coarse_size, int& lo, int& hi) {
+    // candidates around c/scale; exact membership is re-tested with nearest_src by the caller
+    lo = (int)floorf((float)c / scale) - 1; if (lo < 0) lo = 0;
+    hi = (int)ceilf((float)(c + 1) / scale) + 1; if (hi > fine_size) hi = fine_size;
+    (void)coarse_size;
+}
+
+template <typename T, bool NHWC>
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const T* __restrict__ dfine, T* __restrict__ dcoarse, int N, int C,
+                                                               int Hf, int Wf, int Hc, int Wc, float sh, float sw) {
+    constexpr int VEC = NHWC ? Vec16<T>::N : 1;
+    const int vpc = NHWC ? C / VEC : 1;
+    int64_t n = NHWC ? (int64_t)N * Hc * Wc * vpc : (int64_t)N * C * Hc * Wc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int cv = 0, xc, yc;
+        int64_t outer;
+        int64_t t = i;
+        if (NHWC) { cv = (int)(t % vpc); t /= vpc; }
+        xc = (int)(t % Wc); t /= Wc;
+        yc = (int)(t % Hc); outer = t / Hc;   // NHWC: batch index; NCHW: n*C + c
+        int y0, y1, x0, x1;
+        footprint(yc, sh, Hf, Hc, y0, y1);
+        footprint(xc, sw, Wf, Wc, x0, x1);
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        if (NHWC) {
+            Vec16<T> cur; cur.load(dcoarse + i * Vec16<T>::N);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = cur.get(e);
+        } else {
+            acc[0] = Elt<T>::ld(dcoarse + i);
+        }
+        for (int y = y0; y < y1; ++y) {
+            if (nearest_src(y, sh, Hc) != yc) continue;
+            for (int x = x0; x < x1; ++x) {
+                if (nearest_src(x, sw, Wc) != xc) continue;
+                if (NHWC) {
+                    Vec16<T> d; d.load(dfine + (((outer * Hf + y) * Wf + x) * vpc + cv) * Vec16<T>::N);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += d.get(e);
+                } else {
+                    acc[0] += Elt<T>::ld(dfine + (outer * Hf + y) * Wf + x);
+                }
+            }
+        }
+        if (NHWC) {
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+            o.store(dcoarse + i * Vec16<T>::N);
+        } else {
+            Elt<T>::st(dcoarse + i, acc[0]);
+        }
+    }
+}
+
+template <typename T>
+static int upsample_launch(void* fine, const void* coarse, int N, int C, int Hf, int Wf, int Hc, int Wc,
+                           int channels_last, bool bwd, hipStream_t s) {
+    float sh = (float)Hc / (float)Hf, sw = (float)Wc / (float)Wf;
+    if (channels_last && C % Vec16<T>::N) return SWIN_ERR_UNSUPPORTED;
+    if (!bwd) {
+        if (channels_last) {
+            int64_t n = (int64_t)N * Hf * Wf * (C / Vec16<T>::N);
+            upsample_add_nhwc_kernel<T><<<ew_blocks(n), 256, 0, s>>>((T*)fine, (const T*)coarse, N, C, Hf, Wf, Hc, Wc, sh, sw);
+        } else {
+            int64_t n = (int64_t)N * C * Hf * Wf;
+            upsample_add_nchw_kernel<T><<<ew_blocks(n), 256, 0, s>>>((T*)fine, (const T*)coarse, (int64_t)N * C, Hf, Wf, Hc, Wc,
+                                                                    sh, sw);
+        }
+    } else {
+        // here `fine` is dfine (read) and `coarse` is dcoarse (read-modify-write)
+        if (channels_last) {
+            int64_t n = (int64_t)N * Hc * Wc * (C / Vec16<T>::N);
+            upsample_add_bwd_kernel<T, true><<<ew_blocks(n), 256, 0, s>>>((const T*)fine, (T*)coarse, N, C, Hf, Wf, Hc, Wc, sh, sw);
+        } else {
+            int64_t n = (int64_t)N * C * Hc * Wc;
+            upsample_add_bwd_kernel<T, false><<<ew_blocks(n), 256, 0, s>>>((const T*)fine, (T*)coarse, N, C, Hf, Wf, Hc, Wc, sh,
+                                                                          sw);
+        }
+    }
+    return swin_launch_status();
+}
+
+extern "C" int fpn_upsample_add_fwd(void* fine, const void* coarse, int N, int C, int Hf, int Wf, int Hc, int Wc,
+                                    int channels_last, int dtype, void* stream) {
+    if (!fine || !coarse || N <= 0 || C <= 0 || Hf <= 0 || Wf <= 0 || Hc <= 0 || Wc <= 0) return SWIN_ERR_BAD_ARG;
+    if (dtype == SWIN_BF16) return upsample_launch<bf16>(fine, coarse, N, C, Hf, Wf, Hc, Wc, channels_last, false, (hipStream_t)stream);
+    if (dtype == SWIN_F32) return upsample_launch<float>(fine, coarse, N, C, Hf, Wf, Hc, Wc, channels_last, false, (hipStream_t)stream);
+    return SWIN_ERR_UNSUPPORTED;
+}
+
+extern "C" int fpn_upsample_add_bwd(const void* dfine, void* dcoarse, int N, int C, int Hf, int Wf, int Hc, int Wc,
+                                    int channels_last, int dtype, void* stream) {
+    if (!dfine || !dcoarse || N <= 0 || C <= 0 || Hf <= 0 || Wf <= 0 || Hc <= 0 || Wc <= 0) return SWIN_ERR_BAD_ARG;
+    if (dtype == SWIN_BF16) return upsample_launch<bf16>((void*)dfine, dcoarse, N, C, Hf, Wf, Hc, Wc, channels_last, true, (hipStream_t)stream);
+    if (dtype == SWIN_F32) return upsample_launch<float>((void*)dfine, dcoarse, N, C, Hf, Wf, Hc, Wc, channels_last, true, (hipStream_t)stream);
+    return SWIN_ERR_UNSUPPORTED;
+}

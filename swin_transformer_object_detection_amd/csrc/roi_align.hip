@@ -1,0 +1,221 @@
+// RoIAlign ('avg' pooling, aligned flag, adaptive sampling grid) for gfx950.
+// Semantics: mmcv.ops.roi_align as called at base_roi_extractor.py:49-55 /
+// single_level_roi_extractor.py:93-97 / structures.py:353-354 of the reference.
+//
+// Two memory layouts for the feature map and the output:
+//   channels_last = 0 : input (N,C,H,W), output (K,C,ph,pw)   -- mmcv's layout, one thread per output element
+//   channels_last = 1 : input (N,H,W,C), output (K,ph,pw,C)   -- lanes run along C: every bilinear corner is one
+//                       coalesced read, and the backward's fp32 atomics are 256-byte contiguous per wave
+// Features may be fp32 or bf16 (converted on load, which is what the reference's force_fp32 does);
+// output and all arithmetic are fp32.  Gradient w.r.t. features is fp32 (atomics), caller zeroes it.
+#include "common.h"
+
+struct RoiGeom {
+    float start_w, start_h, bin_w, bin_h;
+    int grid_h, grid_w, batch;
+    float count;
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int aligned, int ph, int pw, int sampling_ratio) {
+    RoiGeom g;
+    g.batch = (int)roi[0];
+    float off = aligned ? 0.5f : 0.0f;
+    g.start_w = roi[1] * scale - off;
+    g.start_h = roi[2] * scale - off;
+    float end_w = roi[3] * scale - off;
+    float end_h = roi[4] * scale - off;
+    float rw = end_w - g.start_w, rh = end_h - g.start_h;
+    if (!aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+    g.bin_h = rh / (float)ph;
+    g.bin_w = rw / (float)pw;
+    g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph);
+    g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw);
+    int c = g.grid_h * g.grid_w;
+    g.count = (float)(c > 1 ? c : 1);
+    return g;
+}
+
+struct Bilin { int yl, xl, yh, xh; float w1, w2, w3, w4; bool valid; };
+
+__device__ __forceinline__ Bilin bilin_setup(int H, int W, float y, float x) {
+    Bilin b;
+    b.valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+    if (!b.valid) { b.yl = b.xl = b.yh = b.xh = 0; b.w1 = b.w2 = b.w3 = b.w4 = 0.f; return b; }
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+    b.yl = yl; b.xl = xl; b.yh = yh; b.xh = xh;
+    b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
+    return b;
+}
+
+// ----------------------------------------------------------------------------- NCHW
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_nchw(const T* __restrict__ in, const float* __restrict__ rois,
+                                                          float* __restrict__ out, int C, int H, int W, int64_t total,
+                                                          int ph, int pw, float scale, int sr, int aligned) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int j = (int)(idx % pw), i = (int)((idx / pw) % ph);
+        int c = (int)((idx / pw / ph) % C);
+        int64_t k = idx / pw / ph / C;
+        RoiGeom g = roi_geom(rois + 5 * k, scale, aligned, ph, pw, sr);
+        const T* p = in + ((int64_t)g.batch * C + c) * H * W;
+        float acc = 0.f;
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                Bilin b = bilin_setup(H, W, y, x);
+                if (!b.valid) continue;
+                acc += b.w1 * Elt<T>::ld(p + b.yl * W + b.xl) + b.w2 * Elt<T>::ld(p + b.yl * W + b.xh) +
+                       b.w3 * Elt<T>::ld(p + b.yh * W + b.xl) + b.w4 * Elt<T>::ld(p + b.yh * W + b.xh);
+            }
+        }
+        out[idx] = acc / g.count;
+    }
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_nchw(const float* __restrict__ gout, const float* __restrict__ rois,
+                                                          float* __restrict__ gin, int C, int H, int W, int64_t total,
+                                                          int ph, int pw, float scale, int sr, int aligned) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int j = (int)(idx % pw), i = (int)((idx / pw) % ph);
+        int c = (int)((idx / pw / ph) % C);
+        int64_t k = idx / pw / ph / C;
+        RoiGeom g = roi_geom(rois + 5 * k, scale, aligned, ph, pw, sr);
+        float* p = gin + ((int64_t)g.batch * C + c) * H * W;
+        float go = gout[idx];
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                Bilin b = bilin_setup(H, W, y, x);
+                if (!b.valid) continue;
+                atomicAdd(p + b.yl * W + b.xl, go * b.w1 / g.count);
+                atomicAdd(p + b.yl * W + b.xh, go * b.w2 / g.count);
+                atomicAdd(p + b.yh * W + b.xl, go * b.w3 / g.count);
+                atomicAdd(p + b.yh * W + b.xh, go * b.w4 / g.count);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- NHWC
+// one thread per (k, i, j, 4-channel group); a wave covers 256 consecutive channels of one bin
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const T* __restrict__ in, const float* __restrict__ rois,
+                                                          float* __restrict__ out, int C, int H, int W, int64_t total,
+                                                          int ph, int pw, float scale, int sr, int aligned) {
+    const int cg = C / 4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int c4 = (int)(idx % cg) * 4;
+        int64_t t = idx / cg;
+        int j = (int)(t % pw); t /= pw;
+        int i = (int)(t % ph);
+        int64_t k = t / ph;
+        RoiGeom g = roi_geom(rois + 5 * k, scale, aligned, ph, pw, sr);
+        const T* p = in + (int64_t)g.batch * H * W * C + c4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                Bilin b = bilin_setup(H, W, y, x);
+                if (!b.valid) continue;
+                const T* p1 = p + ((int64_t)b.yl * W + b.xl) * C;
+                const T* p2 = p + ((int64_t)b.yl * W + b.xh) * C;
+                const T* p3 = p + ((int64_t)b.yh * W + b.xl) * C;
+                const T* p4 = p + ((int64_t)b.yh * W + b.xh) * C;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[e] += b.w1 * Elt<T>::ld(p1 + e) + b.w2 * Elt<T>::ld(p2 + e) + b.w3 * Elt<T>::ld(p3 + e) +
+                              b.w4 * Elt<T>::ld(p4 + e);
+            }
+        }
+        float4 o = {acc[0] / g.count, acc[1] / g.count, acc[2] / g.count, acc[3] / g.count};
+        *(float4*)(out + idx * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restrict__ gout, const float* __restrict__ rois,
+                                                          float* __restrict__ gin, int C, int H, int W, int64_t total,
+                                                          int ph, int pw, float scale, int sr, int aligned) {
+    // one thread per (k, i, j, channel): consecutive lanes = consecutive channels = contiguous atomics
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int c = (int)(idx % C);
+        int64_t t = idx / C;
+        int j = (int)(t % pw); t /= pw;
+        int i = (int)(t % ph);
+        int64_t k = t / ph;
+        RoiGeom g = roi_geom(rois + 5 * k, scale, aligned, ph, pw, sr);
+        float* p = gin + (int64_t)g.batch * H * W * C + c;
+        float go = gout[idx];
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                Bilin b = bilin_setup(H, W, y, x);
+                if (!b.valid) continue;
+                atomicAdd(p + ((int64_t)b.yl * W + b.xl) * C, go * b.w1 / g.count);
+                atomicAdd(p + ((int64_t)b.yl * W + b.xh) * C, go * b.w2 / g.count);
+                atomicAdd(p + ((int64_t)b.yh * W + b.xl) * C, go * b.w3 / g.count);
+                atomicAdd(p + ((int64_t)b.yh * W + b.xh) * C, go * b.w4 / g.count);
+            }
+        }
+    }
+}
+
+static inline int ra_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 65535 ? (b > 0 ? b : 1) : 65535);
+}
+
+extern "C" int roi_align_fwd(const void* input, const float* rois, float* output, int N, int C, int H, int W, int K,
+                             int ph, int pw, float spatial_scale, int sampling_ratio, int aligned, int channels_last,
+                             int in_dtype, void* stream) {
+    if (K == 0) return SWIN_OK;
+    if (!input || !rois || !output || N <= 0 || C <= 0 || H <= 0 || W <= 0 || K < 0 || ph <= 0 || pw <= 0)
+        return SWIN_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (channels_last) {
+        if (C % 4) return SWIN_ERR_UNSUPPORTED;
+        int64_t total = (int64_t)K * ph * pw * (C / 4);
+        if (in_dtype == SWIN_F32)
+            roi_align_fwd_nhwc<float><<<ra_blocks(total), 256, 0, s>>>((const float*)input, rois, output, C, H, W, total, ph, pw,
+                                                                      spatial_scale, sampling_ratio, aligned);
+        else if (in_dtype == SWIN_BF16)
+            roi_align_fwd_nhwc<bf16><<<ra_blocks(total), 256, 0, s>>>((const bf16*)input, rois, output, C, H, W, total, ph, pw,
+                                                                     spatial_scale, sampling_ratio, aligned);
+        else return SWIN_ERR_UNSUPPORTED;
+    } else {
+        int64_t total = (int64_t)K * C * ph * pw;
+        if (in_dtype == SWIN_F32)
+            roi_align_fwd_nchw<float><<<ra_blocks(total), 256, 0, s>>>((const float*)input, rois, output, C, H, W, total, ph, pw,
+                                                                      spatial_scale, sampling_ratio, aligned);
+        else if (in_dtype == SWIN_BF16)
+            roi_align_fwd_nchw<bf16><<<ra_blocks(total), 256, 0, s>>>((const bf16*)input, rois, output, C, H, W, total, ph, pw,
+                                                                     spatial_scale, sampling_ratio, aligned);
+        else return SWIN_ERR_UNSUPPORTED;
+    }
+    return swin_launch_status();
+}
+
+extern "C" int roi_align_bwd(const float* grad_output, const float* rois, float* grad_input, int N, int C, int H, int W,
+                             int K, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
+                             int channels_last, void* stream) {
+    if (K == 0) return SWIN_OK;
+    if (!grad_output || !rois || !grad_input || N <= 0 || C <= 0 || H <= 0 || W <= 0 || K < 0 || ph <= 0 || pw <= 0)
+        return SWIN_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t total = (int64_t)K * C * ph * pw;
+    if (channels_last)
+        roi_align_bwd_nhwc<<<ra_blocks(total), 256, 0, s>>>(grad_output, rois, grad_input, C, H, W, total, ph, pw,
+                                                           spatial_scale, sampling_ratio, aligned);
+    else
+        roi_align_bwd_nchw<<<ra_blocks(total), 256, 0, s>>>(grad_output, rois, grad_input, C, H, W, total, ph, pw,
+                                                           spatial_scale, sampling_ratio, aligned);
+    return swin_launch_status();
+}

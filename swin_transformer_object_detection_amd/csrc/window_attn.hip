@@ -1,0 +1,767 @@
+// Window attention core for gfx950: cyclic shift + pad + window partition/reverse +
+// relative-position bias + shift mask + softmax + PV in one kernel, reading the qkv
+// projection and writing the attention output on the NATURAL (B,H,W) token grid.
+//
+// Reference semantics: mmdet/models/backbones/swin_transformer.py:129-150 (core),
+// :214-231 / :237-247 (pad, roll, partition, reverse, crop), :371-389 (mask).
+//
+// bf16 path (one wave per (window, head), persistent over windows of one head):
+//   S^T = K Q^T   as 2x2 tiles of v_mfma_f32_32x32x16_bf16 (49 -> 64 padding), query on the
+//   lane, key on the accumulator registers, so the softmax reduction is in-lane plus one
+//   lane^32 exchange and P^T is directly the B operand of  O^T = V^T P^T  (no LDS trip).
+//   The expanded bias tile of the wave's head stays in 64 VGPRs across its windows.
+// fp32 path: exact-fp32 VALU kernel (parity path for the 1e-4 gate).
+#include "common.h"
+
+#define NTOK 49
+#define TILE 64
+#define HD 32
+#define LROW 40  // LDS row stride in bf16 elements (80 B: conflict-free ds_read_b128 of 32-wide rows)
+#define NEG_BIG (-30000.0f)
+
+struct WinGeom {
+    int B, H, W, C, nH, shift, Hp, Wp, nWh, nWw, nW;
+};
+
+static inline WinGeom make_geom(int B, int H, int W, int C, int nH, int shift) {
+    WinGeom g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.nH = nH; g.shift = shift;
+    g.nWh = (H + 6) / 7; g.nWw = (W + 6) / 7;
+    g.Hp = g.nWh * 7; g.Wp = g.nWw * 7; g.nW = g.nWh * g.nWw;
+    return g;
+}
+
+// token `t` (0..48, row-major 7x7) of window (b, wr, wc) on the shifted padded grid ->
+// linear token index on the natural grid, or -1 for a padded token.
+__device__ __forceinline__ int token_src(const WinGeom& g, int b, int wr, int wc, int t) {
+    int th = t / 7, tw = t - th * 7;
+    int r = wr * 7 + th + g.shift; if (r >= g.Hp) r -= g.Hp;   // roll(-shift): shifted[r] = x[(r+shift)%Hp]
+    int c = wc * 7 + tw + g.shift; if (c >= g.Wp) c -= g.Wp;
+    if (r >= g.H || c >= g.W) return -1;
+    return (b * g.H + r) * g.W + c;
+}
+
+// ------------------------------------------------------------------------------------
+// relative position bias: table (169,nH) <-> expanded (nH,64,64) [head][key][query]
+// ------------------------------------------------------------------------------------
+__global__ void rel_bias_expand_kernel(const float* __restrict__ table, float* __restrict__ out, int nH) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nH * TILE * TILE) return;
+    int q = i & 63, k = (i >> 6) & 63, h = i >> 12;
+    float v = NEG_BIG;
+    if (k < NTOK) {
+        v = 0.f;
+        if (q < NTOK) {
+            int qh = q / 7, qw = q % 7, kh = k / 7, kw = k % 7;
+            int idx = (qh - kh + 6) * 13 + (qw - kw + 6);   // swin_transformer.py:105-110
+            v = table[idx * nH + h];
+        }
+    }
+    out[i] = v;
+}
+
+__global__ void rel_bias_reduce_kernel(const float* __restrict__ dexp, float* __restrict__ dtable, int nH) {
+    // one thread per (idx, head): sum the (q,k) pairs that map to idx
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 169 * nH) return;
+    int h = i % nH, idx = i / nH;
+    int dh = idx / 13 - 6, dw = idx % 13 - 6;
+    float acc = 0.f;
+    for (int kh = 0; kh < 7; ++kh) {
+        int qh = kh + dh;
+        if (qh < 0 || qh >= 7) continue;
+        for (int kw = 0; kw < 7; ++kw) {
+            int qw = kw + dw;
+            if (qw < 0 || qw >= 7) continue;
+            acc += dexp[(h * TILE + kh * 7 + kw) * TILE + qh * 7 + qw];
+        }
+    }
+    dtable[i] += acc;
+}
+
+// ------------------------------------------------------------------------------------
+// bf16 forward
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 bias_to_bf16x8(const float* p) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16)p[e];
+    return r;
+}
+
+// mask bits for the 64 accumulator elements a lane owns: bit (kt*2+qt)*16+reg set when query and key
+// fall on different sides of the "last 3 rows" (resp. columns) boundary inside a window.
+__device__ __forceinline__ void lane_mask_bits(int lane, uint64_t& mrow, uint64_t& mcol) {
+    int c = lane & 31, h = lane >> 5;
+    mrow = 0; mcol = 0;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                int q = 32 * qt + c;
+                int qh = q / 7, qw = q % 7, kh = key / 7, kw = key % 7;
+                uint64_t bit = 1ull << ((kt * 2 + qt) * 16 + reg);
+                if ((qh >= 4) != (kh >= 4)) mrow |= bit;
+                if ((qw >= 4) != (kw >= 4)) mcol |= bit;
+            }
+}
+
+__global__ __launch_bounds__(256) void win_attn_fwd_bf16_kernel(
+    const bf16* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
+    bf16* __restrict__ out, float* __restrict__ lse, WinGeom g, float scale, int n_tasks) {
+    __shared__ __attribute__((aligned(16))) bf16 lds[4][3][TILE][LROW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, h = lane >> 5;
+    bf16(*Qs)[LROW] = lds[wave][0];
+    bf16(*Ks)[LROW] = lds[wave][1];
+    bf16(*Vs)[LROW] = lds[wave][2];
+
+    // zero the wave's LDS (rows 49..63 must read as 0 for the padded MFMA tiles)
+    {
+        uint4 z = {0, 0, 0, 0};
+        uint4* p = (uint4*)&lds[wave][0][0][0];
+        for (int i = lane; i < 3 * TILE * LROW * 2 / 16; i += WAVE) p[i] = z;
+    }
+    const int n_waves = gridDim.x * 4;   // host guarantees n_waves % nH == 0
+    int task = blockIdx.x * 4 + wave;
+    if (task >= n_tasks) return;
+    const int head = task % g.nH;
+
+    // expanded bias of this head, in accumulator layout, kept in registers
+    float biasr[2][2][16];
+    {
+        const float* bp = bias_exp + (size_t)head * TILE * TILE;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    biasr[kt][qt][reg] = bp[key * TILE + 32 * qt + c];
+                }
+    }
+    uint64_t mrow = 0, mcol = 0;
+    if (g.shift > 0) lane_mask_bits(lane, mrow, mcol);
+
+    // staging role of this lane: 5 tokens per round, 12 16-byte pieces per token (q|k|v x 4)
+    const int tokr = lane / 12, rem = lane - tokr * 12;
+    const int which = rem >> 2, part = rem & 3;
+    const bool stager = lane < 60;
+    const int C3 = 3 * g.C;
+    __builtin_amdgcn_wave_barrier();
+
+    for (; task < n_tasks; task += n_waves) {
+        const int win = task / g.nH;
+        const int b = win / g.nW, wrem = win - b * g.nW;
+        const int wr = wrem / g.nWw, wc = wrem - wr * g.nWw;
+
+        // ---- stage q,k,v head slices (49 x 32 each) into LDS -------------------------------
+        bf16x8 stg[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            int t = 5 * i + tokr;
+            if (stager && t < NTOK) {
+                int src = token_src(g, b, wr, wc, t);
+                int ch = which * g.C + head * HD + part * 8;
+                if (src >= 0) stg[i] = *(const bf16x8*)(qkv + (size_t)src * C3 + ch);
+                else stg[i] = bias_to_bf16x8(qkv_bias + ch);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            int t = 5 * i + tokr;
+            if (stager && t < NTOK) *(bf16x8*)&lds[wave][which][t][part * 8] = stg[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- S^T = K Q^T ---------------------------------------------------------------------
+        bf16x8 qf[2][2], kf[2][2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                qf[t2][s] = *(const bf16x8*)&Qs[32 * t2 + c][16 * s + 8 * h];
+                kf[t2][s] = *(const bf16x8*)&Ks[32 * t2 + c][16 * s + 8 * h];
+            }
+        f32x16 sacc[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x16 a = {0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], a, 0, 0, 0);
+                sacc[kt][qt] = a;
+            }
+
+        // ---- scale + bias (+ mask), softmax over keys (registers + lane^32) -------------------
+        uint64_t mbits = 0;
+        if (g.shift > 0) {
+            if (wr == g.nWh - 1) mbits |= mrow;
+            if (wc == g.nWw - 1) mbits |= mcol;
+        }
+        float inv[2], lsev[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float m = NEG_BIG;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float v = sacc[kt][qt][reg] * scale + biasr[kt][qt][reg];
+                    if ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1) v += -100.0f;   // swin_transformer.py:389
+                    sacc[kt][qt][reg] = v;
+                    m = fmaxf(m, v);
+                }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float p = __expf(sacc[kt][qt][reg] - m);
+                    sacc[kt][qt][reg] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 32);
+            inv[qt] = 1.0f / sum;
+            lsev[qt] = m + __logf(sum);
+        }
+
+        // ---- O^T = V^T P^T  (P^T accumulator registers are the B operand) ---------------------
+        f32x16 oacc[2] = {{0}, {0}};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 vf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vf[j] = Vs[32 * kt + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)][c];
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][qt][8 * s + j];
+                    oacc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[qt], 0, 0, 0);
+                }
+            }
+
+        // ---- write O (window_reverse + roll back + crop == scatter to the source position) ----
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            int q = 32 * qt + c;
+            if (q < NTOK) {
+                int src = token_src(g, b, wr, wc, q);
+                if (src >= 0) {
+                    bf16* op = out + (size_t)src * g.C + head * HD + 4 * h;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        bf16x4 o4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = (bf16)(oacc[qt][4 * gq + e] * inv[qt]);
+                        *(bf16x4*)(op + 8 * gq) = o4;
+                    }
+                }
+                if (lse != nullptr && h == 0) lse[(size_t)task * TILE + q] = lsev[qt];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// fp32 forward (parity path): one 64-thread block per (window, head), thread = query
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void win_attn_fwd_f32_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
+    float* __restrict__ out, float* __restrict__ lse, WinGeom g, float scale) {
+    __shared__ float Ks[NTOK][HD + 1];
+    __shared__ float Vs[NTOK][HD + 1];
+    __shared__ int srcs[NTOK];
+    const int task = blockIdx.x, t = threadIdx.x;
+    const int head = task % g.nH, win = task / g.nH;
+    const int b = win / g.nW, wrem = win - b * g.nW;
+    const int wr = wrem / g.nWw, wc = wrem - wr * g.nWw;
+    const int C3 = 3 * g.C;
+    float q[HD];
+    int src = -1;
+    if (t < NTOK) {
+        src = token_src(g, b, wr, wc, t);
+        srcs[t] = src;
+        const float* base = src >= 0 ? qkv + (size_t)src * C3 : qkv_bias;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            q[d] = base[head * HD + d] * scale;                 // q = q * scale  (:132)
+            Ks[t][d] = base[g.C + head * HD + d];
+            Vs[t][d] = base[2 * g.C + head * HD + d];
+        }
+    }
+    __syncthreads();
+    if (t >= NTOK) return;
+    const float* bp = bias_exp + (size_t)head * TILE * TILE;
+    const bool lastr = g.shift > 0 && wr == g.nWh - 1, lastc = g.shift > 0 && wc == g.nWw - 1;
+    const int qh = t / 7, qw = t % 7;
+    float s[NTOK];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NTOK; ++k) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) a = fmaf(q[d], Ks[k][d], a);
+        a += bp[k * TILE + t];
+        int kh = k / 7, kw = k % 7;
+        if ((lastr && ((qh >= 4) != (kh >= 4))) || (lastc && ((qw >= 4) != (kw >= 4)))) a += -100.0f;
+        s[k] = a;
+        m = fmaxf(m, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NTOK; ++k) { s[k] = expf(s[k] - m); sum += s[k]; }
+    float invs = 1.0f / sum;
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NTOK; ++k) {
+        float p = s[k] * invs;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = fmaf(p, Vs[k][d], o[d]);
+    }
+    if (src >= 0) {
+        float* op = out + (size_t)src * g.C + head * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) op[d] = o[d];
+    }
+    if (lse != nullptr) lse[(size_t)task * TILE + t] = m + logf(sum);
+}
+
+// ------------------------------------------------------------------------------------
+// bf16 backward: one wave per (window, head), persistent over the windows of one head.
+//   phase A (query on the lane):  S^T, P^T = exp(S^T - lse), dP^T = V dO^T, delta = sum_k P dP,
+//       dS^T = P^T (dP^T - delta);  dbias += dS^T (registers);  dQ^T = scale * K^T dS^T  with dS^T
+//       taken straight from the accumulator registers as the B operand;
+//   phase B: P^T and scale*dS^T go through LDS once ([key][query] bf16 tiles) and come back as
+//       row-major B operands of  dV^T = dO^T P  and  dK^T = Q^T dS.
+// ------------------------------------------------------------------------------------
+#define PROW 72   // row stride (bf16 elements) of the 64x64 P^T / dS^T tiles: 144 B
+
+__device__ __forceinline__ bf16x8 lds_col_frag(const bf16 (*tile)[LROW], int row0, int h, int col) {
+    // 8 rows {row0 + 8*(j>>2) + 4*h + (j&3)} of one column: the k-permuted fragment that pairs with an
+    // accumulator-as-operand (see the forward kernel)
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = tile[row0 + 8 * (j >> 2) + 4 * h + (j & 3)][col];
+    return f;
+}
+
+__device__ __forceinline__ bf16x8 lds_col_frag_lin(const bf16 (*tile)[LROW], int row0, int h, int col) {
+    // 8 consecutive rows row0 + 8*h + j of one column (natural k order)
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = tile[row0 + 8 * h + j][col];
+    return f;
+}
+
+struct BwdLds {
+    bf16 t[4][TILE][LROW];     // Q, K, V, dO head slices
+    bf16 pt[TILE][PROW];       // P^T   [key][query]
+    bf16 dst[TILE][PROW];      // scale * dS^T [key][query]
+};
+
+__global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
+    const bf16* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
+    const float* __restrict__ lse, const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
+    float* __restrict__ dbias_exp, float* __restrict__ dbias_pad, WinGeom g, float scale, int n_tasks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    BwdLds* L = reinterpret_cast<BwdLds*>(smem_raw) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, h = lane >> 5;
+    bf16(*Qs)[LROW] = L->t[0];
+    bf16(*Ks)[LROW] = L->t[1];
+    bf16(*Vs)[LROW] = L->t[2];
+    bf16(*Ds)[LROW] = L->t[3];
+    {
+        uint4 z = {0, 0, 0, 0};
+        uint4* p = (uint4*)L;
+        for (int i = lane; i < (int)(sizeof(BwdLds) / 16); i += WAVE) p[i] = z;
+    }
+    const int n_waves = gridDim.x * 4;
+    int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= n_tasks) return;
+    const int head = task % g.nH;
+
+    float biasr[2][2][16], dbacc[2][2][16];
+    {
+        const float* bp = bias_exp + (size_t)head * TILE * TILE;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    biasr[kt][qt][reg] = bp[key * TILE + 32 * qt + c];
+                    dbacc[kt][qt][reg] = 0.f;
+                }
+    }
+    uint64_t mrow = 0, mcol = 0;
+    if (g.shift > 0) lane_mask_bits(lane, mrow, mcol);
+
+    // staging: 4 tokens per round, 16 pieces per token (q|k|v|dO x 4 pieces of 16 B)
+    const int tokr = lane >> 4, rem = lane & 15;
+    const int which = rem >> 2, part = rem & 3;
+    const int C3 = 3 * g.C;
+    __builtin_amdgcn_wave_barrier();
+
+    for (; task < n_tasks; task += n_waves) {
+        const int win = task / g.nH;
+        const int b = win / g.nW, wrem = win - b * g.nW;
+        const int wr = wrem / g.nWw, wc = wrem - wr * g.nWw;
+
+        bf16x8 stg[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            int t = 4 * i + tokr;
+            if (t < NTOK) {
+                int src = token_src(g, b, wr, wc, t);
+                if (which < 3) {
+                    int ch = which * g.C + head * HD + part * 8;
+                    if (src >= 0) stg[i] = *(const bf16x8*)(qkv + (size_t)src * C3 + ch);
+                    else stg[i] = bias_to_bf16x8(qkv_bias + ch);
+                } else {
+                    if (src >= 0) stg[i] = *(const bf16x8*)(dout + (size_t)src * g.C + head * HD + part * 8);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) stg[i][e] = (bf16)0.f;   // cropped rows get no gradient
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            int t = 4 * i + tokr;
+            if (t < NTOK) *(bf16x8*)&L->t[which][t][part * 8] = stg[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------------- phase A -------------------------------------------------------------
+        uint64_t mbits = 0;
+        if (g.shift > 0) {
+            if (wr == g.nWh - 1) mbits |= mrow;
+            if (wc == g.nWw - 1) mbits |= mcol;
+        }
+        f32x16 pacc[2][2], dpacc[2][2];
+        {
+            bf16x8 qf[2][2], kf[2][2], vf[2][2], df[2][2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    qf[t2][s] = *(const bf16x8*)&Qs[32 * t2 + c][16 * s + 8 * h];
+                    kf[t2][s] = *(const bf16x8*)&Ks[32 * t2 + c][16 * s + 8 * h];
+                    vf[t2][s] = *(const bf16x8*)&Vs[32 * t2 + c][16 * s + 8 * h];
+                    df[t2][s] = *(const bf16x8*)&Ds[32 * t2 + c][16 * s + 8 * h];
+                }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    f32x16 a = {0}, d = {0};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], a, 0, 0, 0);   // S^T
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], df[qt][s], d, 0, 0, 0);   // dP^T
+                    }
+                    pacc[kt][qt] = a;
+                    dpacc[kt][qt] = d;
+                }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = 32 * qt + c;
+            const float l = lse[(size_t)task * TILE + (q < NTOK ? q : 0)];
+            float delta = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float v = pacc[kt][qt][reg] * scale + biasr[kt][qt][reg];
+                    if ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1) v += -100.0f;
+                    float p = __expf(v - l);
+                    pacc[kt][qt][reg] = p;
+                    delta += p * dpacc[kt][qt][reg];
+                }
+            delta += __shfl_xor(delta, 32);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float ds = pacc[kt][qt][reg] * (dpacc[kt][qt][reg] - delta);
+                    if (q >= NTOK) ds = 0.f;                      // padded query columns carry garbage
+                    dbacc[kt][qt][reg] += ds;
+                    dpacc[kt][qt][reg] = ds * scale;              // scale * dS^T from here on
+                    int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    L->pt[key][q] = (bf16)(q < NTOK ? pacc[kt][qt][reg] : 0.f);
+                    L->dst[key][q] = (bf16)dpacc[kt][qt][reg];
+                }
+        }
+        // dQ^T = K^T (scale dS^T)
+        f32x16 dq[2] = {{0}, {0}};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 kc = lds_col_frag(Ks, 32 * kt + 16 * s, h, c);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    bf16x8 sf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sf[j] = (bf16)dpacc[kt][qt][8 * s + j];
+                    dq[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, sf, dq[qt], 0, 0, 0);
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------------- phase B: dV^T = dO^T P ,  dK^T = Q^T (scale dS) ----------------------
+        f32x16 dv[2] = {{0}, {0}}, dk[2] = {{0}, {0}};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {          // k-steps of 16 queries
+            bf16x8 doc = lds_col_frag_lin(Ds, 16 * ks, h, c);   // A = dO^T : rows d, k = query
+            bf16x8 qc = lds_col_frag_lin(Qs, 16 * ks, h, c);    // A = Q^T
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                bf16x8 pb = *(const bf16x8*)&L->pt[32 * kt + c][16 * ks + 8 * h];    // B[k=query][col=key]
+                bf16x8 sb = *(const bf16x8*)&L->dst[32 * kt + c][16 * ks + 8 * h];
+                dv[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doc, pb, dv[kt], 0, 0, 0);
+                dk[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qc, sb, dk[kt], 0, 0, 0);
+            }
+        }
+
+        // ---------------- write dq | dk | dv for this lane's token ------------------------------
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            int tok = 32 * tt + c;
+            if (tok < NTOK) {
+                int src = token_src(g, b, wr, wc, tok);
+                if (src >= 0) {
+                    bf16* op = dqkv + (size_t)src * C3 + head * HD + 4 * h;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        bf16x4 a, bb, cc;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[e] = (bf16)dq[tt][4 * gq + e];
+                            bb[e] = (bf16)dk[tt][4 * gq + e];
+                            cc[e] = (bf16)dv[tt][4 * gq + e];
+                        }
+                        *(bf16x4*)(op + 8 * gq) = a;
+                        *(bf16x4*)(op + g.C + 8 * gq) = bb;
+                        *(bf16x4*)(op + 2 * g.C + 8 * gq) = cc;
+                    }
+                } else {
+                    // padded token: its q|k|v ARE qkv.bias, so the gradient lands on the bias
+                    float* bp = dbias_pad + head * HD + 4 * h;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int d = (r & 3) + 8 * (r >> 2);
+                        atomicAdd(bp + d, dq[tt][r]);
+                        atomicAdd(bp + g.C + d, dk[tt][r]);
+                        atomicAdd(bp + 2 * g.C + d, dv[tt][r]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // flush the relative-position-bias gradient of this wave's head
+    float* db = dbias_exp + (size_t)head * TILE * TILE;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (key < NTOK && 32 * qt + c < NTOK) atomicAdd(db + key * TILE + 32 * qt + c, dbacc[kt][qt][reg]);
+            }
+}
+
+// ------------------------------------------------------------------------------------
+// fp32 backward (parity path): 64-thread block per (window, head)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void win_attn_bwd_f32_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
+    const float* __restrict__ lse, const float* __restrict__ dout, float* __restrict__ dqkv,
+    float* __restrict__ dbias_exp, float* __restrict__ dbias_pad, WinGeom g, float scale) {
+    __shared__ float Qs[NTOK][HD + 1], Ks[NTOK][HD + 1], Vs[NTOK][HD + 1], Ds[NTOK][HD + 1];
+    __shared__ float Ps[NTOK][NTOK + 1], Ss[NTOK][NTOK + 1];
+    const int task = blockIdx.x, t = threadIdx.x;
+    const int head = task % g.nH, win = task / g.nH;
+    const int b = win / g.nW, wrem = win - b * g.nW;
+    const int wr = wrem / g.nWw, wc = wrem - wr * g.nWw;
+    const int C3 = 3 * g.C;
+    int src = -1;
+    if (t < NTOK) {
+        src = token_src(g, b, wr, wc, t);
+        const float* base = src >= 0 ? qkv + (size_t)src * C3 : qkv_bias;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            Qs[t][d] = base[head * HD + d] * scale;
+            Ks[t][d] = base[g.C + head * HD + d];
+            Vs[t][d] = base[2 * g.C + head * HD + d];
+            Ds[t][d] = src >= 0 ? dout[(size_t)src * g.C + head * HD + d] : 0.f;
+        }
+    }
+    __syncthreads();
+    const float* bp = bias_exp + (size_t)head * TILE * TILE;
+    float* db = dbias_exp + (size_t)head * TILE * TILE;
+    const bool lastr = g.shift > 0 && wr == g.nWh - 1, lastc = g.shift > 0 && wc == g.nWw - 1;
+    float dq[HD];
+    if (t < NTOK) {
+        const int qh = t / 7, qw = t % 7;
+        const float l = lse[(size_t)task * TILE + t];
+        float p[NTOK], dp[NTOK];
+        float delta = 0.f;
+#pragma unroll
+        for (int k = 0; k < NTOK; ++k) {
+            float a = 0.f, e = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) { a = fmaf(Qs[t][d], Ks[k][d], a); e = fmaf(Ds[t][d], Vs[k][d], e); }
+            a += bp[k * TILE + t];
+            int kh = k / 7, kw = k % 7;
+            if ((lastr && ((qh >= 4) != (kh >= 4))) || (lastc && ((qw >= 4) != (kw >= 4)))) a += -100.0f;
+            p[k] = expf(a - l);
+            dp[k] = e;
+            delta += p[k] * e;
+        }
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NTOK; ++k) {
+            float ds = p[k] * (dp[k] - delta);
+            Ps[t][k] = p[k];
+            Ss[t][k] = ds;
+            atomicAdd(db + k * TILE + t, ds);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, Ks[k][d], dq[d]);
+        }
+    }
+    __syncthreads();
+    if (t >= NTOK) return;
+    float dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int q = 0; q < NTOK; ++q) {
+        float pq = Ps[q][t], sq = Ss[q][t];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dv[d] = fmaf(pq, Ds[q][d], dv[d]); dk[d] = fmaf(sq, Qs[q][d], dk[d]); }   // Qs holds q*scale
+    }
+    if (src >= 0) {
+        float* op = dqkv + (size_t)src * C3 + head * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { op[d] = dq[d] * scale; op[g.C + d] = dk[d]; op[2 * g.C + d] = dv[d]; }
+    } else {
+        float* op = dbias_pad + head * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            atomicAdd(op + d, dq[d] * scale);
+            atomicAdd(op + g.C + d, dk[d]);
+            atomicAdd(op + 2 * g.C + d, dv[d]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+static int check_attn_args(const void* qkv, const float* qkv_bias, const float* bias_exp, const void* out,
+                           int B, int H, int W, int C, int nH, int shift, int dtype) {
+    if (!qkv || !bias_exp || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || nH <= 0) return SWIN_ERR_BAD_ARG;
+    if (C != nH * HD || (shift != 0 && shift != 3) || (dtype != SWIN_F32 && dtype != SWIN_BF16))
+        return SWIN_ERR_UNSUPPORTED;
+    if ((H % 7 != 0 || W % 7 != 0) && !qkv_bias) return SWIN_ERR_BAD_ARG;
+    return SWIN_OK;
+}
+
+static int attn_grid_blocks(int n_tasks, int nH) {
+    // persistent waves: 4 per block; total wave count must be a multiple of nH so a wave keeps its head
+    int blocks = (n_tasks + 3) / 4;
+    const int cap = 256 * 2;  // 2 blocks (8 waves) per CU
+    if (blocks > cap) blocks = cap;
+    // 4*blocks % nH == 0  <=  blocks % nH == 0
+    blocks = (blocks + nH - 1) / nH * nH;
+    return blocks;
+}
+
+extern "C" int swin_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bias_exp, void* out,
+                                    float* lse, int B, int H, int W, int C, int nH, int shift, float scale,
+                                    int dtype, void* stream) {
+    int st = check_attn_args(qkv, qkv_bias, bias_exp, out, B, H, W, C, nH, shift, dtype);
+    if (st != SWIN_OK) return st;
+    WinGeom g = make_geom(B, H, W, C, nH, shift);
+    int n_tasks = B * g.nW * nH;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SWIN_BF16) {
+        int blocks = attn_grid_blocks(n_tasks, nH);
+        win_attn_fwd_bf16_kernel<<<blocks, 256, 0, s>>>((const bf16*)qkv, qkv_bias, bias_exp, (bf16*)out, lse, g,
+                                                        scale, n_tasks);
+    } else {
+        win_attn_fwd_f32_kernel<<<n_tasks, 64, 0, s>>>((const float*)qkv, qkv_bias, bias_exp, (float*)out, lse, g,
+                                                       scale);
+    }
+    return swin_launch_status();
+}
+
+extern "C" int swin_rel_bias_expand(const float* table, float* bias_exp, int nH, void* stream) {
+    if (!table || !bias_exp || nH <= 0) return SWIN_ERR_BAD_ARG;
+    int n = nH * TILE * TILE;
+    rel_bias_expand_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(table, bias_exp, nH);
+    return swin_launch_status();
+}
+
+extern "C" int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int nH, void* stream) {
+    if (!dbias_exp || !dtable || nH <= 0) return SWIN_ERR_BAD_ARG;
+    int n = 169 * nH;
+    rel_bias_reduce_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(dbias_exp, dtable, nH);
+    return swin_launch_status();
+}
+
+extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_exp, const float* lse,
+                                    const void* dout, void* dqkv, float* dbias_exp, float* dqkv_bias_pad, int B, int H,
+                                    int W, int C, int nH, int shift, float scale, int dtype, void* stream) {
+    int st = check_attn_args(qkv, qkv_bias, bias_exp, dqkv, B, H, W, C, nH, shift, dtype);
+    if (st != SWIN_OK) return st;
+    if (!lse || !dout || !dbias_exp) return SWIN_ERR_BAD_ARG;
+    if ((H % 7 != 0 || W % 7 != 0) && !dqkv_bias_pad) return SWIN_ERR_BAD_ARG;
+    WinGeom g = make_geom(B, H, W, C, nH, shift);
+    int n_tasks = B * g.nW * nH;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SWIN_BF16) {
+        int blocks = (n_tasks + 3) / 4;
+        if (blocks > 256) blocks = 256;           // LDS allows one 4-wave block per CU
+        blocks = (blocks + nH - 1) / nH * nH;
+        static bool attr_set = false;
+        size_t shm = 4 * sizeof(BwdLds);
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)win_attn_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)shm) != hipSuccess) return SWIN_ERR_LAUNCH;
+            attr_set = true;
+        }
+        win_attn_bwd_bf16_kernel<<<blocks, 256, shm, s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
+                                                          (bf16*)dqkv, dbias_exp, dqkv_bias_pad, g, scale, n_tasks);
+    } else {
+        win_attn_bwd_f32_kernel<<<n_tasks, 64, 0, s>>>((const float*)qkv, qkv_bias, bias_exp, lse, (const float*)dout,
+                                                       (float*)dqkv, dbias_exp, dqkv_bias_pad, g, scale);
+    }
+    return swin_launch_status();
+}

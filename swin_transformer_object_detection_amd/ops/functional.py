@@ -1,0 +1,332 @@
+"""torch-facing wrappers of the C ABI (include/swin_hip.h): tensors in, tensors out.
+
+Every function here launches hand-written HIP kernels through ctypes on torch's
+current stream.  torch only provides device memory, streams and autograd
+bookkeeping.  There is deliberately no CPU / eager fallback: a tensor that is
+not on a GPU, or a missing library, raises.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .._lib import SWIN_BF16, SWIN_F32, SwinHipError, call
+
+LN_EPS = 1e-5
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return SWIN_BF16
+    if t.dtype == torch.float32:
+        return SWIN_F32
+    raise SwinHipError(f"unsupported activation dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise SwinHipError("HIP path needs GPU tensors (no CPU fallback)")
+        if not t.is_contiguous():
+            raise SwinHipError("HIP path needs contiguous tensors")
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise SwinHipError("parameters must be float32")
+    return t
+
+
+# --------------------------------------------------------------------------------------
+# LayerNorm
+# --------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        _chk(x, w, b)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        call("swin_layernorm_fwd", _p(x), _p(_f32(w)), _p(_f32(b)), _p(y), _p(mean), _p(rstd), rows, C, eps, _dt(x), _s())
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(w)
+        call("swin_layernorm_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), None, _p(dx), None, None, 1,
+             _p(dw), _p(db), rows, C, _dt(x), _s())
+        return dx, dw, db, None
+
+
+def layer_norm(x, weight, bias, eps=LN_EPS):
+    return _LayerNorm.apply(x, weight, bias, eps)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """xo = x + scale[b]*y ; n = LN(xo).  Returns (xo, n)."""
+
+    @staticmethod
+    def forward(ctx, x, y, scale, rows_per_sample, w, b, eps):
+        _chk(x, y, scale, w, b)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        xo = torch.empty_like(x)
+        n = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        call("swin_add_layernorm_fwd", _p(x), _p(y), _p(scale), rows_per_sample, _p(_f32(w)), _p(_f32(b)), _p(xo), _p(n),
+             _p(mean), _p(rstd), rows, C, eps, _dt(x), _s())
+        ctx.save_for_backward(xo, w, mean, rstd, scale)
+        ctx.rps = rows_per_sample
+        return xo, n
+
+    @staticmethod
+    def backward(ctx, dxo, dn):
+        xo, w, mean, rstd, scale = ctx.saved_tensors
+        C = xo.shape[-1]
+        rows = xo.numel() // C
+        dn = torch.zeros_like(xo) if dn is None else dn.contiguous()
+        dxo = None if dxo is None else dxo.contiguous()
+        dx = torch.empty_like(xo)
+        dyb = torch.empty_like(xo) if scale is not None else None
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(w)
+        call("swin_layernorm_bwd", _p(dn), _p(xo), _p(w), _p(mean), _p(rstd), _p(dxo), _p(dx), _p(dyb), _p(scale),
+             ctx.rps, _p(dw), _p(db), rows, C, _dt(xo), _s())
+        return dx, (dyb if scale is not None else dx), None, None, dw, db, None
+
+
+def add_layer_norm(x, y, scale, rows_per_sample, weight, bias, eps=LN_EPS):
+    return _AddLayerNorm.apply(x, y, scale, rows_per_sample, weight, bias, eps)
+
+
+class _AddScaled(torch.autograd.Function):
+    """xo = x + scale[b]*y (residual + DropPath) without a following norm."""
+
+    @staticmethod
+    def forward(ctx, x, y, scale, rows_per_sample):
+        _chk(x, y, scale)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        xo = torch.empty_like(x)
+        call("swin_add_layernorm_fwd", _p(x), _p(y), _p(scale), rows_per_sample, None, None, _p(xo), None, None, None,
+             rows, C, LN_EPS, _dt(x), _s())
+        ctx.save_for_backward(scale)
+        ctx.rps = rows_per_sample
+        return xo
+
+    @staticmethod
+    def backward(ctx, dxo):
+        (scale,) = ctx.saved_tensors
+        if scale is None:
+            return dxo, dxo, None, None
+        B = scale.numel()
+        dy = (dxo.reshape(B, -1) * scale.to(dxo.dtype).view(B, 1)).view_as(dxo)
+        return dxo, dy, None, None
+
+
+def add_scaled(x, y, scale, rows_per_sample):
+    return _AddScaled.apply(x, y, scale, rows_per_sample)
+
+
+# --------------------------------------------------------------------------------------
+# Window attention
+# --------------------------------------------------------------------------------------
+def rel_bias_expand(table):
+    _chk(table)
+    nH = table.shape[1]
+    out = torch.empty(nH, 64, 64, device=table.device, dtype=torch.float32)
+    call("swin_rel_bias_expand", _p(_f32(table)), _p(out), nH, _s())
+    return out
+
+
+class _WindowAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, table, B, H, W, nH, shift):
+        _chk(qkv, qkv_bias, table)
+        C = qkv.shape[-1] // 3
+        assert qkv.numel() == B * H * W * 3 * C
+        bias_exp = rel_bias_expand(table)
+        out = torch.empty(B, H * W, C, device=qkv.device, dtype=qkv.dtype)
+        nW = ((H + 6) // 7) * ((W + 6) // 7)
+        lse = torch.empty(B * nW * nH, 64, device=qkv.device, dtype=torch.float32)
+        scale = float((C // nH) ** -0.5)
+        call("swin_window_attn_fwd", _p(qkv), _p(qkv_bias), _p(bias_exp), _p(out), _p(lse), B, H, W, C, nH, shift, scale,
+             _dt(qkv), _s())
+        ctx.save_for_backward(qkv, qkv_bias, bias_exp, lse)
+        ctx.geom = (B, H, W, C, nH, shift, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, qkv_bias, bias_exp, lse = ctx.saved_tensors
+        B, H, W, C, nH, shift, scale = ctx.geom
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dbexp = torch.zeros_like(bias_exp)
+        dpad = torch.zeros(3 * C, device=qkv.device, dtype=torch.float32)
+        call("swin_window_attn_bwd", _p(qkv), _p(qkv_bias), _p(bias_exp), _p(lse), _p(dout), _p(dqkv), _p(dbexp), _p(dpad),
+             B, H, W, C, nH, shift, scale, _dt(qkv), _s())
+        dtable = torch.zeros(169, nH, device=qkv.device, dtype=torch.float32)
+        call("swin_rel_bias_reduce", _p(dbexp), _p(dtable), nH, _s())
+        return dqkv, dpad, dtable, None, None, None, None, None
+
+
+def window_attention(qkv, qkv_bias, table, B, H, W, num_heads, shift):
+    """qkv (B, H*W, 3C) on the natural token grid -> attention output (B, H*W, C).
+
+    Pad, roll, window partition/reverse, bias, mask, softmax and PV are one kernel."""
+    return _WindowAttention.apply(qkv, qkv_bias, table, B, H, W, num_heads, shift)
+
+
+# --------------------------------------------------------------------------------------
+# bias + GELU
+# --------------------------------------------------------------------------------------
+class _BiasGelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        _chk(x, bias)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        call("swin_bias_gelu_fwd", _p(x), _p(bias), _p(y), rows, C, _dt(x), _s())
+        ctx.save_for_backward(x, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bias = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dx = torch.empty_like(x)
+        call("swin_bias_gelu_bwd", _p(dy), _p(x), _p(bias), _p(dx), rows, C, _dt(x), _s())
+        dbias = None
+        if bias is not None:
+            dbias = dx.reshape(rows, C).sum(0, dtype=torch.float32)
+        return dx, dbias
+
+
+def bias_gelu(x, bias):
+    return _BiasGelu.apply(x, bias)
+
+
+# --------------------------------------------------------------------------------------
+# PatchMerging gather + LN, PatchEmbed im2row
+# --------------------------------------------------------------------------------------
+class _PatchMergeLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, B, H, W, eps):
+        _chk(x, w, b)
+        C = x.shape[-1]
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        y = torch.empty(B, Ho * Wo, 4 * C, device=x.device, dtype=x.dtype)
+        mean = torch.empty(B * Ho * Wo, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        call("swin_patch_merge_ln_fwd", _p(x), _p(_f32(w)), _p(_f32(b)), _p(y), _p(mean), _p(rstd), B, H, W, C, eps,
+             _dt(x), _s())
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.geom = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        B, H, W, C = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(w)
+        call("swin_patch_merge_ln_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db), B, H, W, C,
+             _dt(x), _s())
+        return dx, dw, db, None, None, None, None
+
+
+def patch_merge_layer_norm(x, weight, bias, B, H, W, eps=LN_EPS):
+    return _PatchMergeLN.apply(x, weight, bias, B, H, W, eps)
+
+
+class _PatchIm2Row(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, out_dtype):
+        _chk(img)
+        if img.dtype != torch.float32:
+            raise SwinHipError("image must be float32")
+        B, Cin, Hi, Wi = img.shape
+        if Cin != 3:
+            raise SwinHipError("patch_im2row: in_chans must be 3")
+        Ho, Wo = (Hi + 3) // 4, (Wi + 3) // 4
+        rows = torch.empty(B * Ho * Wo, 48, device=img.device, dtype=out_dtype)
+        call("swin_patch_im2row", _p(img), _p(rows), B, Hi, Wi, _dt(rows), _s())
+        ctx.geom = (B, Hi, Wi, Ho, Wo)
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        # pure layout (non-overlapping patches): only needed when the image itself requires grad
+        B, Hi, Wi, Ho, Wo = ctx.geom
+        g = drows.float().view(B, Ho, Wo, 3, 4, 4).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, Ho * 4, Wo * 4)
+        return g[:, :, :Hi, :Wi].contiguous(), None
+
+
+def patch_im2row(img, out_dtype):
+    return _PatchIm2Row.apply(img, out_dtype)
+
+
+# --------------------------------------------------------------------------------------
+# FPN top-down
+# --------------------------------------------------------------------------------------
+def _nchw_layout(t):
+    """(channels_last_flag, N, C, H, W) of a logically-NCHW tensor; raises if neither layout."""
+    N, C, H, W = t.shape
+    if t.is_contiguous():
+        return 0, N, C, H, W
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return 1, N, C, H, W
+    raise SwinHipError("tensor must be NCHW-contiguous or channels_last")
+
+
+class _UpsampleAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fine, coarse):
+        cl, N, C, Hf, Wf = _nchw_layout(fine)
+        cl2, _, _, Hc, Wc = _nchw_layout(coarse)
+        if cl != cl2 or not fine.is_cuda:
+            raise SwinHipError("fine/coarse must share a memory layout and live on the GPU")
+        out = fine.clone(memory_format=torch.preserve_format)
+        call("fpn_upsample_add_fwd", _p(out), _p(coarse), N, C, Hf, Wf, Hc, Wc, cl, _dt(fine), _s())
+        ctx.geom = (cl, N, C, Hf, Wf, Hc, Wc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cl, N, C, Hf, Wf, Hc, Wc = ctx.geom
+        dout = dout.contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+        dcoarse = torch.empty((N, C, Hc, Wc), device=dout.device, dtype=dout.dtype,
+                              memory_format=torch.channels_last if cl else torch.contiguous_format).zero_()
+        call("fpn_upsample_add_bwd", _p(dout), _p(dcoarse), N, C, Hf, Wf, Hc, Wc, cl, _dt(dout), _s())
+        return dout, dcoarse
+
+
+def upsample_add(fine, coarse):
+    """fine + nearest_upsample(coarse, size=fine.shape[2:])  (fpn.py:188-191)."""
+    return _UpsampleAdd.apply(fine, coarse)

@@ -1,0 +1,82 @@
+"""``mmcv.ops.nms`` / ``batched_nms`` surface over the HIP kernels.
+
+Call sites in the reference: ``rpn_head.py:233`` and ``bbox_nms.py:84``
+(``batched_nms(boxes, scores, idxs, nms_cfg)``).  Build spec:
+stable descending sort, suppression test ``inter > thr * (Sa + Sb - inter)`` in fp32.
+The bitmask AND its greedy reduction run on the device; the only host
+synchronisation is the one the caller's dynamic output shape requires (boolean
+indexing of the keep flags), exactly as any torch masked_select.
+"""
+import torch
+
+from .._lib import SwinHipError, call, lib
+from .functional import _p, _s
+
+
+def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
+    """-> (dets (k,5), inds (k,) int64 into the input, descending score order)."""
+    assert boxes.size(1) == 4 and boxes.size(0) == scores.size(0) and offset in (0, 1)
+    if not boxes.is_cuda:
+        raise SwinHipError("nms: HIP path needs GPU tensors (no CPU fallback)")
+    boxes = boxes.float()
+    scores = scores.float()
+    valid_inds = None
+    if score_threshold > 0:
+        valid = scores > score_threshold
+        valid_inds = torch.nonzero(valid, as_tuple=False).squeeze(1)
+        boxes, scores = boxes[valid], scores[valid]
+    n = boxes.size(0)
+    if n == 0:
+        inds = torch.zeros(0, dtype=torch.long, device=boxes.device)
+    else:
+        order = torch.sort(scores, descending=True, stable=True)[1]
+        bs = boxes.index_select(0, order).contiguous()
+        ws = torch.empty(lib().swin_nms_workspace_bytes(n), dtype=torch.uint8, device=boxes.device)
+        flags = torch.empty(n, dtype=torch.uint8, device=boxes.device)
+        cnt = torch.empty(1, dtype=torch.int32, device=boxes.device)
+        call("nms_sorted", _p(bs), n, float(iou_threshold), int(offset), _p(flags), _p(cnt), _p(ws), _s())
+        inds = order[flags.bool()]
+    if max_num > 0:
+        inds = inds[:max_num]
+    dets = torch.cat((boxes[inds], scores[inds].reshape(-1, 1)), dim=1)
+    if valid_inds is not None:
+        inds = valid_inds[inds]
+    return dets, inds
+
+
+def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+    """mmcv.ops.batched_nms: NMS within each id of ``idxs`` -> (dets (k,5), keep (k,))."""
+    nms_cfg_ = dict(nms_cfg)
+    class_agnostic = nms_cfg_.pop('class_agnostic', class_agnostic)
+    if boxes.numel() == 0:
+        return boxes.new_zeros((0, 5)), torch.zeros(0, dtype=torch.long, device=boxes.device)
+    if class_agnostic:
+        boxes_for_nms = boxes
+    else:
+        max_coordinate = boxes.max()
+        offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+        boxes_for_nms = boxes + offsets[:, None]
+    nms_type = nms_cfg_.pop('type', 'nms')
+    if nms_type != 'nms':
+        raise NotImplementedError(f"nms type {nms_type!r} is not on the Swin path")
+    split_thr = nms_cfg_.pop('split_thr', 10000)
+    if boxes_for_nms.shape[0] < split_thr:
+        dets, keep = nms(boxes_for_nms, scores, **nms_cfg_)
+        boxes = boxes[keep]
+        scores = dets[:, 4]
+    else:
+        max_num = nms_cfg_.pop('max_num', -1)
+        total_mask = scores.new_zeros(scores.size(), dtype=torch.bool)
+        scores_after_nms = scores.new_zeros(scores.size())
+        for id in torch.unique(idxs):
+            mask = (idxs == id).nonzero(as_tuple=False).view(-1)
+            dets, keep = nms(boxes_for_nms[mask], scores[mask], **nms_cfg_)
+            total_mask[mask[keep]] = True
+            scores_after_nms[mask[keep]] = dets[:, -1]
+        keep = total_mask.nonzero(as_tuple=False).view(-1)
+        scores, inds = scores_after_nms[keep].sort(descending=True, stable=True)
+        keep = keep[inds]
+        boxes = boxes[keep]
+        if max_num > 0:
+            keep, boxes, scores = keep[:max_num], boxes[:max_num], scores[:max_num]
+    return torch.cat([boxes, scores[:, None]], -1), keep

@@ -1,0 +1,90 @@
+"""``mmcv.ops.RoIAlign`` / ``roi_align`` surface over the HIP kernels.
+
+Signature and semantics follow the reference's call sites
+(``base_roi_extractor.py:49-55`` builds ``RoIAlign(spatial_scale=1/s, output_size, sampling_ratio)``
+by name with ``getattr``; ``structures.py:353-354`` calls
+``roi_align(input, rois, output_size, 1.0, 0, 'avg', True)`` positionally).
+"""
+import torch
+import torch.nn as nn
+
+from .._lib import SWIN_BF16, SWIN_F32, SwinHipError, call
+from .functional import _p, _s
+
+
+def _pair(x):
+    return (int(x), int(x)) if isinstance(x, int) else (int(x[0]), int(x[1]))
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, rois, output_size, spatial_scale, sampling_ratio, aligned):
+        if not inp.is_cuda:
+            raise SwinHipError("roi_align: HIP path needs GPU tensors (no CPU fallback)")
+        N, C, H, W = inp.shape
+        if inp.is_contiguous():
+            cl = 0
+        elif inp.is_contiguous(memory_format=torch.channels_last):
+            cl = 1
+        else:
+            inp = inp.contiguous()
+            cl = 0
+        if inp.dtype == torch.float32:
+            dt = SWIN_F32
+        elif inp.dtype == torch.bfloat16:
+            dt = SWIN_BF16
+        else:
+            raise SwinHipError(f"roi_align: unsupported feature dtype {inp.dtype}")
+        rois = rois.contiguous().float()
+        K = rois.shape[0]
+        ph, pw = output_size
+        out = torch.empty((K, C, ph, pw), device=inp.device, dtype=torch.float32,
+                          memory_format=torch.channels_last if cl else torch.contiguous_format)
+        if K > 0:
+            call("roi_align_fwd", _p(inp), _p(rois), _p(out), N, C, H, W, K, ph, pw, float(spatial_scale),
+                 int(sampling_ratio), int(bool(aligned)), cl, dt, _s())
+        ctx.save_for_backward(rois)
+        ctx.cfg = (N, C, H, W, K, ph, pw, float(spatial_scale), int(sampling_ratio), int(bool(aligned)), cl, inp.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (rois,) = ctx.saved_tensors
+        N, C, H, W, K, ph, pw, scale, sr, aligned, cl, in_dtype = ctx.cfg
+        mf = torch.channels_last if cl else torch.contiguous_format
+        gin = torch.empty((N, C, H, W), device=gout.device, dtype=torch.float32, memory_format=mf).zero_()
+        if K > 0:
+            gout = gout.float().contiguous(memory_format=mf)
+            call("roi_align_bwd", _p(gout), _p(rois), _p(gin), N, C, H, W, K, ph, pw, scale, sr, aligned, cl, _s())
+        return gin.to(in_dtype), None, None, None, None, None
+
+
+def roi_align(input, rois, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True):
+    """mmcv.ops.roi_align.  input (N,C,H,W), rois (K,5)=[batch_idx,x1,y1,x2,y2] -> (K,C,ph,pw) float32."""
+    if pool_mode != 'avg':
+        raise NotImplementedError("only pool_mode='avg' is on the Swin path (every configs/swin file)")
+    assert rois.dim() == 2 and rois.size(1) == 5, 'RoI must be (idx, x1, y1, x2, y2)!'
+    return _RoIAlignFn.apply(input, rois, _pair(output_size), spatial_scale, sampling_ratio, aligned)
+
+
+class RoIAlign(nn.Module):
+    """mmcv.ops.RoIAlign(output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True,
+    use_torchvision=False)."""
+
+    def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True,
+                 use_torchvision=False):
+        super().__init__()
+        self.output_size = _pair(output_size)     # read as a 2-tuple at single_level_roi_extractor.py:56
+        self.spatial_scale = float(spatial_scale)
+        self.sampling_ratio = int(sampling_ratio)
+        self.pool_mode = pool_mode
+        self.aligned = aligned
+        self.use_torchvision = use_torchvision    # accepted for config compatibility; never used
+
+    def forward(self, input, rois):
+        return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.pool_mode,
+                         self.aligned)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}(output_size={self.output_size}, spatial_scale={self.spatial_scale}, '
+                f'sampling_ratio={self.sampling_ratio}, pool_mode={self.pool_mode}, aligned={self.aligned})')

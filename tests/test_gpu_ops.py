@@ -1,0 +1,355 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (ctypes), against the CPU oracle.
+
+fp32 path: atol 1e-4 (the north_star gate).  bf16 path: the oracle is evaluated in fp32 on the SAME
+bf16-rounded inputs; tolerance = a few bf16 ulps of the output scale (stated per test).
+NMS: bit-exact index order.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import callers_oracle as CO  # noqa: E402
+from oracle import det_ops_oracle as D  # noqa: E402
+from oracle import swin_oracle as S  # noqa: E402
+
+ATOL32 = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import swin_transformer_object_detection_amd.ops as o
+    return o
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def close(a, b, atol, rtol=0.0, msg=""):
+    a = a.detach().float().cpu().numpy()
+    b = b.detach().float().cpu().numpy()
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol, err_msg=msg)
+
+
+def bf16_tol(ref, ulps=4.0):
+    """absolute tolerance = `ulps` bf16 ulps (2^-8 relative) of the reference's max magnitude"""
+    return float(ulps * 2.0 ** -8 * max(ref.detach().abs().max().item(), 1e-3))
+
+
+# ------------------------------------------------------------------------------------------
+# window attention
+# ------------------------------------------------------------------------------------------
+def oracle_attention_natural(qkv, qkv_bias, table, B, H, W, nH, shift):
+    """Reference semantics on the natural grid: pad (padded tokens are 0 before the qkv Linear, so
+    their q|k|v equal qkv.bias -- swin_transformer.py:211-218), roll, partition, core, reverse,
+    roll back, crop (:222-247)."""
+    C3 = qkv.shape[-1]
+    C = C3 // 3
+    Hp, Wp = S.padded_hw(H, W)
+    x = qkv.view(B, H, W, C3)
+    full = qkv_bias.view(1, 1, 1, C3).expand(B, Hp, Wp, C3).clone()
+    full = torch.cat([torch.cat([x, full[:, :H, W:, :]], 2), full[:, H:, :, :]], 1)
+    mask = None
+    if shift > 0:
+        full = torch.roll(full, shifts=(-shift, -shift), dims=(1, 2))
+        mask = S.shift_attn_mask(H, W, 7, shift)
+    win = S.window_partition(full, 7).view(-1, 49, C3)
+    o = S.window_attention_core(win, table, nH, mask)
+    o = S.window_reverse(o.view(-1, 7, 7, C), 7, Hp, Wp)
+    if shift > 0:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o[:, :H, :W, :].reshape(B, H * W, C)
+
+
+ATTN_CASES = [
+    # B, H, W, nH, shift
+    (2, 14, 21, 2, 0),
+    (2, 14, 21, 2, 3),
+    (2, 19, 25, 1, 0),    # pads bottom and right
+    (2, 19, 25, 3, 3),    # pads + shift + 3 heads
+    (1, 5, 7, 4, 3),      # single window row (every window is a "last row" window)
+    (3, 30, 9, 2, 3),
+]
+
+
+@pytest.mark.parametrize("B,H,W,nH,shift", ATTN_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_window_attention_fwd_bwd(ops, B, H, W, nH, shift, dtype):
+    C = 32 * nH
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W + shift)
+    qkv = torch.randn(B, H * W, 3 * C, generator=g) * 0.7
+    qb = torch.randn(3 * C, generator=g) * 0.3
+    table = torch.randn(169, nH, generator=g) * 0.5
+    wgt = torch.randn(B, H * W, C, generator=g)
+    if dtype == torch.bfloat16:
+        qkv = qkv.bfloat16().float()
+        wgt = wgt.bfloat16().float()
+    # oracle (fp32, CPU)
+    q0, b0, t0 = qkv.clone().requires_grad_(True), qb.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    ref = oracle_attention_natural(q0, b0, t0, B, H, W, nH, shift)
+    (ref * wgt).sum().backward()
+    # HIP
+    q1 = dev(qkv, dtype).requires_grad_(True)
+    b1 = dev(qb).requires_grad_(True)
+    t1 = dev(table).requires_grad_(True)
+    out = ops.window_attention(q1, b1, t1, B, H, W, nH, shift)
+    assert out.shape == (B, H * W, C) and out.dtype == dtype
+    (out.float() * dev(wgt)).sum().backward()
+    torch.cuda.synchronize()
+    if dtype == torch.float32:
+        close(out, ref, ATOL32, msg="out")
+        close(q1.grad, q0.grad, ATOL32, 1e-4, msg="dqkv")
+        close(b1.grad, b0.grad, 2e-4, 1e-4, msg="dqkv_bias(pad)")
+        close(t1.grad, t0.grad, 5e-4, 1e-4, msg="dtable")
+    else:
+        # bf16 storage of P (8 bits) and of the outputs: 4 ulps of the output scale; the table
+        # gradient sums B*nW window contributions -> scale the tolerance with its own magnitude
+        close(out, ref, bf16_tol(ref), msg="out")
+        close(q1.grad, q0.grad, bf16_tol(q0.grad, 6), msg="dqkv")
+        close(b1.grad, b0.grad, bf16_tol(b0.grad, 8) + 1e-3, msg="dqkv_bias(pad)")
+        close(t1.grad, t0.grad, bf16_tol(t0.grad, 8), msg="dtable")
+    if H % 7 == 0 and W % 7 == 0:
+        assert float(b1.grad.abs().max()) == 0.0
+
+
+def test_window_attention_rejects_bad_shapes(ops):
+    from swin_transformer_object_detection_amd._lib import SwinHipError
+    qkv = torch.zeros(1, 49, 3 * 48, device="cuda")
+    with pytest.raises(SwinHipError):      # head_dim 48 is not the Swin head_dim
+        ops.window_attention(qkv, torch.zeros(144, device="cuda"), torch.zeros(169, 1, device="cuda"), 1, 7, 7, 1, 0)
+    with pytest.raises(SwinHipError):      # CPU tensors: no fallback
+        ops.window_attention(torch.zeros(1, 49, 96), torch.zeros(96), torch.zeros(169, 1), 1, 7, 7, 1, 0)
+
+
+# ------------------------------------------------------------------------------------------
+# LayerNorm family, GELU, gather kernels
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,C", [(37, 32), (200, 96), (64, 192), (33, 384), (17, 768), (9, 1536), (5, 3072)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm(ops, rows, C, dtype):
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 2 + 0.5
+    w = 1 + 0.2 * torch.randn(C, generator=g)
+    b = 0.2 * torch.randn(C, generator=g)
+    gy = torch.randn(rows, C, generator=g)
+    if dtype == torch.bfloat16:
+        x, gy = x.bfloat16().float(), gy.bfloat16().float()
+    x0, w0, b0 = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = S.layer_norm(x0, w0, b0)
+    (ref * gy).sum().backward()
+    x1, w1, b1 = dev(x, dtype).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = ops.layer_norm(x1, w1, b1)
+    (y.float() * dev(gy)).sum().backward()
+    if dtype == torch.float32:
+        close(y, ref, ATOL32)
+        close(x1.grad, x0.grad, ATOL32, 1e-4)
+        close(w1.grad, w0.grad, 1e-3, 1e-4)
+        close(b1.grad, b0.grad, 1e-3, 1e-4)
+    else:
+        close(y, ref, bf16_tol(ref, 2))
+        close(x1.grad, x0.grad, bf16_tol(x0.grad, 2))
+        close(w1.grad, w0.grad, bf16_tol(w0.grad, 2) + 1e-2)
+        close(b1.grad, b0.grad, bf16_tol(b0.grad, 2) + 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_scale", [False, True])
+def test_add_layernorm(ops, dtype, with_scale):
+    B, L, C = 3, 50, 96
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(B, L, C, generator=g), torch.randn(B, L, C, generator=g)
+    w, b = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    sc = torch.tensor([0.0, 2.0, 2.0]) if with_scale else None
+    g1, g2 = torch.randn(B, L, C, generator=g), torch.randn(B, L, C, generator=g)
+    if dtype == torch.bfloat16:
+        x, y, g1, g2 = [t.bfloat16().float() for t in (x, y, g1, g2)]
+    x0, y0, w0, b0 = [t.clone().requires_grad_(True) for t in (x, y, w, b)]
+    xo_ref = x0 + S.drop_path(y0, sc)
+    n_ref = S.layer_norm(xo_ref, w0, b0)
+    ((xo_ref * g1).sum() + (n_ref * g2).sum()).backward()
+    x1, y1 = dev(x, dtype).requires_grad_(True), dev(y, dtype).requires_grad_(True)
+    w1, b1 = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    xo, n = ops.add_layer_norm(x1, y1, None if sc is None else dev(sc), L, w1, b1)
+    ((xo.float() * dev(g1)).sum() + (n.float() * dev(g2)).sum()).backward()
+    tol = (lambda r, u=3: ATOL32) if dtype == torch.float32 else bf16_tol
+    close(xo, xo_ref, tol(xo_ref)); close(n, n_ref, tol(n_ref))
+    close(x1.grad, x0.grad, tol(x0.grad) * (1 if dtype == torch.float32 else 1.5), 1e-4)
+    close(y1.grad, y0.grad, tol(y0.grad) * (1 if dtype == torch.float32 else 1.5), 1e-4)
+    close(w1.grad, w0.grad, 1e-3 if dtype == torch.float32 else bf16_tol(w0.grad) + 2e-2, 1e-4)
+    # residual-only form
+    xo2 = ops.add_scaled(dev(x, dtype), dev(y, dtype), None if sc is None else dev(sc), L)
+    close(xo2, xo_ref, tol(xo_ref))
+
+
+@pytest.mark.parametrize("H,W", [(6, 8), (7, 9), (5, 6)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patch_merge_ln(ops, H, W, dtype):
+    B, C = 2, 32
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, H * W, C, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    p = {"d.norm.weight": 1 + 0.2 * torch.randn(4 * C, generator=g), "d.norm.bias": 0.2 * torch.randn(4 * C, generator=g),
+         "d.reduction.weight": torch.eye(4 * C)}
+    x0 = x.clone().requires_grad_(True)
+    for v in p.values():
+        v.requires_grad_(True)
+    ref = S.patch_merging(x0, H, W, p, "d.")          # identity reduction -> the gathered+normed rows
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy).sum().backward()
+    x1 = dev(x, dtype).requires_grad_(True)
+    w1, b1 = dev(p["d.norm.weight"].detach()).requires_grad_(True), dev(p["d.norm.bias"].detach()).requires_grad_(True)
+    y = ops.patch_merge_layer_norm(x1, w1, b1, B, H, W)
+    (y.float() * dev(gy)).sum().backward()
+    if dtype == torch.float32:
+        close(y, ref, ATOL32); close(x1.grad, x0.grad, ATOL32, 1e-4)
+        close(w1.grad, p["d.norm.weight"].grad, 1e-3); close(b1.grad, p["d.norm.bias"].grad, 1e-3)
+    else:
+        close(y, ref, bf16_tol(ref, 2)); close(x1.grad, x0.grad, bf16_tol(x0.grad, 2))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_gelu(ops, dtype):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(77, 384, generator=g) * 2
+    b = torch.randn(384, generator=g) * 0.3
+    gy = torch.randn(77, 384, generator=g)
+    if dtype == torch.bfloat16:
+        x, gy = x.bfloat16().float(), gy.bfloat16().float()
+    x0, b0 = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = S.gelu(x0 + b0)
+    (ref * gy).sum().backward()
+    x1, b1 = dev(x, dtype).requires_grad_(True), dev(b).requires_grad_(True)
+    y = ops.bias_gelu(x1, b1)
+    (y.float() * dev(gy)).sum().backward()
+    if dtype == torch.float32:
+        close(y, ref, 1e-5); close(x1.grad, x0.grad, 1e-5); close(b1.grad, b0.grad, 1e-4)
+    else:
+        close(y, ref, bf16_tol(ref, 1)); close(x1.grad, x0.grad, bf16_tol(x0.grad, 1))
+        close(b1.grad, b0.grad, bf16_tol(b0.grad, 2) + 2e-2)
+
+
+@pytest.mark.parametrize("Hi,Wi", [(16, 24), (18, 21)])
+def test_patch_im2row(ops, Hi, Wi):
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(2, 3, Hi, Wi, generator=g)
+    wt = torch.randn(8, 3, 4, 4, generator=g)
+    p = {"patch_embed.proj.weight": wt, "patch_embed.proj.bias": torch.zeros(8)}
+    ref = S.patch_embed(img, p)                                  # (B, 8, Ho, Wo)
+    rows = ops.patch_im2row(dev(img), torch.float32)
+    y = rows @ dev(wt).view(8, 48).t()
+    Ho, Wo = ref.shape[2:]
+    close(y.view(2, Ho, Wo, 8).permute(0, 3, 1, 2), ref, 1e-5)
+
+
+@pytest.mark.parametrize("cl", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hf,wf,hc,wc", [(10, 14, 5, 7), (25, 40, 13, 20), (7, 9, 4, 5)])
+def test_upsample_add(ops, cl, dtype, hf, wf, hc, wc):
+    g = torch.Generator().manual_seed(hf)
+    fine, coarse = torch.randn(2, 16, hf, wf, generator=g), torch.randn(2, 16, hc, wc, generator=g)
+    gy = torch.randn(2, 16, hf, wf, generator=g)
+    if dtype == torch.bfloat16:
+        fine, coarse, gy = fine.bfloat16().float(), coarse.bfloat16().float(), gy.bfloat16().float()
+    f0, c0 = fine.clone().requires_grad_(True), coarse.clone().requires_grad_(True)
+    ref = f0 + F.interpolate(c0, size=(hf, wf), mode="nearest")    # fpn.py:188-191
+    (ref * gy).sum().backward()
+    mf = torch.channels_last if cl else torch.contiguous_format
+    f1 = dev(fine, dtype).contiguous(memory_format=mf).requires_grad_(True)
+    c1 = dev(coarse, dtype).contiguous(memory_format=mf).requires_grad_(True)
+    out = ops.upsample_add(f1, c1)
+    (out.float() * dev(gy)).sum().backward()
+    tol = 1e-6 if dtype == torch.float32 else bf16_tol(ref, 1)
+    close(out, ref, tol); close(f1.grad, f0.grad, tol)
+    close(c1.grad, c0.grad, 1e-5 if dtype == torch.float32 else bf16_tol(c0.grad, 2))
+
+
+# ------------------------------------------------------------------------------------------
+# RoIAlign / nms
+# ------------------------------------------------------------------------------------------
+def _rand_rois(rng, K, N, Wimg, Himg):
+    xy = rng.rand(K, 2) * np.array([Wimg, Himg]) * 1.1 - 0.05 * np.array([Wimg, Himg])
+    wh = rng.rand(K, 2) * np.array([Wimg, Himg]) * 0.6
+    return np.concatenate([rng.randint(0, N, (K, 1)), xy, xy + wh], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("cl", [False, True])
+@pytest.mark.parametrize("out_size,scale", [(7, 0.25), (14, 0.125), ((3, 5), 1.0)])
+def test_roi_align_fwd_bwd(ops, cl, out_size, scale):
+    rng = np.random.RandomState(7)
+    N, C, H, W = 2, 8, 25, 40
+    inp = rng.randn(N, C, H, W).astype(np.float32)
+    rois = _rand_rois(rng, 60, N, W / scale, H / scale)
+    rois[0, 1:] = [5, 5, 5, 5]                 # zero-size roi
+    rois[1, 1:] = [1e4, 1e4, 1e4 + 8, 1e4 + 8]  # fully outside
+    ref = D.roi_align_c(inp, rois, out_size, scale, 0, True)
+    mf = torch.channels_last if cl else torch.contiguous_format
+    x = torch.from_numpy(inp).cuda().contiguous(memory_format=mf).requires_grad_(True)
+    out = ops.roi_align(x, torch.from_numpy(rois).cuda(), out_size, scale, 0, 'avg', True)
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    close(out, torch.from_numpy(ref), ATOL32)
+    gy = rng.randn(*ref.shape).astype(np.float32)
+    (out * torch.from_numpy(gy).cuda()).sum().backward()
+    gref = D.roi_align_bwd_c(gy, rois, inp.shape, scale, 0, True)
+    close(x.grad, torch.from_numpy(gref).float(), 2e-4, 1e-4)
+    # the module form, bf16 features (converted on load == force_fp32), empty roi set
+    layer = ops.RoIAlign(out_size, scale, 0)
+    assert isinstance(layer.output_size, tuple) and len(layer.output_size) == 2
+    xb = x.detach().bfloat16()
+    ob = layer(xb, torch.from_numpy(rois).cuda())
+    refb = D.roi_align_c(xb.float().cpu().numpy(), rois, out_size, scale, 0, True)
+    close(ob, torch.from_numpy(refb), ATOL32)
+    empty = layer(x.detach(), torch.zeros(0, 5, device="cuda"))
+    assert empty.shape == (0, C) + layer.output_size
+
+
+def test_roi_align_not_aligned_and_fixed_grid(ops):
+    rng = np.random.RandomState(8)
+    inp = rng.randn(1, 4, 16, 16).astype(np.float32)
+    rois = _rand_rois(rng, 20, 1, 64, 64)
+    for aligned, sr in [(False, 0), (True, 2), (False, 3)]:
+        ref = D.roi_align_c(inp, rois, 7, 0.25, sr, aligned)
+        out = ops.roi_align(torch.from_numpy(inp).cuda(), torch.from_numpy(rois).cuda(), 7, 0.25, sr, 'avg', aligned)
+        close(out, torch.from_numpy(ref), ATOL32)
+
+
+@pytest.mark.parametrize("n,thr,offset", [(1, 0.5, 0), (63, 0.5, 0), (64, 0.7, 0), (65, 0.7, 1), (777, 0.3, 0),
+                                           (2000, 0.7, 0), (8780, 0.7, 0)])
+def test_nms_bit_exact(ops, n, thr, offset):
+    rng = np.random.RandomState(n)
+    xy = rng.rand(n, 2).astype(np.float32) * (300 if n < 5000 else 1200)
+    wh = rng.rand(n, 2).astype(np.float32) * 80 + 1
+    boxes = np.concatenate([xy, xy + wh], 1)
+    scores = np.round(rng.rand(n), 3).astype(np.float32)          # ties on purpose
+    dref, kref = D.nms_c(boxes, scores, thr, offset)
+    dets, keep = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr, offset)
+    assert keep.dtype == torch.int64
+    np.testing.assert_array_equal(keep.cpu().numpy(), kref)
+    np.testing.assert_array_equal(dets.cpu().numpy(), dref)
+
+
+def test_nms_empty_and_batched(ops):
+    dets, keep = ops.nms(torch.zeros(0, 4, device="cuda"), torch.zeros(0, device="cuda"), 0.5)
+    assert dets.shape == (0, 5) and keep.shape == (0,) and keep.dtype == torch.int64
+    rng = np.random.RandomState(11)
+    n = 3000
+    xy = rng.rand(n, 2).astype(np.float32) * 500
+    boxes = np.concatenate([xy, xy + rng.rand(n, 2).astype(np.float32) * 90 + 1], 1)
+    scores = rng.rand(n).astype(np.float32)
+    ids = rng.randint(0, 5, n).astype(np.int64)
+    for cfg in (dict(type="nms", iou_threshold=0.7), dict(type="nms", iou_threshold=0.5, split_thr=1000),
+                dict(type="nms", iou_threshold=0.5, class_agnostic=True)):
+        dref, kref = D.batched_nms(boxes, scores, ids, cfg)
+        dets, keep = ops.batched_nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(),
+                                     torch.from_numpy(ids).cuda(), cfg)
+        np.testing.assert_array_equal(keep.cpu().numpy(), kref)
+        np.testing.assert_array_equal(dets.cpu().numpy(), dref)
+    d0, k0 = ops.batched_nms(torch.zeros(0, 4, device="cuda"), torch.zeros(0, device="cuda"),
+                             torch.zeros(0, dtype=torch.long, device="cuda"), dict(type="nms", iou_threshold=0.5))
+    assert d0.shape == (0, 5) and k0.shape == (0,)
