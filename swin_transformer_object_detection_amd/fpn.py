@@ -1,0 +1,90 @@
+"""``FPN`` neck on the hot path.  Drop-in for ``mmdet/models/necks/fpn.py:66-221`` in the
+configuration every swin config uses (``add_extra_convs=False``, no norm / activation):
+same registry name, kwargs, ``lateral_convs.{i}.conv`` / ``fpn_convs.{i}.conv`` parameter
+names (mmcv ConvModule nests the conv under ``.conv``), xavier-uniform init.
+
+Execution plan: feature maps stay channels-last (the backbone's token-major buffers), so a
+1x1 lateral conv is a plain GEMM over tokens; the top-down ``+= nearest_upsample`` is one HIP
+kernel (``ops.upsample_add``); the 3x3 output convs go to the library conv (MIOpen) in
+channels-last; the extra pyramid level ``max_pool2d(k=1, s=2)`` is a strided view.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .registry import NECKS
+
+
+class ConvModule(nn.Module):
+    """mmcv.cnn.ConvModule with norm_cfg=None and act_cfg=None: a biased Conv2d stored as ``.conv``."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, conv_cfg=None, norm_cfg=None,
+                 act_cfg=None, inplace=False):
+        super().__init__()
+        if norm_cfg is not None or act_cfg is not None or conv_cfg is not None:
+            raise NotImplementedError("swin configs build FPN convs without norm/activation/conv_cfg")
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=True)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+def _to_cl(x, dtype):
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 extra_convs_on_inputs=True, relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None,
+                 norm_cfg=None, act_cfg=None, upsample_cfg=dict(mode='nearest'), compute_dtype=torch.float32):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        if add_extra_convs or start_level != 0 or end_level != -1:
+            raise NotImplementedError("only the Mask R-CNN form (extra levels by max-pool) is on the Swin path")
+        if upsample_cfg.get('mode', 'nearest') != 'nearest' or 'scale_factor' in upsample_cfg:
+            raise NotImplementedError("upsample_cfg must be dict(mode='nearest')")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        assert num_outs >= self.num_ins
+        self.fp16_enabled = False
+        self.compute_dtype = compute_dtype
+        self.upsample_cfg = upsample_cfg.copy()
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for c in in_channels:
+            self.lateral_convs.append(ConvModule(c, out_channels, 1, conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, conv_cfg=conv_cfg,
+                                             norm_cfg=norm_cfg, act_cfg=act_cfg))
+
+    def init_weights(self):                                     # fpn.py:163-167
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def _w(self, t):
+        return t if self.compute_dtype == torch.float32 else t.to(self.compute_dtype)
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        dt = self.compute_dtype
+        laterals = []
+        for x, lc in zip(inputs, self.lateral_convs):           # fpn.py:175-178: 1x1 conv == GEMM over tokens
+            x = _to_cl(x, dt)
+            N, C, H, W = x.shape
+            tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
+            y = F.linear(tok, self._w(lc.conv.weight.view(self.out_channels, C)), self._w(lc.conv.bias))
+            laterals.append(y.view(N, H, W, self.out_channels).permute(0, 3, 1, 2))
+        for i in range(len(laterals) - 1, 0, -1):               # fpn.py:182-191
+            laterals[i - 1] = ops.upsample_add(laterals[i - 1], laterals[i])
+        outs = [F.conv2d(laterals[i], self._w(fc.conv.weight).contiguous(memory_format=torch.channels_last),
+                         self._w(fc.conv.bias), padding=1)
+                for i, fc in enumerate(self.fpn_convs)]         # fpn.py:195-197
+        for _ in range(self.num_outs - len(outs)):              # fpn.py:202-204: max_pool2d(k=1, s=2)
+            outs.append(outs[-1][:, :, ::2, ::2])
+        return tuple(outs)
