@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- Mask R-CNN Swin-T 800x1280 bf16 training throughput on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward_train + backward + gradient all-reduce (RCCL, overlapped) + AdamW step on a fixed
+synthetic batch of 2 images per GPU (BASELINE.json configs[1]; weak scaling).  Rank 0 prints ONE JSON
+line.  Besides the contract keys it carries
+  roofline     : the WindowAttention forward kernel (stage-1 geometry of this workload) timed live with
+                 HIP events on the launch stream, against the HBM roofline;
+  cpu_baseline : the CPU oracle (torch-CPU fp32 restatement + C RoIAlign/NMS) timed on the host cores
+                 on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IMG_H, IMG_W, PER_GPU_BATCH = 800, 1280, 2
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    return ap.parse_args()
+
+
+def build_param_groups(model, opt_cfg):
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if any(k in n for k in opt_cfg["no_decay_keys"]) else decay).append(p)
+    return [dict(params=decay, weight_decay=opt_cfg["weight_decay"]), dict(params=no_decay, weight_decay=0.0)]
+
+
+def attention_roofline(device, steps=30):
+    """WindowAttention forward (bf16 MFMA kernel) at the stage-1 geometry of the workload:
+    B=2, 200x320 tokens, C=96, 3 heads, shifted.  Algorithmic bytes per launch = read qkv (3C) +
+    write out (C) per real token in bf16 = 8*T*C bytes (4*T*C*bpe)."""
+    from swin_transformer_object_detection_amd import ops
+    B, H, W, C, nH = PER_GPU_BATCH, IMG_H // 4, IMG_W // 4, 96, 3
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(B, H * W, 3 * C, generator=g).to(device=device, dtype=torch.bfloat16)
+    qb = (torch.randn(3 * C, generator=g) * 0.1).to(device)
+    table = (torch.randn(169, nH, generator=g) * 0.02).to(device)
+    for _ in range(5):
+        ops.window_attention(qkv, qb, table, B, H, W, nH, 3)
+    torch.cuda.synchronize()
+    # the op wrapper also launches the (tiny) bias-expand kernel; time the attention launch alone through the ABI
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    bias_exp = ops.rel_bias_expand(table)
+    out = torch.empty(B, H * W, C, device=device, dtype=torch.bfloat16)
+    lse = torch.empty(B * ((H + 6) // 7) * ((W + 6) // 7) * nH, 64, device=device, dtype=torch.float32)
+    scale = 32 ** -0.5
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for s, e in ev:
+        s.record()
+        Fn.call("swin_window_attn_fwd", Fn._p(qkv), Fn._p(qb), Fn._p(bias_exp), Fn._p(out), Fn._p(lse), B, H, W, C, nH, 3,
+                scale, Fn.SWIN_BF16, Fn._s())
+        e.record()
+    torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in ev)
+    avg_ms = sum(ms) / len(ms)
+    alg_bytes = 8.0 * B * H * W * C
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    return {"kernel": "win_attn_fwd_bf16_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_ms": round(avg_ms, 5), "median_launch_ms": round(ms[len(ms) // 2], 5),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "shape": {"B": B, "H": H, "W": W, "C": C, "heads": nH, "shift": 3, "windows": B * 29 * 46}}
+
+
+def cpu_baseline():
+    """Oracle on the host cores: Swin-T backbone + FPN forward+backward on ONE 800x1280 image, then the C
+    RoIAlign (512 rois, 7x7, 4 levels) and NMS (8780 boxes) of one image.  Heads / losses are NOT included, so
+    this over-states what a CPU would reach on the full step."""
+    import numpy as np
+    from oracle import callers_oracle, det_ops_oracle, fpn_oracle, swin_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = swin_oracle.make_params(seed=0)
+    fp = fpn_oracle.make_params(seed=0)
+    for v in list(p.values()) + list(fp.values()):
+        v.requires_grad_(True)
+    img = torch.randn(1, 3, IMG_H, IMG_W, generator=torch.Generator().manual_seed(0))
+    t0 = time.perf_counter()
+    outs = fpn_oracle.fpn_forward(swin_oracle.swin_forward(img, p), fp, 5)
+    sum(o.square().mean() for o in outs).backward()
+    rng = np.random.RandomState(0)
+    feats = [o.detach().numpy() for o in outs[:4]]
+    xy = rng.rand(512, 2) * [IMG_W * 0.8, IMG_H * 0.8]
+    rois = np.concatenate([np.zeros((512, 1)), xy, xy + rng.rand(512, 2) * [IMG_W * 0.3, IMG_H * 0.3] + 8], 1).astype(np.float32)
+    callers_oracle.roi_extract(feats, rois, 7)
+    bxy = rng.rand(8780, 2).astype(np.float32) * [IMG_W, IMG_H]
+    boxes = np.concatenate([bxy, bxy + rng.rand(8780, 2).astype(np.float32) * 200 + 4], 1).astype(np.float32)
+    det_ops_oracle.batched_nms(boxes, rng.rand(8780).astype(np.float32), rng.randint(0, 5, 8780),
+                               dict(type="nms", iou_threshold=0.7))
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 image 3x800x1280: oracle Swin-T+FPN fwd+bwd (torch-CPU fp32) + C RoIAlign(512 rois) + "
+                      "C batched NMS(8780 boxes); heads/losses/optimizer excluded", "seconds": round(dt, 2)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from swin_transformer_object_detection_amd import data, ddp, detector, presets
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)                       # identical weights on every rank
+    model = detector.build_detector(presets.mask_rcnn_swin("tiny"), compute_dtype=dtype).to(device)
+    model.train()
+    reducer = ddp.BucketedGradReducer(model.parameters())
+    reducer.broadcast_parameters()
+    opt_cfg = presets.OPTIMIZER
+    optim = torch.optim.AdamW(build_param_groups(model, opt_cfg), lr=opt_cfg["lr"], betas=opt_cfg["betas"], fused=True)
+    batch = data.synthetic_batch(PER_GPU_BATCH, IMG_H, IMG_W, device, seed=rank)     # per-rank data
+    torch.manual_seed(1000 + rank)             # per-rank sampling / DropPath randomness
+
+    def step():
+        reducer.zero_grad()
+        losses = model.forward_train(**batch)
+        loss, log_vars = model.parse_losses(losses)
+        loss.backward()
+        reducer.finish()
+        optim.step()
+        return log_vars
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        log_vars = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        log_vars = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    logs = {k: float(v) for k, v in ddp.reduce_log_vars(log_vars).items()}
+    if not all(map(lambda v: v == v and abs(v) != float("inf"), logs.values())):
+        raise SystemExit(f"non-finite loss in the timed region: {logs}")
+
+    roof = attention_roofline(device) if rank == 0 else None
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if rank == 0:
+        gb = PER_GPU_BATCH * world
+        out = {
+            "metric": "images/sec/node Mask R-CNN Swin-T 800x1280 bf16 train (fwd+bwd+allreduce+AdamW)",
+            "value": round(gb * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "Mask R-CNN Swin-T patch4 window7, 2x3x800x1280 per GPU, 8 GT boxes+masks/image, "
+                                   "AdamW, DropPath 0.1 (BASELINE.json configs[1])",
+                       "global_batch": gb, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
+            "losses": {k: round(v, 4) for k, v in logs.items()},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

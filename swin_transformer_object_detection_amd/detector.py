@@ -1,0 +1,558 @@
+"""Callers of the hot path: the Mask R-CNN training step around backbone -> FPN -> NMS -> RoIAlign.
+
+The hot path is the Swin backbone, the FPN and the mmcv ops; to measure the
+reference's headline metric (Mask R-CNN Swin-T training images/s) those kernels have to be
+driven by a real ``forward_train``.  This file restates that orchestration with the reference's
+wiring and registry names so ``configs/swin/mask_rcnn_*.py`` build unchanged:
+
+    TwoStageDetector.forward_train     mmdet/models/detectors/two_stage.py:105-167
+    RPNHead / AnchorHead loss+targets  mmdet/models/dense_heads/rpn_head.py:27-80, anchor_head.py:175-493
+    RPNHead._get_bboxes -> batched_nms rpn_head.py:82-236
+    MaxIoUAssigner / RandomSampler     mmdet/core/bbox/assigners/max_iou_assigner.py, samplers/random_sampler.py
+    StandardRoIHead.forward_train      mmdet/models/roi_heads/standard_roi_head.py:70-194
+    SingleRoIExtractor                 roi_heads/roi_extractors/single_level_roi_extractor.py:32-108
+    Shared2FCBBoxHead / FCNMaskHead    roi_heads/bbox_heads/convfc_bbox_head.py, mask_heads/fcn_mask_head.py
+    mask_target                        mmdet/core/mask/mask_target.py:66-122 (kept on the device)
+
+The dense layers of the heads are plain library GEMM/conv calls (SURVEY 8(f) rank 1 is where they
+get their own kernels); the hot-path ops (``ops.batched_nms``, ``ops.RoIAlign``) are the HIP ones.
+Everything between the kernels runs on the device: the reference's numpy round trips in
+``mask_target`` are gone.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .registry import BACKBONES, DETECTORS, HEADS, NECKS, ROI_EXTRACTORS, build_from_cfg, build_roi_extractor
+
+
+def _cfg_get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    return cfg.get(key, default) if isinstance(cfg, dict) else getattr(cfg, key, default)
+
+
+# ------------------------------------------------------------------------------------------
+# box utilities (mmdet/core/bbox)
+# ------------------------------------------------------------------------------------------
+def bbox_overlaps(b1, b2, eps=1e-6):
+    """IoU matrix (len(b1), len(b2)); mmdet/core/bbox/iou_calculators/iou2d_calculator.py."""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, None, :2], b2[None, :, :2])
+    rb = torch.min(b1[:, None, 2:], b2[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = (a1[:, None] + a2[None, :] - inter).clamp(min=eps)
+    return inter / union
+
+
+def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+    """delta_xywh_bbox_coder.py:82-130."""
+    px = (proposals[:, 0] + proposals[:, 2]) * 0.5
+    py = (proposals[:, 1] + proposals[:, 3]) * 0.5
+    pw = proposals[:, 2] - proposals[:, 0]
+    ph = proposals[:, 3] - proposals[:, 1]
+    gx = (gt[:, 0] + gt[:, 2]) * 0.5
+    gy = (gt[:, 1] + gt[:, 3]) * 0.5
+    gw = gt[:, 2] - gt[:, 0]
+    gh = gt[:, 3] - gt[:, 1]
+    d = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
+    return (d - d.new_tensor(means)) / d.new_tensor(stds)
+
+
+def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None, wh_ratio_clip=16 / 1000):
+    """delta_xywh_bbox_coder.py:189-237 for (N,4) rois / deltas."""
+    d = deltas * deltas.new_tensor(stds) + deltas.new_tensor(means)
+    mr = abs(math.log(wh_ratio_clip))
+    dw = d[:, 2].clamp(min=-mr, max=mr)
+    dh = d[:, 3].clamp(min=-mr, max=mr)
+    px = (rois[:, 0] + rois[:, 2]) * 0.5
+    py = (rois[:, 1] + rois[:, 3]) * 0.5
+    pw = rois[:, 2] - rois[:, 0]
+    ph = rois[:, 3] - rois[:, 1]
+    gw, gh = pw * dw.exp(), ph * dh.exp()
+    gx, gy = px + pw * d[:, 0], py + ph * d[:, 1]
+    b = torch.stack([gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5], dim=-1)
+    if max_shape is not None:
+        b[:, 0::2] = b[:, 0::2].clamp(min=0, max=float(max_shape[1]))
+        b[:, 1::2] = b[:, 1::2].clamp(min=0, max=float(max_shape[0]))
+    return b
+
+
+def bbox2roi(bbox_list):
+    """mmdet/core/bbox/transforms.py:69-77."""
+    out = []
+    for i, b in enumerate(bbox_list):
+        if b.size(0) > 0:
+            out.append(torch.cat([b.new_full((b.size(0), 1), i), b[:, :4]], dim=-1))
+        else:
+            out.append(b.new_zeros((0, 5)))
+    return torch.cat(out, 0)
+
+
+class AnchorGenerator:
+    """anchor_generator.py:161-185, 255-270 (scale_major, center_offset 0)."""
+
+    def __init__(self, strides, ratios, scales):
+        self.strides = list(strides)
+        self.ratios = torch.tensor(ratios, dtype=torch.float32)
+        self.scales = torch.tensor(scales, dtype=torch.float32)
+        self.num_base_anchors = len(ratios) * len(scales)
+        self._cache = {}
+
+    def _base(self, stride):
+        h_r = torch.sqrt(self.ratios)
+        w_r = 1 / h_r
+        ws = (stride * w_r[:, None] * self.scales[None, :]).view(-1)
+        hs = (stride * h_r[:, None] * self.scales[None, :]).view(-1)
+        return torch.stack([-0.5 * ws, -0.5 * hs, 0.5 * ws, 0.5 * hs], dim=-1)
+
+    def grid_anchors(self, featmap_sizes, device):
+        key = (tuple(featmap_sizes), str(device))
+        if key not in self._cache:
+            out = []
+            for (h, w), s in zip(featmap_sizes, self.strides):
+                base = self._base(s).to(device)
+                sx = torch.arange(0, w, device=device, dtype=torch.float32) * s
+                sy = torch.arange(0, h, device=device, dtype=torch.float32) * s
+                yy, xx = torch.meshgrid(sy, sx, indexing='ij')
+                shifts = torch.stack([xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)], dim=-1)
+                out.append((shifts[:, None, :] + base[None, :, :]).view(-1, 4))
+            self._cache[key] = out
+        return self._cache[key]
+
+
+def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality=True, gt_labels=None):
+    """MaxIoUAssigner.assign_wrt_overlaps (max_iou_assigner.py:130-212), ignore_iof_thr=-1."""
+    n = bboxes.size(0)
+    assigned = bboxes.new_full((n,), -1, dtype=torch.long)
+    if gt_bboxes.size(0) == 0 or n == 0:
+        assigned[:] = 0
+        labels = None if gt_labels is None else bboxes.new_full((n,), -1, dtype=torch.long)
+        return assigned, bboxes.new_zeros((n,)), labels
+    overlaps = bbox_overlaps(gt_bboxes, bboxes)
+    max_ov, argmax = overlaps.max(dim=0)
+    gt_max, _ = overlaps.max(dim=1)
+    assigned[(max_ov >= 0) & (max_ov < neg_iou_thr)] = 0
+    pos = max_ov >= pos_iou_thr
+    assigned[pos] = argmax[pos] + 1
+    if match_low_quality:
+        # later gts override earlier ones, as the reference's python loop does: take the LAST gt whose
+        # row attains its own maximum at this box
+        hit = (overlaps == gt_max[:, None]) & (gt_max[:, None] >= min_pos_iou)
+        idx = torch.arange(1, gt_bboxes.size(0) + 1, device=bboxes.device)[:, None].expand_as(hit)
+        last = torch.where(hit, idx, torch.zeros_like(idx)).max(dim=0)[0]
+        assigned = torch.where(last > 0, last, assigned)
+    labels = None
+    if gt_labels is not None:
+        labels = assigned.new_full((n,), -1)
+        p = assigned > 0
+        labels[p] = gt_labels[assigned[p] - 1]
+    return assigned, max_ov, labels
+
+
+def random_sample(assigned, num, pos_fraction):
+    """RandomSampler (random_sampler.py:31-78), neg_pos_ub=-1."""
+    pos_inds = torch.nonzero(assigned > 0, as_tuple=False).view(-1)
+    num_pos = int(num * pos_fraction)
+    if pos_inds.numel() > num_pos:
+        pos_inds = pos_inds[torch.randperm(pos_inds.numel(), device=pos_inds.device)[:num_pos]]
+    neg_inds = torch.nonzero(assigned == 0, as_tuple=False).view(-1)
+    num_neg = num - pos_inds.numel()
+    if neg_inds.numel() > num_neg:
+        neg_inds = neg_inds[torch.randperm(neg_inds.numel(), device=neg_inds.device)[:num_neg]]
+    return pos_inds, neg_inds
+
+
+def _cast(t, dtype):
+    return t if t.dtype == dtype else t.to(dtype)
+
+
+def _conv(x, conv, dtype, padding=0, relu=False):
+    w = _cast(conv.weight, dtype).contiguous(memory_format=torch.channels_last)
+    y = F.conv2d(x, w, _cast(conv.bias, dtype), padding=padding)
+    return F.relu(y, inplace=True) if relu else y
+
+
+# ------------------------------------------------------------------------------------------
+# RPN
+# ------------------------------------------------------------------------------------------
+@HEADS.register_module()
+class RPNHead(nn.Module):
+    def __init__(self, in_channels, feat_channels=256, anchor_generator=None, bbox_coder=None, loss_cls=None,
+                 loss_bbox=None, train_cfg=None, test_cfg=None, compute_dtype=torch.float32, **kwargs):
+        super().__init__()
+        ag = dict(anchor_generator)
+        assert ag.pop('type', 'AnchorGenerator') == 'AnchorGenerator'
+        self.anchor_generator = AnchorGenerator(ag['strides'], ag['ratios'], ag['scales'])
+        self.num_anchors = self.anchor_generator.num_base_anchors
+        bc = dict(bbox_coder or {})
+        self.means = tuple(bc.get('target_means', (0., 0., 0., 0.)))
+        self.stds = tuple(bc.get('target_stds', (1., 1., 1., 1.)))
+        self.loss_cls_weight = _cfg_get(loss_cls, 'loss_weight', 1.0)
+        self.loss_bbox_weight = _cfg_get(loss_bbox, 'loss_weight', 1.0)
+        if _cfg_get(loss_bbox, 'type', 'L1Loss') != 'L1Loss' or not _cfg_get(loss_cls, 'use_sigmoid', True):
+            raise NotImplementedError("RPN: sigmoid CE + L1 (the swin configs)")
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.compute_dtype = compute_dtype
+        self.rpn_conv = nn.Conv2d(in_channels, feat_channels, 3, padding=1)
+        self.rpn_cls = nn.Conv2d(feat_channels, self.num_anchors, 1)
+        self.rpn_reg = nn.Conv2d(feat_channels, self.num_anchors * 4, 1)
+
+    def init_weights(self):                                     # rpn_head.py:34-39
+        for m in (self.rpn_conv, self.rpn_cls, self.rpn_reg):
+            nn.init.normal_(m.weight, std=0.01)
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, feats):                                   # rpn_head.py:41-47
+        dt = self.compute_dtype
+        cls, reg = [], []
+        for x in feats:
+            x = _conv(x, self.rpn_conv, dt, padding=1, relu=True)
+            cls.append(_conv(x, self.rpn_cls, dt))
+            reg.append(_conv(x, self.rpn_reg, dt))
+        return cls, reg
+
+    # ---- training targets + loss (anchor_head.py:175-493) ----
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, img_shapes):
+        cfg = self.train_cfg
+        a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        anchors = torch.cat(self.anchor_generator.grid_anchors(sizes, cls_scores[0].device), 0)
+        B = cls_scores[0].size(0)
+        A = anchors.size(0)
+        labels = anchors.new_full((B, A), 1, dtype=torch.long)            # background = num_classes = 1
+        label_w = anchors.new_zeros((B, A))
+        bbox_t = anchors.new_zeros((B, A, 4))
+        bbox_w = anchors.new_zeros((B, A, 4))
+        total = 0
+        for i in range(B):
+            assigned, _, _ = max_iou_assign(anchors, gt_bboxes[i], a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'],
+                                            a_cfg['min_pos_iou'], a_cfg.get('match_low_quality', True))
+            pos, neg = random_sample(assigned, s_cfg['num'], s_cfg['pos_fraction'])
+            if pos.numel() > 0:
+                bbox_t[i, pos] = bbox2delta(anchors[pos], gt_bboxes[i][assigned[pos] - 1], self.means, self.stds)
+                bbox_w[i, pos] = 1.0
+                labels[i, pos] = 0
+                label_w[i, pos] = 1.0
+            label_w[i, neg] = 1.0
+            total += pos.numel() + neg.numel()
+        avg = float(max(total, 1))
+        cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1).float()
+        reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1).float()
+        target = (labels == 0).float()
+        loss_cls = (F.binary_cross_entropy_with_logits(cls, target, reduction='none') * label_w).sum() / avg
+        loss_bbox = ((reg - bbox_t).abs() * bbox_w).sum() / avg
+        return dict(loss_rpn_cls=loss_cls * self.loss_cls_weight, loss_rpn_bbox=loss_bbox * self.loss_bbox_weight)
+
+    # ---- proposals (rpn_head.py:82-236): detached, per level top-k by a full stable sort ----
+    @torch.no_grad()
+    def get_bboxes(self, cls_scores, bbox_preds, img_shapes, cfg):
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        mlvl_anchors = self.anchor_generator.grid_anchors(sizes, cls_scores[0].device)
+        B = cls_scores[0].size(0)
+        nms_pre = cfg['nms_pre']
+        sc_l, bp_l, an_l, id_l = [], [], [], []
+        for lvl, (cs, bp) in enumerate(zip(cls_scores, bbox_preds)):
+            s = cs.detach().permute(0, 2, 3, 1).reshape(B, -1).float().sigmoid()
+            d = bp.detach().permute(0, 2, 3, 1).reshape(B, -1, 4).float()
+            an = mlvl_anchors[lvl][None].expand(B, -1, -1)
+            if s.shape[1] > nms_pre:
+                ranked, rank_inds = s.sort(dim=1, descending=True, stable=True)
+                topk = rank_inds[:, :nms_pre]
+                s = ranked[:, :nms_pre]
+                d = torch.gather(d, 1, topk[..., None].expand(-1, -1, 4))
+                an = torch.gather(an, 1, topk[..., None].expand(-1, -1, 4))
+            sc_l.append(s); bp_l.append(d); an_l.append(an)
+            id_l.append(s.new_full((B, s.size(1)), lvl, dtype=torch.long))
+        scores, deltas = torch.cat(sc_l, 1), torch.cat(bp_l, 1)
+        anchors, ids = torch.cat(an_l, 1), torch.cat(id_l, 1)
+        out = []
+        for i in range(B):
+            props = delta2bbox(anchors[i], deltas[i], self.means, self.stds, max_shape=img_shapes[i])
+            if cfg.get('min_bbox_size', 0) > 0:
+                w, h = props[:, 2] - props[:, 0], props[:, 3] - props[:, 1]
+                v = (w >= cfg['min_bbox_size']) & (h >= cfg['min_bbox_size'])
+                props, sc, idl = props[v], scores[i][v], ids[i][v]
+            else:
+                sc, idl = scores[i], ids[i]
+            dets, _ = ops.batched_nms(props, sc, idl, cfg['nms'])               # HIP nms
+            out.append(dets[:cfg['max_per_img']])
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+# RoI extractor / heads
+# ------------------------------------------------------------------------------------------
+@ROI_EXTRACTORS.register_module()
+class SingleRoIExtractor(nn.Module):
+    """single_level_roi_extractor.py:32-108 over ops.RoIAlign (looked up by name as the reference does)."""
+
+    def __init__(self, roi_layer, out_channels, featmap_strides, finest_scale=56):
+        super().__init__()
+        cfg = dict(roi_layer)
+        layer_type = cfg.pop('type')
+        assert hasattr(ops, layer_type)                          # base_roi_extractor.py:51
+        layer_cls = getattr(ops, layer_type)
+        self.roi_layers = nn.ModuleList([layer_cls(spatial_scale=1 / s, **cfg) for s in featmap_strides])
+        self.out_channels, self.featmap_strides, self.finest_scale = out_channels, featmap_strides, finest_scale
+        self.fp16_enabled = False
+
+    @property
+    def num_inputs(self):
+        return len(self.featmap_strides)
+
+    def map_roi_levels(self, rois, num_levels):                  # :47-51
+        scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+        lv = torch.floor(torch.log2(scale / self.finest_scale + 1e-6))
+        return lv.clamp(min=0, max=num_levels - 1).long()
+
+    def forward(self, feats, rois, roi_scale_factor=None):
+        out_size = self.roi_layers[0].output_size
+        num_levels = len(feats)
+        cl = feats[0].is_contiguous(memory_format=torch.channels_last) and not feats[0].is_contiguous()
+        roi_feats = torch.empty((rois.size(0), self.out_channels, *out_size), device=rois.device, dtype=torch.float32,
+                                memory_format=torch.channels_last if cl else torch.contiguous_format).zero_()
+        if rois.size(0) == 0:
+            return roi_feats
+        if num_levels == 1:
+            return self.roi_layers[0](feats[0], rois)
+        lvls = self.map_roi_levels(rois, num_levels)
+        # one stable sort groups the rois by level (no per-level nonzero sync); scatter back by index_copy
+        order = torch.sort(lvls, stable=True)[1]
+        counts = torch.bincount(lvls, minlength=num_levels).tolist()
+        start = 0
+        pieces = []
+        dummy = 0.
+        for i in range(num_levels):
+            n = counts[i]
+            if n > 0:
+                inds = order[start:start + n]
+                pieces.append((inds, self.roi_layers[i](feats[i], rois[inds])))
+            else:
+                # keep every level in the graph (single_level_roi_extractor.py:98-107: avoids a DDP hang)
+                dummy = dummy + feats[i].sum() * 0.
+            start += n
+        roi_feats = roi_feats.index_copy(0, torch.cat([p[0] for p in pieces]), torch.cat([p[1] for p in pieces]))
+        if isinstance(dummy, torch.Tensor):
+            roi_feats = roi_feats + dummy.float()
+        return roi_feats
+
+
+@HEADS.register_module()
+class Shared2FCBBoxHead(nn.Module):
+    """convfc_bbox_head.py:135 (2 shared fcs) + bbox_head.py loss/targets."""
+
+    def __init__(self, in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=80, bbox_coder=None,
+                 reg_class_agnostic=False, loss_cls=None, loss_bbox=None, compute_dtype=torch.float32, **kwargs):
+        super().__init__()
+        bc = dict(bbox_coder or {})
+        self.means = tuple(bc.get('target_means', (0., 0., 0., 0.)))
+        self.stds = tuple(bc.get('target_stds', (0.1, 0.1, 0.2, 0.2)))
+        if reg_class_agnostic or _cfg_get(loss_bbox, 'type', 'L1Loss') != 'L1Loss':
+            raise NotImplementedError("Shared2FCBBoxHead: class-specific L1 regression (mask_rcnn swin configs)")
+        self.num_classes = num_classes
+        self.loss_cls_weight = _cfg_get(loss_cls, 'loss_weight', 1.0)
+        self.loss_bbox_weight = _cfg_get(loss_bbox, 'loss_weight', 1.0)
+        self.compute_dtype = compute_dtype
+        area = roi_feat_size * roi_feat_size
+        self.shared_fcs = nn.ModuleList([nn.Linear(in_channels * area, fc_out_channels),
+                                         nn.Linear(fc_out_channels, fc_out_channels)])
+        self.fc_cls = nn.Linear(fc_out_channels, num_classes + 1)
+        self.fc_reg = nn.Linear(fc_out_channels, 4 * num_classes)
+
+    def init_weights(self):
+        for m in self.shared_fcs:
+            nn.init.xavier_uniform_(m.weight); nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self.fc_cls.weight, 0, 0.01); nn.init.constant_(self.fc_cls.bias, 0)
+        nn.init.normal_(self.fc_reg.weight, 0, 0.001); nn.init.constant_(self.fc_reg.bias, 0)
+
+    def forward(self, x):
+        dt = self.compute_dtype
+        x = _cast(x.flatten(1), dt)                 # (K, C*7*7) in the reference's (C,7,7) order
+        for fc in self.shared_fcs:
+            x = F.relu(F.linear(x, _cast(fc.weight, dt), _cast(fc.bias, dt)), inplace=True)
+        cls = F.linear(x, _cast(self.fc_cls.weight, dt), _cast(self.fc_cls.bias, dt))
+        reg = F.linear(x, _cast(self.fc_reg.weight, dt), _cast(self.fc_reg.bias, dt))
+        return cls, reg
+
+    def loss(self, cls_score, bbox_pred, labels, bbox_targets, num_pos_mask):
+        cls_score, bbox_pred = cls_score.float(), bbox_pred.float()
+        n = cls_score.size(0)
+        loss_cls = F.cross_entropy(cls_score, labels, reduction='sum') / max(float(n), 1.)
+        acc = (cls_score.argmax(1) == labels).float().mean() * 100
+        pos = num_pos_mask
+        pred = bbox_pred.view(n, -1, 4)[pos, labels[pos]]
+        loss_bbox = (pred - bbox_targets[pos]).abs().sum() / max(float(n), 1.)
+        return dict(loss_cls=loss_cls * self.loss_cls_weight, acc=acc, loss_bbox=loss_bbox * self.loss_bbox_weight)
+
+
+@HEADS.register_module()
+class FCNMaskHead(nn.Module):
+    """fcn_mask_head.py:20-126: 4x (conv3x3+ReLU), deconv 2x2 s2 + ReLU, conv1x1 -> num_classes."""
+
+    def __init__(self, num_convs=4, roi_feat_size=14, in_channels=256, conv_kernel_size=3, conv_out_channels=256,
+                 num_classes=80, class_agnostic=False, upsample_cfg=dict(type='deconv', scale_factor=2), loss_mask=None,
+                 compute_dtype=torch.float32, **kwargs):
+        super().__init__()
+        if upsample_cfg.get('type', 'deconv') != 'deconv' or class_agnostic or conv_kernel_size != 3:
+            raise NotImplementedError("FCNMaskHead: deconv upsampling, class-specific masks (swin configs)")
+        self.num_classes, self.compute_dtype = num_classes, compute_dtype
+        self.loss_mask_weight = _cfg_get(loss_mask, 'loss_weight', 1.0)
+        from .fpn import ConvModule
+        self.convs = nn.ModuleList([ConvModule(in_channels if i == 0 else conv_out_channels, conv_out_channels, 3, padding=1)
+                                    for i in range(num_convs)])
+        self.upsample = nn.ConvTranspose2d(conv_out_channels, conv_out_channels, 2, stride=2)
+        self.conv_logits = nn.Conv2d(conv_out_channels, num_classes, 1)
+
+    def init_weights(self):
+        for m in [self.upsample, self.conv_logits]:
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        dt = self.compute_dtype
+        x = _cast(x, dt).contiguous(memory_format=torch.channels_last)
+        for c in self.convs:
+            x = _conv(x, c.conv, dt, padding=1, relu=True)
+        x = F.relu(F.conv_transpose2d(x, _cast(self.upsample.weight, dt), _cast(self.upsample.bias, dt), stride=2),
+                   inplace=True)
+        return _conv(x, self.conv_logits, dt)
+
+    def loss(self, mask_pred, mask_targets, labels):
+        if mask_pred.size(0) == 0:
+            return dict(loss_mask=mask_pred.sum() * 0)
+        pred = mask_pred.float()[torch.arange(mask_pred.size(0), device=mask_pred.device), labels]
+        return dict(loss_mask=F.binary_cross_entropy_with_logits(pred, mask_targets, reduction='mean') * self.loss_mask_weight)
+
+
+@HEADS.register_module()
+class StandardRoIHead(nn.Module):
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None, shared_head=None,
+                 train_cfg=None, test_cfg=None, compute_dtype=torch.float32):
+        super().__init__()
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.bbox_roi_extractor = build_roi_extractor(bbox_roi_extractor)
+        self.bbox_head = build_from_cfg(bbox_head, HEADS, dict(compute_dtype=compute_dtype))
+        self.mask_roi_extractor = build_roi_extractor(mask_roi_extractor) if mask_roi_extractor else None
+        self.mask_head = build_from_cfg(mask_head, HEADS, dict(compute_dtype=compute_dtype)) if mask_head else None
+
+    def init_weights(self, pretrained=None):
+        self.bbox_head.init_weights()
+        if self.mask_head is not None:
+            self.mask_head.init_weights()
+
+    def forward_train(self, x, proposal_list, gt_bboxes, gt_labels, gt_masks):
+        """standard_roi_head.py:70-131.  gt_masks: list of (G_i, H, W) uint8/bool tensors on the device."""
+        cfg = self.train_cfg
+        a, s = cfg['assigner'], cfg['sampler']
+        nimg = len(proposal_list)
+        rois_l, labels_l, tgt_l, pos_l = [], [], [], []
+        pos_boxes, pos_gt_inds, pos_labels = [], [], []
+        for i in range(nimg):
+            props = proposal_list[i][:, :4]
+            if s.get('add_gt_as_proposals', True):
+                props = torch.cat([gt_bboxes[i], props], 0)
+            assigned, _, lab = max_iou_assign(props, gt_bboxes[i], a['pos_iou_thr'], a['neg_iou_thr'], a['min_pos_iou'],
+                                              a.get('match_low_quality', True), gt_labels[i])
+            if s.get('add_gt_as_proposals', True):          # AssignResult.add_gt_: gts are assigned to themselves
+                g = gt_bboxes[i].size(0)
+                assigned[:g] = torch.arange(1, g + 1, device=assigned.device)
+                lab[:g] = gt_labels[i]
+            pos, neg = random_sample(assigned, s['num'], s['pos_fraction'])
+            pb, nb = props[pos], props[neg]
+            rois_l.append(torch.cat([pb, nb], 0))
+            lab_i = props.new_full((pos.numel() + neg.numel(),), self.bbox_head.num_classes, dtype=torch.long)
+            lab_i[:pos.numel()] = lab[pos]
+            t_i = props.new_zeros((pos.numel() + neg.numel(), 4))
+            if pos.numel() > 0:
+                t_i[:pos.numel()] = bbox2delta(pb, gt_bboxes[i][assigned[pos] - 1], self.bbox_head.means, self.bbox_head.stds)
+            m_i = torch.zeros(pos.numel() + neg.numel(), dtype=torch.bool, device=props.device)
+            m_i[:pos.numel()] = True
+            labels_l.append(lab_i); tgt_l.append(t_i); pos_l.append(m_i)
+            pos_boxes.append(pb); pos_gt_inds.append(assigned[pos] - 1); pos_labels.append(lab[pos])
+        losses = {}
+        rois = bbox2roi(rois_l)
+        feats = x[:self.bbox_roi_extractor.num_inputs]
+        bbox_feats = self.bbox_roi_extractor(feats, rois)                         # HIP RoIAlign
+        cls_score, bbox_pred = self.bbox_head(bbox_feats)
+        losses.update(self.bbox_head.loss(cls_score, bbox_pred, torch.cat(labels_l), torch.cat(tgt_l), torch.cat(pos_l)))
+        if self.mask_head is not None:
+            pos_rois = bbox2roi(pos_boxes)
+            mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois)
+            mask_pred = self.mask_head(mask_feats)
+            size = cfg.get('mask_size', 28)
+            tg = []
+            for i in range(nimg):                                                 # mask_target.py:66-122, on device
+                if pos_boxes[i].size(0) == 0:
+                    tg.append(pos_boxes[i].new_zeros((0, size, size)))
+                    continue
+                m = gt_masks[i].to(torch.bfloat16)[:, None].contiguous()          # 0/1 exact in bf16
+                r = torch.cat([pos_gt_inds[i].to(pos_boxes[i].dtype)[:, None], pos_boxes[i]], 1)
+                t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)        # structures.py:353-354
+                tg.append((t[:, 0] >= 0.5).float())
+            losses.update(self.mask_head.loss(mask_pred, torch.cat(tg), torch.cat(pos_labels)))
+        return losses
+
+
+@DETECTORS.register_module()
+class MaskRCNN(nn.Module):
+    """TwoStageDetector wiring (two_stage.py:17-167) for the Mask R-CNN swin configs."""
+
+    def __init__(self, backbone, neck=None, rpn_head=None, roi_head=None, train_cfg=None, test_cfg=None, pretrained=None,
+                 compute_dtype=torch.float32):
+        super().__init__()
+        self.compute_dtype = compute_dtype
+        self.backbone = build_from_cfg(backbone, BACKBONES, dict(compute_dtype=compute_dtype))
+        self.neck = build_from_cfg(neck, NECKS, dict(compute_dtype=compute_dtype)) if neck is not None else None
+        rpn_train = _cfg_get(train_cfg, 'rpn')
+        self.rpn_head = build_from_cfg(rpn_head, HEADS, dict(train_cfg=rpn_train, test_cfg=_cfg_get(test_cfg, 'rpn'),
+                                                             compute_dtype=compute_dtype))
+        self.roi_head = build_from_cfg(roi_head, HEADS, dict(train_cfg=_cfg_get(train_cfg, 'rcnn'),
+                                                             test_cfg=_cfg_get(test_cfg, 'rcnn'),
+                                                             compute_dtype=compute_dtype))
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_weights(pretrained)
+
+    def init_weights(self, pretrained=None):                    # two_stage.py:50-68
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.neck is not None:
+            self.neck.init_weights()
+        self.rpn_head.init_weights()
+        self.roi_head.init_weights(pretrained)
+
+    def extract_feat(self, img):                                # two_stage.py:80-85
+        x = self.backbone(img)
+        return self.neck(x) if self.neck is not None else x
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_masks=None, proposals=None):
+        x = self.extract_feat(img)
+        losses = {}
+        img_shapes = [m['img_shape'] for m in img_metas]
+        cls_scores, bbox_preds = self.rpn_head(x)
+        losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_shapes))
+        proposal_cfg = _cfg_get(self.train_cfg, 'rpn_proposal', _cfg_get(self.test_cfg, 'rpn'))
+        proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_shapes, proposal_cfg)
+        losses.update(self.roi_head.forward_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks))
+        return losses
+
+    @staticmethod
+    def parse_losses(losses):
+        """base.py:185-218 without the per-scalar all-reduce/.item(): returns (loss tensor, dict of tensors)."""
+        total = sum(v for k, v in losses.items() if 'loss' in k)
+        return total, losses
+
+
+def build_detector(cfg, train_cfg=None, test_cfg=None, compute_dtype=torch.float32):
+    """mmdet/models/builder.py:67-77."""
+    cfg = dict(cfg)
+    if train_cfg is not None:
+        cfg['train_cfg'] = train_cfg
+    if test_cfg is not None:
+        cfg['test_cfg'] = test_cfg
+    return build_from_cfg(cfg, DETECTORS, dict(compute_dtype=compute_dtype))
