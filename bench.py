@@ -91,7 +91,11 @@ def cpu_baseline():
     this over-states what a CPU would reach on the full step."""
     import numpy as np
     from oracle import callers_oracle, det_ops_oracle, fpn_oracle, swin_oracle
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, 16)      # a 1-GPU box owns a 16-core share of the host (more threads only oversubscribe)
     torch.set_num_threads(cores)
     p = swin_oracle.make_params(seed=0)
     fp = fpn_oracle.make_params(seed=0)

@@ -135,6 +135,21 @@ int fpn_upsample_add_bwd(const void* dfine, void* dcoarse, int N, int C, int Hf,
                          int channels_last, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * bf16 MFMA implicit-GEMM convolution, 3x3 / pad 1 / stride 1, channels-last.  Replaces the conv
+ * library calls behind FPN's output convs (fpn.py:195-197), the RPN conv (rpn_head.py:43) and the FCN
+ * mask-head convs (fcn_mask_head.py:119-121).
+ *   x (N,H,W,Cin) bf16;  w (Cout,3,3,Cin) bf16 (= channels_last memory of the (Cout,Cin,3,3) parameter);
+ *   bias (Cout) f32 or NULL;  y (N,H,W,Cout) bf16 = conv(x,w)+bias, ReLU if relu != 0.
+ *   Cin % 64 == 0, Cout % 4 == 0.  The data gradient is the same call on dy with the 180-degree rotated,
+ *   in/out-transposed weight.
+ * gemm_nt_bf16: c (M,N) = a (M,K) w(N,K)^T + bias, same core with a plain A loader (K % 64 == 0).
+ * ---------------------------------------------------------------------------------- */
+int conv3x3_nhwc_bf16(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin,
+                      int Cout, int relu, void* stream);
+int gemm_nt_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int relu,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------
  * mmcv.ops.RoIAlign / roi_align ('avg', aligned flag) -- call sites
  * base_roi_extractor.py:49-55, single_level_roi_extractor.py:93-97, structures.py:353-354.
  * rois (K,5) f32 [batch_idx,x1,y1,x2,y2]; arithmetic and output fp32.

@@ -174,8 +174,20 @@ def _cast(t, dtype):
 
 
 def _conv(x, conv, dtype, padding=0, relu=False):
-    w = _cast(conv.weight, dtype).contiguous(memory_format=torch.channels_last)
-    y = F.conv2d(x, w, _cast(conv.bias, dtype), padding=padding)
+    """conv on a channels-last activation.  1x1 convs are GEMMs over the token-major view (no conv
+    library involved); 3x3 convs go to the conv library with PACKED channels-last operands (a strided
+    view silently selects MIOpen's naive reference kernels)."""
+    N, C, H, W = x.shape
+    if conv.kernel_size == (1, 1):
+        tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
+        y = F.linear(tok, _cast(conv.weight, dtype).view(conv.out_channels, C), _cast(conv.bias, dtype))
+        y = y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
+    elif dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and padding == 1 and C % 64 == 0:
+        return ops.conv3x3(x, conv.weight, conv.bias, relu)              # HIP implicit-GEMM kernel (ReLU fused)
+    else:
+        x = x.contiguous(memory_format=torch.channels_last)
+        w = _cast(conv.weight, dtype).contiguous(memory_format=torch.channels_last)
+        y = F.conv2d(x, w, _cast(conv.bias, dtype), padding=padding)
     return F.relu(y, inplace=True) if relu else y
 
 
@@ -420,9 +432,20 @@ class FCNMaskHead(nn.Module):
         x = _cast(x, dt).contiguous(memory_format=torch.channels_last)
         for c in self.convs:
             x = _conv(x, c.conv, dt, padding=1, relu=True)
-        x = F.relu(F.conv_transpose2d(x, _cast(self.upsample.weight, dt), _cast(self.upsample.bias, dt), stride=2),
-                   inplace=True)
+        x = self._deconv2x2_relu(x, dt)
         return _conv(x, self.conv_logits, dt)
+
+    def _deconv2x2_relu(self, x, dt):
+        """ConvTranspose2d(k=2, s=2) + ReLU (fcn_mask_head.py:122-125) as one GEMM over tokens followed by a
+        2x2 pixel shuffle: out[n,co,2y+ky,2x+kx] = sum_ci x[n,ci,y,x] W[ci,co,ky,kx] + b[co]."""
+        P, C, H, W = x.shape
+        Co = self.upsample.out_channels
+        tok = x.permute(0, 2, 3, 1).reshape(P * H * W, C)
+        w = _cast(self.upsample.weight, dt).permute(2, 3, 1, 0).reshape(4 * Co, C)     # rows (ky,kx,co)
+        b = _cast(self.upsample.bias, dt).repeat(4)
+        y = F.relu(F.linear(tok, w, b), inplace=True)                                  # (P*H*W, 4*Co)
+        y = y.view(P, H, W, 2, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(P, 2 * H, 2 * W, Co)
+        return y.permute(0, 3, 1, 2)                                                   # channels-last view
 
     def loss(self, mask_pred, mask_targets, labels):
         if mask_pred.size(0) == 0:

@@ -82,9 +82,13 @@ class FPN(nn.Module):
             laterals.append(y.view(N, H, W, self.out_channels).permute(0, 3, 1, 2))
         for i in range(len(laterals) - 1, 0, -1):               # fpn.py:182-191
             laterals[i - 1] = ops.upsample_add(laterals[i - 1], laterals[i])
-        outs = [F.conv2d(laterals[i], self._w(fc.conv.weight).contiguous(memory_format=torch.channels_last),
-                         self._w(fc.conv.bias), padding=1)
-                for i, fc in enumerate(self.fpn_convs)]         # fpn.py:195-197
+        if dt == torch.bfloat16 and self.out_channels % 64 == 0:
+            outs = [ops.conv3x3(laterals[i], fc.conv.weight, fc.conv.bias) for i, fc in enumerate(self.fpn_convs)]
+        else:                                                   # fp32 parity path: library conv
+            outs = [F.conv2d(laterals[i].contiguous(memory_format=torch.channels_last),
+                             self._w(fc.conv.weight).contiguous(memory_format=torch.channels_last),
+                             self._w(fc.conv.bias), padding=1)
+                    for i, fc in enumerate(self.fpn_convs)]     # fpn.py:195-197
         for _ in range(self.num_outs - len(outs)):              # fpn.py:202-204: max_pool2d(k=1, s=2)
-            outs.append(outs[-1][:, :, ::2, ::2])
+            outs.append(outs[-1][:, :, ::2, ::2].contiguous(memory_format=torch.channels_last))
         return tuple(outs)

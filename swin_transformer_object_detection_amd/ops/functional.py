@@ -330,3 +330,63 @@ class _UpsampleAdd(torch.autograd.Function):
 def upsample_add(fine, coarse):
     """fine + nearest_upsample(coarse, size=fine.shape[2:])  (fpn.py:188-191)."""
     return _UpsampleAdd.apply(fine, coarse)
+
+
+# --------------------------------------------------------------------------------------
+# 3x3 convolution (bf16, channels-last) on the MFMA implicit-GEMM kernel
+# --------------------------------------------------------------------------------------
+def _conv3x3_raw(x_cl, w_khwc, bias, relu):
+    """x_cl: (N,C,H,W) bf16 with channels_last strides; w_khwc: (Cout,3,3,Cin) bf16 contiguous."""
+    N, Cin, H, W = x_cl.shape
+    Cout = w_khwc.shape[0]
+    y = torch.empty((N, Cout, H, W), device=x_cl.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    call("conv3x3_nhwc_bf16", _p(x_cl), _p(w_khwc), _p(bias), _p(y), N, H, W, Cin, Cout, int(relu), _s())
+    return y
+
+
+def _im2col3x3(x_cl):
+    """(N,C,H,W) channels-last -> (N*H*W, 9*C) with column order (ky, kx, c) -- used for the weight gradient."""
+    N, C, H, W = x_cl.shape
+    xp = torch.nn.functional.pad(x_cl.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))      # (N, H+2, W+2, C)
+    cols = torch.cat([xp[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)], dim=-1)
+    return cols.reshape(N * H * W, 9 * C)
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        if x.dtype != torch.bfloat16 or not x.is_cuda:
+            raise SwinHipError("conv3x3: bf16 GPU activations only (fp32 parity runs use the library conv)")
+        x = x.contiguous(memory_format=torch.channels_last)
+        w = weight.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()               # (Cout,3,3,Cin)
+        b = None if bias is None else _f32(bias.float()).contiguous()
+        y = _conv3x3_raw(x, w, b, relu)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if ctx.relu:
+            dy = dy * (y > 0)
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx = conv(dy, rot180(w) with in/out swapped): (Cin, 3, 3, Cout)
+            wt = weight.to(torch.bfloat16).flip(2, 3).permute(1, 2, 3, 0).contiguous()
+            dx = _conv3x3_raw(dy, wt, None, False)
+        if ctx.needs_input_grad[1]:
+            cols = _im2col3x3(x)                                                       # (M, 9*Cin)
+            dyt = dy.permute(0, 2, 3, 1).reshape(N * H * W, Cout)
+            dw = (dyt.t() @ cols).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.permute(0, 2, 3, 1).reshape(-1, Cout).sum(0, dtype=torch.float32)
+        return dx, dw, db, None
+
+
+def conv3x3(x, weight, bias=None, relu=False):
+    """3x3, padding 1, stride 1 conv of a logically-NCHW bf16 tensor (channels-last memory)."""
+    return _Conv3x3.apply(x, weight, bias, relu)

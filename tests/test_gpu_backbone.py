@@ -162,3 +162,16 @@ def test_full_size_attention_sampled_windows(pkg):
             got = out32[b].cpu()[src.clamp(min=0)]
             valid = src >= 0
             np.testing.assert_allclose(got[valid].numpy(), ref[valid].numpy(), atol=2e-4)
+
+
+def test_mask_head_deconv_as_gemm(pkg):
+    """FCNMaskHead's ConvTranspose2d(2, stride 2)+ReLU expressed as GEMM + pixel shuffle == F.conv_transpose2d."""
+    import torch.nn.functional as F
+    from swin_transformer_object_detection_amd.detector import FCNMaskHead
+    torch.manual_seed(0)
+    h = FCNMaskHead(num_convs=1, in_channels=64, conv_out_channels=64, num_classes=5)
+    h.init_weights()
+    x = torch.randn(3, 64, 14, 14)
+    ref = F.relu(F.conv_transpose2d(x, h.upsample.weight, h.upsample.bias, stride=2))
+    got = h.cuda()._deconv2x2_relu(x.cuda().contiguous(memory_format=torch.channels_last), torch.float32)
+    _cmp(got, ref.detach().numpy(), 1e-4)

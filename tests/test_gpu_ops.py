@@ -353,3 +353,32 @@ def test_nms_empty_and_batched(ops):
     d0, k0 = ops.batched_nms(torch.zeros(0, 4, device="cuda"), torch.zeros(0, device="cuda"),
                              torch.zeros(0, dtype=torch.long, device="cuda"), dict(type="nms", iou_threshold=0.5))
     assert d0.shape == (0, 5) and k0.shape == (0,)
+
+
+# ------------------------------------------------------------------------------------------
+# MFMA implicit-GEMM 3x3 convolution (bf16)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Cin,Cout,relu", [(2, 13, 20, 64, 64, False), (1, 25, 40, 256, 256, True),
+                                                  (3, 7, 9, 128, 192, False), (2, 50, 80, 256, 256, False)])
+def test_conv3x3_bf16(ops, N, H, W, Cin, Cout, relu):
+    """Oracle: fp32 F.conv2d on the CPU with the same bf16-rounded operands (fpn.py:195-197 semantics).
+    Tolerance: bf16 output rounding (2^-8 relative) of sums of 9*Cin bf16 products accumulated in fp32."""
+    g = torch.Generator().manual_seed(N * H + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).bfloat16().float()
+    b = torch.randn(Cout, generator=g) * 0.1
+    gy = torch.randn(N, Cout, H, W, generator=g).bfloat16().float()
+    x0, w0, b0 = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(x0, w0, b0, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    (ref * gy).sum().backward()
+    x1 = x.cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w1, b1 = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.conv3x3(x1, w1, b1, relu)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    (y.float() * gy.cuda()).sum().backward()
+    close(y, ref, bf16_tol(ref, 2), msg="y")
+    close(x1.grad, x0.grad, bf16_tol(x0.grad, 3), msg="dx")
+    close(w1.grad, w0.grad, bf16_tol(w0.grad, 3), msg="dw")
+    close(b1.grad, b0.grad, bf16_tol(b0.grad, 3) + 1e-2, msg="db")
