@@ -1,0 +1,136 @@
+"""CPU tests of the host-side mirror: registry, config loader, module construction / state_dict schema,
+box utilities, assigner and sampler (pure torch, device independent), against the oracle's numpy callers
+and, when the reference tree is present, against the reference's config files."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import swin_transformer_object_detection_amd as pkg
+from oracle import callers_oracle as CO
+from swin_transformer_object_detection_amd import config, detector, presets, registry
+
+REF = "/root/reference"
+has_ref = os.path.isdir(os.path.join(REF, "configs", "swin"))
+
+
+def test_registry_and_build_from_cfg():
+    assert "SwinTransformer" in registry.BACKBONES and "FPN" in registry.NECKS
+    assert "SingleRoIExtractor" in registry.ROI_EXTRACTORS and "MaskRCNN" in registry.DETECTORS
+    m = registry.build_backbone(dict(type="SwinTransformer", embed_dim=32, depths=[2, 2], num_heads=[1, 2],
+                                     out_indices=(0, 1)))
+    assert isinstance(m, pkg.SwinTransformer) and m.num_features == [32, 64]
+    with pytest.raises(KeyError):
+        registry.build_backbone(dict(type="ResNet"))
+    with pytest.raises(TypeError):
+        m.init_weights(pretrained=3)                      # swin_transformer.py:598
+    with pytest.raises(NotImplementedError):
+        registry.build_backbone(dict(type="SwinTransformer", window_size=12))
+
+
+def test_swin_tiny_state_dict_schema():
+    """189 entries, 27.52 M parameters, the reference's key names."""
+    m = pkg.SwinTransformer()
+    sd = m.state_dict()
+    assert len(sd) == 189
+    assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - 27.52) < 0.01
+    assert sd["layers.0.blocks.1.attn.relative_position_bias_table"].shape == (169, 3)
+    assert sd["layers.2.blocks.5.attn.relative_position_index"].dtype == torch.int64
+    assert sd["layers.0.blocks.0.attn.relative_position_index"][0, :8].tolist() == [84, 83, 82, 81, 80, 79, 78, 71]
+    assert sd["layers.1.downsample.reduction.weight"].shape == (384, 768)
+    assert sd["patch_embed.proj.weight"].shape == (96, 3, 4, 4) and "norm3.bias" in sd
+    f = pkg.FPN([96, 192, 384, 768], 256, 5)
+    assert sorted(f.state_dict())[:2] == ["fpn_convs.0.conv.bias", "fpn_convs.0.conv.weight"]
+    assert "lateral_convs.3.conv.weight" in f.state_dict()
+
+
+def test_frozen_stages_and_train_mode():
+    m = pkg.SwinTransformer(embed_dim=32, depths=[2, 2, 2], num_heads=[1, 2, 4], out_indices=(0, 1, 2), frozen_stages=2)
+    m.train()
+    assert not any(p.requires_grad for p in m.patch_embed.parameters())
+    assert not any(p.requires_grad for p in m.layers[0].parameters())
+    assert all(p.requires_grad for p in m.layers[1].parameters())
+    assert not m.layers[0].training and m.layers[1].training
+
+
+def test_config_loader_merge_and_delete(tmp_path):
+    (tmp_path / "base.py").write_text("model = dict(type='A', backbone=dict(type='R', depth=50), neck=dict(k=1))\nlr = 0.1\n")
+    (tmp_path / "child.py").write_text("_base_ = './base.py'\nmodel = dict(backbone=dict(_delete_=True, type='S', dim=96), neck=dict(j=2))\n")
+    c = config.Config.fromfile(str(tmp_path / "child.py"))
+    assert c.model.backbone == dict(type='S', dim=96) and c.model.neck == dict(k=1, j=2) and c.lr == 0.1
+    c.merge_from_dict({"model.backbone.use_checkpoint": True})
+    assert c.model.backbone.use_checkpoint is True and c.model.type == 'A'
+
+
+@pytest.mark.skipif(not has_ref, reason="reference tree not present (GPU box)")
+def test_reference_swin_configs_load_unchanged():
+    files = sorted(glob.glob(os.path.join(REF, "configs", "swin", "*.py")))
+    assert len(files) == 7
+    for f in files:
+        cfg = config.Config.fromfile(f)
+        bb = registry.build_backbone(cfg.model.backbone)
+        nk = registry.build_neck(cfg.model.neck)
+        assert bb.num_features[-1] == cfg.model.neck.in_channels[-1] and nk.num_outs == 5
+        assert cfg.optimizer.type == 'AdamW' and cfg.runner.type == 'EpochBasedRunnerAmp'
+        if cfg.model.type == 'MaskRCNN':
+            det = pkg.build_detector(cfg.model)
+            assert abs(sum(p.numel() for p in det.parameters()) / 1e6 - {96: 47.8, }.get(cfg.model.backbone.embed_dim, 0)) < 0.2 \
+                or cfg.model.backbone.depths[2] == 18
+
+
+@pytest.mark.skipif(not has_ref, reason="reference tree not present (GPU box)")
+def test_presets_equal_reference_config():
+    def plain(d):
+        if isinstance(d, dict):
+            return {k: plain(v) for k, v in d.items()}
+        if isinstance(d, (list, tuple)):
+            return [plain(v) for v in d]
+        return d
+    cfg = config.Config.fromfile(os.path.join(
+        REF, "configs/swin/mask_rcnn_swin_tiny_patch4_window7_mstrain_480-800_adamw_1x_coco.py"))
+    assert plain(cfg.to_dict()["model"]) == plain(presets.mask_rcnn_swin("tiny"))
+    assert cfg.optimizer.lr == presets.OPTIMIZER["lr"] and cfg.optimizer.weight_decay == presets.OPTIMIZER["weight_decay"]
+    assert set(cfg.optimizer.paramwise_cfg.custom_keys) == set(presets.OPTIMIZER["no_decay_keys"])
+
+
+def test_box_utils_match_oracle_callers():
+    rng = np.random.RandomState(0)
+    rois = np.array([[0., 0., 1., 1.], [0., 0., 1., 1.], [0., 0., 1., 1.], [5., 5., 5., 5.]], np.float32)
+    deltas = np.array([[0., 0., 0., 0.], [1., 1., 1., 1.], [0., 0., 2., -1.], [0.7, -1.9, -0.5, 0.3]], np.float32)
+    got = detector.delta2bbox(torch.from_numpy(rois), torch.from_numpy(deltas), max_shape=(32, 32))
+    np.testing.assert_allclose(got.numpy(), CO.delta2bbox(rois, deltas, max_shape=(32, 32)), atol=1e-6)
+    ag = detector.AnchorGenerator([4, 8], [0.5, 1.0, 2.0], [8])
+    a = ag.grid_anchors([(3, 5), (2, 2)], torch.device("cpu"))
+    np.testing.assert_allclose(a[0].numpy(), CO.grid_anchors(3, 5, 4), atol=1e-4)
+    np.testing.assert_allclose(a[1].numpy(), CO.grid_anchors(2, 2, 8), atol=1e-4)
+    # encode / decode round trip
+    xy = rng.rand(50, 2).astype(np.float32) * 100
+    p = torch.from_numpy(np.concatenate([xy, xy + rng.rand(50, 2).astype(np.float32) * 50 + 2], 1))
+    xy = rng.rand(50, 2).astype(np.float32) * 100
+    g = torch.from_numpy(np.concatenate([xy, xy + rng.rand(50, 2).astype(np.float32) * 50 + 2], 1))
+    d = detector.bbox2delta(p, g, (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2))
+    back = detector.delta2bbox(p, d, (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2))
+    np.testing.assert_allclose(back.numpy(), g.numpy(), atol=1e-3)
+    rois5 = torch.tensor([[0, 0, 0, 10, 10], [0, 0, 0, 112, 112], [1, 0, 0, 448, 448]], dtype=torch.float32)
+    ex = detector.SingleRoIExtractor(dict(type='RoIAlign', output_size=7, sampling_ratio=0), 256, [4, 8, 16, 32])
+    assert ex.map_roi_levels(rois5, 4).tolist() == CO.map_roi_levels(rois5.numpy(), 4).tolist() == [0, 1, 3]
+    assert ex.roi_layers[2].spatial_scale == 1 / 16 and ex.roi_layers[0].output_size == (7, 7)
+
+
+def test_max_iou_assigner_semantics():
+    """Known-answer case of the reference's tests/test_utils/test_assigner.py:14-35."""
+    bboxes = torch.FloatTensor([[0, 0, 10, 10], [10, 10, 20, 20], [5, 5, 15, 15], [32, 32, 38, 42]])
+    gt = torch.FloatTensor([[0, 0, 10, 9], [0, 10, 10, 19]])
+    assigned, _, labels = detector.max_iou_assign(bboxes, gt, 0.5, 0.5, 0.0, True, torch.LongTensor([2, 3]))   # min_pos_iou default .0
+    assert assigned.tolist() == [1, 0, 2, 0]
+    assert labels.tolist() == [2, -1, 3, -1]
+    a0, _, _ = detector.max_iou_assign(bboxes, torch.zeros(0, 4), 0.5, 0.5, 0.5)
+    assert a0.tolist() == [0, 0, 0, 0]
+    torch.manual_seed(0)
+    big = torch.cat([torch.ones(300, dtype=torch.long), torch.zeros(700, dtype=torch.long), -torch.ones(50, dtype=torch.long)])
+    pos, neg = detector.random_sample(big, 256, 0.5)
+    assert pos.numel() == 128 and neg.numel() == 128 and (big[pos] > 0).all() and (big[neg] == 0).all()
+    pos, neg = detector.random_sample(big[280:], 512, 0.25)
+    assert pos.numel() == 20 and neg.numel() == 492
