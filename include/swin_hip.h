@@ -86,12 +86,15 @@ int swin_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bi
 
 /* Backward of the above.
  *   dout  : (B,H,W,C) dtype;  dqkv: (B,H,W,3C) dtype (fully written)
- *   dbias_exp : (nH,64,64) f32, ACCUMULATED (atomics) -- reduce with swin_rel_bias_reduce
+ *   dbias_exp : (nH,64,64) f32, ACCUMULATED -- reduce with swin_rel_bias_reduce
  *   dqkv_bias_pad : (3C) f32, ACCUMULATED: gradient reaching qkv.bias through padded tokens
- *                   (may be NULL iff no padding) */
+ *                   (may be NULL iff no padding)
+ *   workspace : >= swin_window_attn_bwd_workspace_bytes() bytes of device scratch (bf16 path: one
+ *               (64,64) f32 slab per persistent wave for the bias gradient; may be NULL for SWIN_F32) */
+int64_t swin_window_attn_bwd_workspace_bytes(int B, int H, int W, int nH, int dtype);
 int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_exp, const float* lse,
                          const void* dout, void* dqkv, float* dbias_exp, float* dqkv_bias_pad,
-                         int B, int H, int W, int C, int nH, int shift, float scale,
+                         void* workspace, int B, int H, int W, int C, int nH, int shift, float scale,
                          int dtype, void* stream);
 
 /* table (169, nH) f32  ->  bias_exp (nH, 64, 64) f32 laid out [head][key][query] with

@@ -3,7 +3,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libswin_hip.so")
+# SWIN_HIP_LIB selects an alternative build of the SAME ABI (A/B experiments); default: the in-tree library
+LIB_PATH = os.environ.get("SWIN_HIP_LIB") or os.path.join(HERE, "lib", "libswin_hip.so")
 
 SWIN_F32, SWIN_BF16 = 0, 1
 _ERR = {1: "SWIN_ERR_BAD_ARG", 2: "SWIN_ERR_UNSUPPORTED", 3: "SWIN_ERR_LAUNCH"}
@@ -17,7 +18,8 @@ SIGNATURES = {
     "swin_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i, _i, _p],
     "swin_add_layernorm_fwd": [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _i, _p],
     "swin_window_attn_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
-    "swin_window_attn_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "swin_window_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
+    "swin_window_attn_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "swin_rel_bias_expand": [_p, _p, _i, _p],
     "swin_rel_bias_reduce": [_p, _p, _i, _p],
     "swin_bias_gelu_fwd": [_p, _p, _p, _i64, _i, _i, _p],
@@ -34,7 +36,7 @@ SIGNATURES = {
     "swin_nms_workspace_bytes": [_i64],
     "nms_sorted": [_p, _i64, _f, _i, _p, _p, _p, _p],
 }
-_RESTYPE = {"swin_nms_workspace_bytes": _i64}
+_RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64}
 
 _lib = None
 

@@ -109,28 +109,91 @@ __device__ __forceinline__ void lane_mask_bits(int lane, uint64_t& mrow, uint64_
             }
 }
 
-__global__ __launch_bounds__(256) void win_attn_fwd_bf16_kernel(
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// transposed fragment: 8 rows {row0 + 8*(j>>2) + 4*h + (j&3)} of column `c` of a [rows][LROW] bf16 tile, via two
+// ds_read_b64_tr_b16 (each 16-lane group fetches a 4-row x 16-column block and gets it column-major).
+// Pairs with an accumulator-as-operand whose k order is the 32x32 C-layout row order.
+__device__ __forceinline__ bf16x8 lds_tr_frag_perm(const bf16 (*tile)[LROW], int row0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int h = g >> 1, dh = g & 1;
+    const bf16* a0 = &tile[row0 + 4 * h + q][16 * dh + 4 * p];
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 8 * LROW));
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    return f;
+}
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+// combine a value with the one held by lane^32 using v_permlane32_swap (no LDS round trip)
+__device__ __forceinline__ float half_swap_max(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Per-wave constant state of the forward kernel.
+struct FwdLane {
+    int lane, c, h;
+    int tokr, which, part;        // staging role: token-in-round, q|k|v, 16-byte piece
+    unsigned ld_off[10];          // interior fast path: element offset of staged piece i relative to the window base
+    unsigned st_off[2];           // interior fast path: element offset of this lane's output row (per query tile)
+};
+
+// One (window, head) task.  INTERIOR windows (no wrap-around of the cyclic shift, no padding) use
+// precomputed per-lane offsets from a wave-uniform base; the general path resolves every token.
+template <bool INTERIOR>
+__device__ __forceinline__ void fwd_issue_loads(bf16x8 (&stg)[10], const FwdLane& L, const WinGeom& g, const bf16* __restrict__ qkv,
+                                                const float* __restrict__ qkv_bias, int head, int b, int wr, int wc) {
+    const int C3 = 3 * g.C;
+    const int ch = L.which * g.C + head * HD + L.part * 8;
+    if (INTERIOR) {
+        const bf16* pb = qkv + ((size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift) * C3 + ch;
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+            if (i < 9 || L.tokr < 4) stg[i] = *(const bf16x8*)(pb + L.ld_off[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            int t = 5 * i + L.tokr;
+            if (t < NTOK) {
+                int src = token_src(g, b, wr, wc, t);
+                if (src >= 0) stg[i] = *(const bf16x8*)(qkv + (size_t)src * C3 + ch);
+                else stg[i] = bias_to_bf16x8(qkv_bias + ch);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
     const bf16* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
     bf16* __restrict__ out, float* __restrict__ lse, WinGeom g, float scale, int n_tasks) {
     __shared__ __attribute__((aligned(16))) bf16 lds[4][3][TILE][LROW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    FwdLane L;
+    L.lane = threadIdx.x & 63; L.c = L.lane & 31; L.h = L.lane >> 5;
+    const int lane = L.lane, c = L.c, h = L.h;
     bf16(*Qs)[LROW] = lds[wave][0];
     bf16(*Ks)[LROW] = lds[wave][1];
     bf16(*Vs)[LROW] = lds[wave][2];
-
-    // zero the wave's LDS (rows 49..63 must read as 0 for the padded MFMA tiles)
     {
         uint4 z = {0, 0, 0, 0};
         uint4* p = (uint4*)&lds[wave][0][0][0];
-        for (int i = lane; i < 3 * TILE * LROW * 2 / 16; i += WAVE) p[i] = z;
+        for (int i = lane; i < 3 * TILE * LROW * 2 / 16; i += WAVE) p[i] = z;   // rows 49..63 stay zero
     }
     const int n_waves = gridDim.x * 4;   // host guarantees n_waves % nH == 0
     int task = blockIdx.x * 4 + wave;
     if (task >= n_tasks) return;
     const int head = task % g.nH;
 
-    // expanded bias of this head, in accumulator layout, kept in registers
+    // expanded bias of this head (pre-multiplied by log2 e), in accumulator layout, kept in registers
     float biasr[2][2][16];
     {
         const float* bp = bias_exp + (size_t)head * TILE * TILE;
@@ -141,134 +204,160 @@ __global__ __launch_bounds__(256) void win_attn_fwd_bf16_kernel(
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    biasr[kt][qt][reg] = bp[key * TILE + 32 * qt + c];
+                    biasr[kt][qt][reg] = bp[key * TILE + 32 * qt + c] * LOG2E;
                 }
     }
     uint64_t mrow = 0, mcol = 0;
     if (g.shift > 0) lane_mask_bits(lane, mrow, mcol);
+    const float sl2 = scale * LOG2E;
 
-    // staging role of this lane: 5 tokens per round, 12 16-byte pieces per token (q|k|v x 4)
-    const int tokr = lane / 12, rem = lane - tokr * 12;
-    const int which = rem >> 2, part = rem & 3;
-    const bool stager = lane < 60;
-    const int C3 = 3 * g.C;
+    // staging role: 5 tokens per round x 12 16-byte pieces (q|k|v x 4); lanes 60..63 duplicate lanes 48..51
+    {
+        const int sl = lane < 60 ? lane : lane - 12;
+        L.tokr = sl / 12;
+        const int rem = sl - L.tokr * 12;
+        L.which = rem >> 2; L.part = rem & 3;
+        const int C3 = 3 * g.C;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            int t = 5 * i + L.tokr; if (t >= NTOK) t = NTOK - 1;
+            L.ld_off[i] = (unsigned)(((t / 7) * g.W + (t % 7)) * C3);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            int q = 32 * qt + c; if (q >= NTOK) q = NTOK - 1;
+            L.st_off[qt] = (unsigned)(((q / 7) * g.W + (q % 7)) * g.C);
+        }
+    }
+    const int which = L.which, part = L.part, tokr = L.tokr;
+
+    auto decode = [&](int t_, int& b, int& wr, int& wc, bool& interior) {
+        const int win = t_ / g.nH;
+        b = win / g.nW;
+        const int wrem = win - b * g.nW;
+        wr = wrem / g.nWw; wc = wrem - wr * g.nWw;
+        interior = (wr * 7 + 6 + g.shift < g.H) && (wc * 7 + 6 + g.shift < g.W);
+    };
+
+    bf16x8 stg[10];
+    {
+        int b, wr, wc; bool in;
+        decode(task, b, wr, wc, in);
+        if (in) fwd_issue_loads<true>(stg, L, g, qkv, qkv_bias, head, b, wr, wc);
+        else fwd_issue_loads<false>(stg, L, g, qkv, qkv_bias, head, b, wr, wc);
+    }
     __builtin_amdgcn_wave_barrier();
 
     for (; task < n_tasks; task += n_waves) {
-        const int win = task / g.nH;
-        const int b = win / g.nW, wrem = win - b * g.nW;
-        const int wr = wrem / g.nWw, wc = wrem - wr * g.nWw;
+        int b, wr, wc; bool interior;
+        decode(task, b, wr, wc, interior);
 
-        // ---- stage q,k,v head slices (49 x 32 each) into LDS -------------------------------
-        bf16x8 stg[10];
+        // ---- registers -> LDS (q,k,v head slices, 49 x 32 each), then prefetch the next task ----
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             int t = 5 * i + tokr;
-            if (stager && t < NTOK) {
-                int src = token_src(g, b, wr, wc, t);
-                int ch = which * g.C + head * HD + part * 8;
-                if (src >= 0) stg[i] = *(const bf16x8*)(qkv + (size_t)src * C3 + ch);
-                else stg[i] = bias_to_bf16x8(qkv_bias + ch);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            int t = 5 * i + tokr;
-            if (stager && t < NTOK) *(bf16x8*)&lds[wave][which][t][part * 8] = stg[i];
+            if (i < 9 || tokr < 4) *(bf16x8*)&lds[wave][which][t][part * 8] = stg[i];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (task + n_waves < n_tasks) {
+            int b2, wr2, wc2; bool in2;
+            decode(task + n_waves, b2, wr2, wc2, in2);
+            if (in2) fwd_issue_loads<true>(stg, L, g, qkv, qkv_bias, head, b2, wr2, wc2);
+            else fwd_issue_loads<false>(stg, L, g, qkv, qkv_bias, head, b2, wr2, wc2);
+        }
 
-        // ---- S^T = K Q^T ---------------------------------------------------------------------
-        bf16x8 qf[2][2], kf[2][2];
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                qf[t2][s] = *(const bf16x8*)&Qs[32 * t2 + c][16 * s + 8 * h];
-                kf[t2][s] = *(const bf16x8*)&Ks[32 * t2 + c][16 * s + 8 * h];
-            }
-        f32x16 sacc[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                f32x16 a = {0};
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], a, 0, 0, 0);
-                sacc[kt][qt] = a;
-            }
-
-        // ---- scale + bias (+ mask), softmax over keys (registers + lane^32) -------------------
+        const bool edge = g.shift > 0 && (wr == g.nWh - 1 || wc == g.nWw - 1);
         uint64_t mbits = 0;
-        if (g.shift > 0) {
+        if (edge) {
             if (wr == g.nWh - 1) mbits |= mrow;
             if (wc == g.nWw - 1) mbits |= mcol;
         }
-        float inv[2], lsev[2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float m = NEG_BIG;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    float v = sacc[kt][qt][reg] * scale + biasr[kt][qt][reg];
-                    if ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1) v += -100.0f;   // swin_transformer.py:389
-                    sacc[kt][qt][reg] = v;
-                    m = fmaxf(m, v);
-                }
-            m = fmaxf(m, __shfl_xor(m, 32));
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    float p = __expf(sacc[kt][qt][reg] - m);
-                    sacc[kt][qt][reg] = p;
-                    sum += p;
-                }
-            sum += __shfl_xor(sum, 32);
-            inv[qt] = 1.0f / sum;
-            lsev[qt] = m + __logf(sum);
-        }
-
-        // ---- O^T = V^T P^T  (P^T accumulator registers are the B operand) ---------------------
-        f32x16 oacc[2] = {{0}, {0}};
+        bf16x8 kf[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 vf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vf[j] = Vs[32 * kt + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)][c];
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][qt][8 * s + j];
-                    oacc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[qt], 0, 0, 0);
-                }
-            }
+            for (int s = 0; s < 2; ++s) kf[kt][s] = *(const bf16x8*)&Ks[32 * kt + c][16 * s + 8 * h];
 
-        // ---- write O (window_reverse + roll back + crop == scatter to the source position) ----
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            int q = 32 * qt + c;
+            // ---- S^T = K Q^T for 32 queries --------------------------------------------------
+            bf16x8 qf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) qf[s] = *(const bf16x8*)&Qs[32 * qt + c][16 * s + 8 * h];
+            f32x16 sacc[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 a = {0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], a, 0, 0, 0);
+                sacc[kt] = a;
+            }
+            // ---- logits in the log2 domain, softmax over keys ------------------------------------
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) sacc[kt][reg] = fmaf(sacc[kt][reg], sl2, biasr[kt][qt][reg]);
+            if (edge) {                                       // wave-uniform: only last-row / last-column windows
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1) sacc[kt][reg] += -100.0f * LOG2E;   // :389
+            }
+            // 4 independent partial reductions (ILP), then a VALU half-swap instead of an LDS bpermute
+            float m4[4] = {NEG_BIG * 2.f, NEG_BIG * 2.f, NEG_BIG * 2.f, NEG_BIG * 2.f};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) m4[reg & 3] = fmaxf(m4[reg & 3], sacc[kt][reg]);
+            float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+            m = half_swap_max(m);
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float p = __builtin_amdgcn_exp2f(sacc[kt][reg] - m);
+                    sacc[kt][reg] = p;
+                    s4[reg & 3] += p;
+                }
+            float sum = half_swap_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+            const float inv = 1.0f / sum;
+
+            // ---- O^T = V^T P^T  (P^T accumulator registers are the B operand) -----------------------
+            f32x16 oacc = {0};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 vf = lds_tr_frag_perm(Vs, 32 * kt + 16 * s, lane);
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s + j];
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc, 0, 0, 0);
+                }
+
+            // ---- write O (window_reverse + roll back + crop == scatter to the source position) ----
+            const int q = 32 * qt + c;
             if (q < NTOK) {
-                int src = token_src(g, b, wr, wc, q);
-                if (src >= 0) {
-                    bf16* op = out + (size_t)src * g.C + head * HD + 4 * h;
+                bf16* op = nullptr;
+                if (interior) {
+                    op = out + ((size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift) * g.C + L.st_off[qt] + head * HD + 4 * h;
+                } else {
+                    int src = token_src(g, b, wr, wc, q);
+                    if (src >= 0) op = out + (size_t)src * g.C + head * HD + 4 * h;
+                }
+                if (op) {
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         bf16x4 o4;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = (bf16)(oacc[qt][4 * gq + e] * inv[qt]);
+                        for (int e = 0; e < 4; ++e) o4[e] = (bf16)(oacc[4 * gq + e] * inv);
                         *(bf16x4*)(op + 8 * gq) = o4;
                     }
                 }
-                if (lse != nullptr && h == 0) lse[(size_t)task * TILE + q] = lsev[qt];
+                if (lse != nullptr && h == 0) lse[(size_t)task * TILE + q] = (m + __builtin_amdgcn_logf(sum)) * LN2;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -344,58 +433,105 @@ __global__ __launch_bounds__(64) void win_attn_fwd_f32_kernel(
 
 // ------------------------------------------------------------------------------------
 // bf16 backward: one wave per (window, head), persistent over the windows of one head.
-//   phase A (query on the lane):  S^T, P^T = exp(S^T - lse), dP^T = V dO^T, delta = sum_k P dP,
+//   phase A (query on the lane):  S^T, P^T = exp2(S^T - lse), dP^T = V dO^T, delta = sum_k P dP,
 //       dS^T = P^T (dP^T - delta);  dbias += dS^T (registers);  dQ^T = scale * K^T dS^T  with dS^T
-//       taken straight from the accumulator registers as the B operand;
-//   phase B: P^T and scale*dS^T go through LDS once ([key][query] bf16 tiles) and come back as
-//       row-major B operands of  dV^T = dO^T P  and  dK^T = Q^T dS.
+//       taken straight from the accumulator registers as the B operand and K^T read with
+//       ds_read_b64_tr_b16;
+//   phase B: P and scale*dS go through LDS once as [query][key] bf16 tiles (8-byte writes of 4
+//       consecutive keys) and come back through transposed reads as B operands of
+//       dV^T = dO^T P  and  dK^T = Q^T dS  (dO^T, Q^T also transposed reads).
 // ------------------------------------------------------------------------------------
-#define PROW 72   // row stride (bf16 elements) of the 64x64 P^T / dS^T tiles: 144 B
+#define PROW 72   // row stride (bf16 elements) of the 64x64 P / dS tiles: 144 B
 
-__device__ __forceinline__ bf16x8 lds_col_frag(const bf16 (*tile)[LROW], int row0, int h, int col) {
-    // 8 rows {row0 + 8*(j>>2) + 4*h + (j&3)} of one column: the k-permuted fragment that pairs with an
-    // accumulator-as-operand (see the forward kernel)
+// transposed fragment in natural k order: rows row0 + 8*h + j (j=0..7) of column (col0 + lane&31)
+template <int STRIDE>
+__device__ __forceinline__ bf16x8 lds_tr_frag_lin(const bf16* tile, int row0, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int h = g >> 1, dh = g & 1;
+    const bf16* a0 = tile + (row0 + 8 * h + q) * STRIDE + col0 + 16 * dh + 4 * p;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * STRIDE));
     bf16x8 f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = tile[row0 + 8 * (j >> 2) + 4 * h + (j & 3)][col];
-    return f;
-}
-
-__device__ __forceinline__ bf16x8 lds_col_frag_lin(const bf16 (*tile)[LROW], int row0, int h, int col) {
-    // 8 consecutive rows row0 + 8*h + j of one column (natural k order)
-    bf16x8 f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = tile[row0 + 8 * h + j][col];
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
     return f;
 }
 
 struct BwdLds {
     bf16 t[4][TILE][LROW];     // Q, K, V, dO head slices
-    bf16 pt[TILE][PROW];       // P^T   [key][query]
-    bf16 dst[TILE][PROW];      // scale * dS^T [key][query]
+    bf16 p[TILE][PROW];        // P        [query][key]
+    bf16 ds[TILE][PROW];       // scale*dS [query][key]
+    float padacc[3 * HD + 32]; // gradient reaching qkv.bias through this wave's padded tokens (q|k|v x 32), padded to 16 B
 };
+#define SLAB (TILE * TILE + 3 * HD + 32)   // floats per wave in the workspace: dbias tile + pad-token bias gradient
+
+struct BwdLane {
+    int lane, c, h, tokr, which, part;
+    unsigned ld_off[13];       // interior path: element offset of staged piece i (qkv stride 3C or dout stride C)
+    unsigned st_off[2];        // interior path: element offset (x 3C) of this lane's token per token tile
+};
+
+template <bool INTERIOR>
+__device__ __forceinline__ void bwd_issue_loads(bf16x8 (&stg)[13], const BwdLane& L, const WinGeom& g, const bf16* __restrict__ qkv,
+                                                const bf16* __restrict__ dout, const float* __restrict__ qkv_bias, int head,
+                                                int b, int wr, int wc) {
+    const int C3 = 3 * g.C;
+    const bool is_do = L.which == 3;
+    const int ch = is_do ? head * HD + L.part * 8 : L.which * g.C + head * HD + L.part * 8;
+    if (INTERIOR) {
+        const size_t wbase = (size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift;
+        const bf16* pb = is_do ? dout + wbase * g.C + ch : qkv + wbase * C3 + ch;
+#pragma unroll
+        for (int i = 0; i < 13; ++i)
+            if (i < 12 || L.tokr == 0) stg[i] = *(const bf16x8*)(pb + L.ld_off[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            int t = 4 * i + L.tokr;
+            if (t < NTOK) {
+                int src = token_src(g, b, wr, wc, t);
+                if (src >= 0) stg[i] = is_do ? *(const bf16x8*)(dout + (size_t)src * g.C + ch)
+                                             : *(const bf16x8*)(qkv + (size_t)src * C3 + ch);
+                else if (is_do) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) stg[i][e] = (bf16)0.f;   // cropped rows get no gradient
+                } else stg[i] = bias_to_bf16x8(qkv_bias + ch);
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
     const bf16* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
     const float* __restrict__ lse, const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
-    float* __restrict__ dbias_exp, float* __restrict__ dbias_pad, WinGeom g, float scale, int n_tasks) {
+    float* __restrict__ dbias_ws, float* __restrict__ dbias_pad, WinGeom g, float scale, int n_tasks) {
+    // dbias_ws: one (64,64) fp32 slab per persistent wave, fully written (plain stores) and summed per head by
+    // dbias_slab_reduce_kernel -- hundreds of waves adding into the same 2401 addresses with atomics serialise
+    // at the memory side (measured: 0.9 ms per launch, almost all of it the final atomic flush)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    BwdLds* L = reinterpret_cast<BwdLds*>(smem_raw) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int c = lane & 31, h = lane >> 5;
-    bf16(*Qs)[LROW] = L->t[0];
-    bf16(*Ks)[LROW] = L->t[1];
-    bf16(*Vs)[LROW] = L->t[2];
-    bf16(*Ds)[LROW] = L->t[3];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    BwdLds* Lm = reinterpret_cast<BwdLds*>(smem_raw) + wave;
+    BwdLane L;
+    L.lane = threadIdx.x & 63; L.c = L.lane & 31; L.h = L.lane >> 5;
+    const int lane = L.lane, c = L.c, h = L.h;
+    bf16(*Qs)[LROW] = Lm->t[0];
+    bf16(*Ks)[LROW] = Lm->t[1];
+    bf16(*Vs)[LROW] = Lm->t[2];
+    bf16(*Ds)[LROW] = Lm->t[3];
     {
         uint4 z = {0, 0, 0, 0};
-        uint4* p = (uint4*)L;
+        uint4* p = (uint4*)Lm;
         for (int i = lane; i < (int)(sizeof(BwdLds) / 16); i += WAVE) p[i] = z;
     }
     const int n_waves = gridDim.x * 4;
-    int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= n_tasks) return;
+    int task = blockIdx.x * 4 + wave;
+    float* const slab = dbias_ws + (size_t)task * SLAB;
+    if (task >= n_tasks) {                      // idle wave: its slab must still read as zero
+        for (int i = lane; i < SLAB; i += WAVE) slab[i] = 0.f;
+        return;
+    }
     const int head = task % g.nH;
+    const int C3 = 3 * g.C;
 
     float biasr[2][2][16], dbacc[2][2][16];
     {
@@ -407,54 +543,70 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    biasr[kt][qt][reg] = bp[key * TILE + 32 * qt + c];
+                    biasr[kt][qt][reg] = bp[key * TILE + 32 * qt + c] * LOG2E;
                     dbacc[kt][qt][reg] = 0.f;
                 }
     }
     uint64_t mrow = 0, mcol = 0;
     if (g.shift > 0) lane_mask_bits(lane, mrow, mcol);
+    const float sl2 = scale * LOG2E;
 
     // staging: 4 tokens per round, 16 pieces per token (q|k|v|dO x 4 pieces of 16 B)
-    const int tokr = lane >> 4, rem = lane & 15;
-    const int which = rem >> 2, part = rem & 3;
-    const int C3 = 3 * g.C;
+    L.tokr = lane >> 4;
+    L.which = (lane & 15) >> 2; L.part = lane & 3;
+    {
+        const int stride = L.which == 3 ? g.C : C3;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            int t = 4 * i + L.tokr; if (t >= NTOK) t = NTOK - 1;
+            L.ld_off[i] = (unsigned)(((t / 7) * g.W + (t % 7)) * stride);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            int q = 32 * tt + c; if (q >= NTOK) q = NTOK - 1;
+            L.st_off[tt] = (unsigned)(((q / 7) * g.W + (q % 7)) * C3);
+        }
+    }
+    const int which = L.which, part = L.part, tokr = L.tokr;
+
+    auto decode = [&](int t_, int& b, int& wr, int& wc, bool& interior) {
+        const int win = t_ / g.nH;
+        b = win / g.nW;
+        const int wrem = win - b * g.nW;
+        wr = wrem / g.nWw; wc = wrem - wr * g.nWw;
+        interior = (wr * 7 + 6 + g.shift < g.H) && (wc * 7 + 6 + g.shift < g.W);
+    };
+
+    bf16x8 stg[13];
+    {
+        int b, wr, wc; bool in;
+        decode(task, b, wr, wc, in);
+        if (in) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, b, wr, wc);
+        else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, b, wr, wc);
+    }
     __builtin_amdgcn_wave_barrier();
 
     for (; task < n_tasks; task += n_waves) {
-        const int win = task / g.nH;
-        const int b = win / g.nW, wrem = win - b * g.nW;
-        const int wr = wrem / g.nWw, wc = wrem - wr * g.nWw;
-
-        bf16x8 stg[13];
+        int b, wr, wc; bool interior;
+        decode(task, b, wr, wc, interior);
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
             int t = 4 * i + tokr;
-            if (t < NTOK) {
-                int src = token_src(g, b, wr, wc, t);
-                if (which < 3) {
-                    int ch = which * g.C + head * HD + part * 8;
-                    if (src >= 0) stg[i] = *(const bf16x8*)(qkv + (size_t)src * C3 + ch);
-                    else stg[i] = bias_to_bf16x8(qkv_bias + ch);
-                } else {
-                    if (src >= 0) stg[i] = *(const bf16x8*)(dout + (size_t)src * g.C + head * HD + part * 8);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) stg[i][e] = (bf16)0.f;   // cropped rows get no gradient
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            int t = 4 * i + tokr;
-            if (t < NTOK) *(bf16x8*)&L->t[which][t][part * 8] = stg[i];
+            if (i < 12 || tokr == 0) *(bf16x8*)&Lm->t[which][t][part * 8] = stg[i];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (task + n_waves < n_tasks) {
+            int b2, wr2, wc2; bool in2;
+            decode(task + n_waves, b2, wr2, wc2, in2);
+            if (in2) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, b2, wr2, wc2);
+            else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, b2, wr2, wc2);
+        }
 
         // ---------------- phase A -------------------------------------------------------------
+        const bool edge = g.shift > 0 && (wr == g.nWh - 1 || wc == g.nWw - 1);
         uint64_t mbits = 0;
-        if (g.shift > 0) {
+        if (edge) {
             if (wr == g.nWh - 1) mbits |= mrow;
             if (wc == g.nWw - 1) mbits |= mcol;
         }
@@ -487,30 +639,38 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int q = 32 * qt + c;
-            const float l = lse[(size_t)task * TILE + (q < NTOK ? q : 0)];
-            float delta = 0.f;
+            const bool qv = q < NTOK;
+            const float l2 = lse[(size_t)task * TILE + (qv ? q : 0)] * LOG2E;
+            float d4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    float v = pacc[kt][qt][reg] * scale + biasr[kt][qt][reg];
-                    if ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1) v += -100.0f;
-                    float p = __expf(v - l);
+                    float v = fmaf(pacc[kt][qt][reg], sl2, biasr[kt][qt][reg]);
+                    if (edge && ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1)) v += -100.0f * LOG2E;
+                    float p = qv ? __builtin_amdgcn_exp2f(v - l2) : 0.f;   // padded query columns carry garbage
                     pacc[kt][qt][reg] = p;
-                    delta += p * dpacc[kt][qt][reg];
+                    d4[reg & 3] = fmaf(p, dpacc[kt][qt][reg], d4[reg & 3]);
                 }
-            delta += __shfl_xor(delta, 32);
+            const float delta = half_swap_sum((d4[0] + d4[1]) + (d4[2] + d4[3]));
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    float ds = pacc[kt][qt][reg] * (dpacc[kt][qt][reg] - delta);
-                    if (q >= NTOK) ds = 0.f;                      // padded query columns carry garbage
-                    dbacc[kt][qt][reg] += ds;
-                    dpacc[kt][qt][reg] = ds * scale;              // scale * dS^T from here on
-                    int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    L->pt[key][q] = (bf16)(q < NTOK ? pacc[kt][qt][reg] : 0.f);
-                    L->dst[key][q] = (bf16)dpacc[kt][qt][reg];
+                for (int gq = 0; gq < 4; ++gq) {
+                    bf16x4 p4, s4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = 4 * gq + e;
+                        float ds = pacc[kt][qt][reg] * (dpacc[kt][qt][reg] - delta);
+                        dbacc[kt][qt][reg] += ds;
+                        ds *= scale;                              // scale * dS^T from here on
+                        dpacc[kt][qt][reg] = ds;
+                        p4[e] = (bf16)pacc[kt][qt][reg];
+                        s4[e] = (bf16)ds;
+                    }
+                    // [query][key] tiles: this lane's 4 consecutive keys
+                    *(bf16x4*)&Lm->p[q][32 * kt + 8 * gq + 4 * h] = p4;
+                    *(bf16x4*)&Lm->ds[q][32 * kt + 8 * gq + 4 * h] = s4;
                 }
         }
         // dQ^T = K^T (scale dS^T)
@@ -519,7 +679,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 kc = lds_col_frag(Ks, 32 * kt + 16 * s, h, c);
+                bf16x8 kc = lds_tr_frag_perm(Ks, 32 * kt + 16 * s, lane);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
                     bf16x8 sf;
@@ -535,12 +695,12 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
         f32x16 dv[2] = {{0}, {0}}, dk[2] = {{0}, {0}};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {          // k-steps of 16 queries
-            bf16x8 doc = lds_col_frag_lin(Ds, 16 * ks, h, c);   // A = dO^T : rows d, k = query
-            bf16x8 qc = lds_col_frag_lin(Qs, 16 * ks, h, c);    // A = Q^T
+            bf16x8 doc = lds_tr_frag_lin<LROW>(&Ds[0][0], 16 * ks, 0, lane);   // A = dO^T : rows d, k = query
+            bf16x8 qc = lds_tr_frag_lin<LROW>(&Qs[0][0], 16 * ks, 0, lane);    // A = Q^T
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                bf16x8 pb = *(const bf16x8*)&L->pt[32 * kt + c][16 * ks + 8 * h];    // B[k=query][col=key]
-                bf16x8 sb = *(const bf16x8*)&L->dst[32 * kt + c][16 * ks + 8 * h];
+                bf16x8 pb = lds_tr_frag_lin<PROW>(&Lm->p[0][0], 16 * ks, 32 * kt, lane);    // B[k=query][col=key]
+                bf16x8 sb = lds_tr_frag_lin<PROW>(&Lm->ds[0][0], 16 * ks, 32 * kt, lane);
                 dv[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doc, pb, dv[kt], 0, 0, 0);
                 dk[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qc, sb, dk[kt], 0, 0, 0);
             }
@@ -551,9 +711,16 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
         for (int tt = 0; tt < 2; ++tt) {
             int tok = 32 * tt + c;
             if (tok < NTOK) {
-                int src = token_src(g, b, wr, wc, tok);
-                if (src >= 0) {
-                    bf16* op = dqkv + (size_t)src * C3 + head * HD + 4 * h;
+                bf16* op = nullptr;
+                bool pad = false;
+                if (interior) {
+                    op = dqkv + ((size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift) * C3 + L.st_off[tt] + head * HD + 4 * h;
+                } else {
+                    int src = token_src(g, b, wr, wc, tok);
+                    if (src >= 0) op = dqkv + (size_t)src * C3 + head * HD + 4 * h;
+                    else pad = true;
+                }
+                if (op) {
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         bf16x4 a, bb, cc;
@@ -567,15 +734,16 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
                         *(bf16x4*)(op + g.C + 8 * gq) = bb;
                         *(bf16x4*)(op + 2 * g.C + 8 * gq) = cc;
                     }
-                } else {
-                    // padded token: its q|k|v ARE qkv.bias, so the gradient lands on the bias
-                    float* bp = dbias_pad + head * HD + 4 * h;
+                } else if (pad) {
+                    // padded token: its q|k|v ARE qkv.bias, so the gradient lands on the bias.  Summed per wave in
+                    // LDS (global atomics from every padded token onto 3C addresses serialise: ~1 ms per launch)
+                    float* bp = Lm->padacc + 4 * h;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         int d = (r & 3) + 8 * (r >> 2);
                         atomicAdd(bp + d, dq[tt][r]);
-                        atomicAdd(bp + g.C + d, dk[tt][r]);
-                        atomicAdd(bp + 2 * g.C + d, dv[tt][r]);
+                        atomicAdd(bp + HD + d, dk[tt][r]);
+                        atomicAdd(bp + 2 * HD + d, dv[tt][r]);
                     }
                 }
             }
@@ -583,8 +751,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    // flush the relative-position-bias gradient of this wave's head
-    float* db = dbias_exp + (size_t)head * TILE * TILE;
+    // this wave's partial relative-position-bias gradient -> its private slab
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -592,8 +759,31 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (key < NTOK && 32 * qt + c < NTOK) atomicAdd(db + key * TILE + 32 * qt + c, dbacc[kt][qt][reg]);
+                slab[key * TILE + 32 * qt + c] = dbacc[kt][qt][reg];
             }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 3 * HD + 32; i += WAVE) slab[TILE * TILE + i] = i < 3 * HD ? Lm->padacc[i] : 0.f;
+}
+
+// dbias_exp[head][key][query] += sum over the slabs of that head (slab s belongs to head s % nH);
+// dbias_pad[which*C + head*32 + d] += the slabs' pad-token part.  grid.y splits the slab range.
+__global__ __launch_bounds__(256) void dbias_slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dbias_exp,
+                                                                float* __restrict__ dbias_pad, int n_slabs, int nH, int C) {
+    const int per_head = TILE * TILE + 3 * HD;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nH * per_head) return;
+    int head = i / per_head, e = i - head * per_head;
+    const int per = (n_slabs / nH + gridDim.y - 1) / gridDim.y;        // slabs of this head handled per y-block
+    const int k0 = blockIdx.y * per, k1 = min(k0 + per, n_slabs / nH);
+    float acc = 0.f;
+    for (int k = k0; k < k1; ++k) acc += ws[(size_t)(head + k * nH) * SLAB + e];
+    if (k1 <= k0) return;
+    if (e < TILE * TILE) atomicAdd(dbias_exp + head * TILE * TILE + e, acc);
+    else if (dbias_pad) {
+        int w = (e - TILE * TILE) / HD, d = (e - TILE * TILE) % HD;
+        atomicAdd(dbias_pad + w * C + head * HD + d, acc);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -736,9 +926,22 @@ extern "C" int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int n
     return swin_launch_status();
 }
 
+static int attn_bwd_blocks(int n_tasks, int nH) {
+    int blocks = (n_tasks + 3) / 4;
+    if (blocks > 256) blocks = 256;           // LDS allows one 4-wave block per CU
+    return (blocks + nH - 1) / nH * nH;
+}
+
+extern "C" int64_t swin_window_attn_bwd_workspace_bytes(int B, int H, int W, int nH, int dtype) {
+    if (dtype != SWIN_BF16 || B <= 0 || H <= 0 || W <= 0 || nH <= 0) return 0;
+    WinGeom g = make_geom(B, H, W, nH * HD, nH, 0);
+    return (int64_t)attn_bwd_blocks(B * g.nW * nH, nH) * 4 * SLAB * sizeof(float);
+}
+
 extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_exp, const float* lse,
-                                    const void* dout, void* dqkv, float* dbias_exp, float* dqkv_bias_pad, int B, int H,
-                                    int W, int C, int nH, int shift, float scale, int dtype, void* stream) {
+                                    const void* dout, void* dqkv, float* dbias_exp, float* dqkv_bias_pad,
+                                    void* workspace, int B, int H, int W, int C, int nH, int shift, float scale,
+                                    int dtype, void* stream) {
     int st = check_attn_args(qkv, qkv_bias, bias_exp, dqkv, B, H, W, C, nH, shift, dtype);
     if (st != SWIN_OK) return st;
     if (!lse || !dout || !dbias_exp) return SWIN_ERR_BAD_ARG;
@@ -747,9 +950,8 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
     int n_tasks = B * g.nW * nH;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SWIN_BF16) {
-        int blocks = (n_tasks + 3) / 4;
-        if (blocks > 256) blocks = 256;           // LDS allows one 4-wave block per CU
-        blocks = (blocks + nH - 1) / nH * nH;
+        if (!workspace) return SWIN_ERR_BAD_ARG;
+        int blocks = attn_bwd_blocks(n_tasks, nH);
         static bool attr_set = false;
         size_t shm = 4 * sizeof(BwdLds);
         if (!attr_set) {
@@ -758,7 +960,10 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
             attr_set = true;
         }
         win_attn_bwd_bf16_kernel<<<blocks, 256, shm, s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
-                                                          (bf16*)dqkv, dbias_exp, dqkv_bias_pad, g, scale, n_tasks);
+                                                          (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks);
+        int n = nH * (TILE * TILE + 3 * HD);
+        dim3 rgrid((n + 255) / 256, 16);
+        dbias_slab_reduce_kernel<<<rgrid, 256, 0, s>>>((const float*)workspace, dbias_exp, dqkv_bias_pad, blocks * 4, nH, C);
     } else {
         win_attn_bwd_f32_kernel<<<n_tasks, 64, 0, s>>>((const float*)qkv, qkv_bias, bias_exp, lse, (const float*)dout,
                                                        (float*)dqkv, dbias_exp, dqkv_bias_pad, g, scale);

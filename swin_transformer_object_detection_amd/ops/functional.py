@@ -184,8 +184,10 @@ class _WindowAttention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dbexp = torch.zeros_like(bias_exp)
         dpad = torch.zeros(3 * C, device=qkv.device, dtype=torch.float32)
+        ws_bytes = _lib.lib().swin_window_attn_bwd_workspace_bytes(B, H, W, nH, _dt(qkv))
+        ws = torch.empty(max(ws_bytes, 16), device=qkv.device, dtype=torch.uint8)
         call("swin_window_attn_bwd", _p(qkv), _p(qkv_bias), _p(bias_exp), _p(lse), _p(dout), _p(dqkv), _p(dbexp), _p(dpad),
-             B, H, W, C, nH, shift, scale, _dt(qkv), _s())
+             _p(ws), B, H, W, C, nH, shift, scale, _dt(qkv), _s())
         dtable = torch.zeros(169, nH, device=qkv.device, dtype=torch.float32)
         call("swin_rel_bias_reduce", _p(dbexp), _p(dtable), nH, _s())
         return dqkv, dpad, dtable, None, None, None, None, None

@@ -1,0 +1,124 @@
+#!/usr/bin/env python
+"""Per-kernel timings on the GPU at the BASELINE configs[1] geometries (development aid).
+usage: python tools/microbench.py [attn] [conv] [ln] [nms] [roi]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from swin_transformer_object_detection_amd import ops  # noqa: E402
+from swin_transformer_object_detection_amd.ops import functional as Fn  # noqa: E402
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for s, e in ev:
+        s.record(); fn(); e.record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in ev)
+    return ts[len(ts) // 2] * 1e3, ts[0] * 1e3        # median, min in us
+
+
+STAGES = [(200, 320, 96, 3), (100, 160, 192, 6), (50, 80, 384, 12), (25, 40, 768, 24)]
+
+
+def attn():
+    B = 2
+    for (H, W, C, nH) in STAGES:
+        for shift in (0, 3):
+            qkv = torch.randn(B, H * W, 3 * C, device="cuda").bfloat16()
+            qb = torch.randn(3 * C, device="cuda") * 0.1
+            table = torch.randn(169, nH, device="cuda") * 0.02
+            bias_exp = ops.rel_bias_expand(table)
+            out = torch.empty(B, H * W, C, device="cuda", dtype=torch.bfloat16)
+            nW = ((H + 6) // 7) * ((W + 6) // 7)
+            lse = torch.empty(B * nW * nH, 64, device="cuda")
+            sc = 32 ** -0.5
+
+            def f():
+                Fn.call("swin_window_attn_fwd", Fn._p(qkv), Fn._p(qb), Fn._p(bias_exp), Fn._p(out), Fn._p(lse), B, H, W, C, nH,
+                        shift, sc, Fn.SWIN_BF16, Fn._s())
+            med, mn = timeit(f)
+            byts = 8.0 * B * H * W * C
+            dout = torch.randn_like(out)
+            dqkv = torch.empty_like(qkv)
+            dbe = torch.zeros_like(bias_exp)
+            dpad = torch.zeros(3 * C, device="cuda")
+            ws = torch.empty(Fn._lib.lib().swin_window_attn_bwd_workspace_bytes(B, H, W, nH, Fn.SWIN_BF16), device="cuda",
+                             dtype=torch.uint8)
+
+            def fb():
+                Fn.call("swin_window_attn_bwd", Fn._p(qkv), Fn._p(qb), Fn._p(bias_exp), Fn._p(lse), Fn._p(dout), Fn._p(dqkv),
+                        Fn._p(dbe), Fn._p(dpad), Fn._p(ws), B, H, W, C, nH, shift, sc, Fn.SWIN_BF16, Fn._s())
+            medb, mnb = timeit(fb)
+            print(f"attn {H}x{W} C={C} nH={nH} shift={shift}: fwd {med:8.1f} us ({byts / med / 1e3:7.1f} GB/s)   "
+                  f"bwd {medb:8.1f} us ({2 * byts / medb / 1e3:7.1f} GB/s)")
+
+
+def conv():
+    for (N, H, W) in [(2, 200, 320), (2, 100, 160), (2, 50, 80), (2, 25, 40), (200, 14, 14)]:
+        x = torch.randn(N, 256, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+        w = torch.randn(256, 3, 3, 256, device="cuda").bfloat16() * 0.02
+        b = torch.zeros(256, device="cuda")
+
+        def f():
+            Fn._conv3x3_raw(x, w, b, False)
+        med, mn = timeit(f)
+        fl = 2.0 * N * H * W * 256 * 256 * 9
+        print(f"conv3x3 {N}x{H}x{W}x256->256: {med:8.1f} us  {fl / med / 1e6:7.1f} TFLOP/s")
+
+
+def ln():
+    for (H, W, C, nH) in STAGES:
+        x = torch.randn(2 * H * W, C, device="cuda").bfloat16()
+        y = torch.randn_like(x)
+        w = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+        med, _ = timeit(lambda: ops.add_layer_norm(x, y, None, H * W, w, b))
+        xr = x.clone().requires_grad_(True)
+        o = ops.layer_norm(xr, w.requires_grad_(True), b.requires_grad_(True))
+        g = torch.randn_like(o)
+        medb, _ = timeit(lambda: torch.autograd.grad(o, xr, g, retain_graph=True))
+        h = torch.randn(2 * H * W, 4 * C, device="cuda").bfloat16()
+        bb = torch.zeros(4 * C, device="cuda")
+        medg, _ = timeit(lambda: ops.bias_gelu(h, bb))
+        print(f"rows={2 * H * W} C={C}: add_ln fwd {med:7.1f} us ({8.0 * x.numel() / med / 1e3:7.1f} GB/s)  ln bwd {medb:7.1f} us  "
+              f"bias_gelu {medg:7.1f} us ({4.0 * h.numel() / medg / 1e3:7.1f} GB/s)")
+
+
+def nms():
+    import numpy as np
+    rng = np.random.RandomState(0)
+    for n in (1000, 4000, 8780):
+        xy = rng.rand(n, 2).astype("float32") * 1000
+        boxes = torch.from_numpy(np.concatenate([xy, xy + rng.rand(n, 2).astype("float32") * 150 + 4], 1)).cuda()
+        scores = torch.from_numpy(rng.rand(n).astype("float32")).cuda()
+        ids = torch.from_numpy(rng.randint(0, 5, n)).cuda()
+        med, _ = timeit(lambda: ops.batched_nms(boxes, scores, ids, dict(type="nms", iou_threshold=0.7)), n=10)
+        print(f"batched_nms n={n}: {med:8.1f} us")
+
+
+def roi():
+    feats = [torch.randn(2, 256, 200 // s, 320 // s, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+             for s in (1, 2, 4, 8)]
+    rois = torch.rand(1024, 5, device="cuda")
+    rois[:, 0] = (rois[:, 0] > 0.5).float()
+    rois[:, 1:3] *= 600
+    rois[:, 3:] = rois[:, 1:3] + rois[:, 3:] * 400 + 8
+    for lvl, sc in enumerate((0.25, 0.125, 0.0625, 0.03125)):
+        x = feats[lvl].clone().requires_grad_(True)
+        med, _ = timeit(lambda: ops.roi_align(x, rois, 7, sc, 0, 'avg', True))
+        o = ops.roi_align(x, rois, 7, sc, 0, 'avg', True)
+        g = torch.randn_like(o)
+        medb, _ = timeit(lambda: torch.autograd.grad(o, x, g, retain_graph=True), n=10)
+        print(f"roi_align 1024 rois lvl{lvl}: fwd {med:7.1f} us  bwd {medb:7.1f} us")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["attn", "conv", "ln", "nms", "roi"]
+    for w in which:
+        globals()[w]()
