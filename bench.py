@@ -141,8 +141,12 @@ def main():
     torch.manual_seed(0)                       # identical weights on every rank
     model = detector.build_detector(presets.mask_rcnn_swin("tiny"), compute_dtype=dtype).to(device)
     model.train()
-    reducer = ddp.BucketedGradReducer(model.parameters())
+    from swin_transformer_object_detection_amd import mixed
+    shadows = mixed.ShadowParams(model, dtype) if dtype != torch.float32 else None
+    reducer = ddp.BucketedGradReducer(model.parameters(), leaf_of=shadows.leaf_of if shadows else None)
     reducer.broadcast_parameters()
+    if shadows:
+        shadows.refresh()
     opt_cfg = presets.OPTIMIZER
     optim = torch.optim.AdamW(build_param_groups(model, opt_cfg), lr=opt_cfg["lr"], betas=opt_cfg["betas"], fused=True)
     batch = data.synthetic_batch(PER_GPU_BATCH, IMG_H, IMG_W, device, seed=rank)     # per-rank data
@@ -155,6 +159,8 @@ def main():
         loss.backward()
         reducer.finish()
         optim.step()
+        if shadows:
+            shadows.refresh()
         return log_vars
 
     def barrier():

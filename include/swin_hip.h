@@ -175,10 +175,11 @@ int roi_align_bwd(const float* grad_output, const float* rois, float* grad_input
  * layer).  Writes keep_flags (n) uint8 (1 = kept) and *num_kept (device int32).
  * workspace: >= swin_nms_workspace_bytes(n) bytes of device memory.
  * The whole greedy reduction runs on the device (mmcv copies the bitmask to the host).
+ * max_num > 0: stop after max_num kept boxes (mmcv nms's `max_num`; == slicing the result).
  * ---------------------------------------------------------------------------------- */
 int64_t swin_nms_workspace_bytes(int64_t n);
-int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int offset, uint8_t* keep_flags,
-               int32_t* num_kept, void* workspace, void* stream);
+int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int offset, int max_num,
+               uint8_t* keep_flags, int32_t* num_kept, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from . import ops
+from . import mixed, ops
 from .registry import BACKBONES
 
 _WS = 7
@@ -117,11 +117,8 @@ class PatchEmbed(_Params):
 
 
 def _lin(x, weight, bias, dtype):
-    """Plain library GEMM (hipBLASLt through torch); fp32 master weights cast to the compute dtype."""
-    if dtype != torch.float32:
-        weight = weight.to(dtype)
-        bias = None if bias is None else bias.to(dtype)
-    return F.linear(x, weight, bias)
+    """Plain library GEMM (hipBLASLt through torch) on the compute-dtype copy of the fp32 master weight."""
+    return F.linear(x, mixed.weight(weight, dtype), mixed.weight(bias, dtype))
 
 
 @BACKBONES.register_module()

@@ -40,43 +40,61 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
 }
 
 // one workgroup: walks the 64-box blocks in order; the in-block greedy scan is done by one
-// lane on the 64 diagonal words staged in LDS, then all threads OR the kept rows into `remv`.
+// lane on the 64 diagonal words staged in LDS, then all threads OR the kept rows into `remv`
+// (4 independent loads in flight per thread).  Stops as soon as `max_num` boxes are kept (> 0):
+// the callers slice `dets[:max_per_img]` (rpn_head.py:235, bbox_nms.py:86-88), so later boxes never matter.
 __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks,
-                                                         uint8_t* __restrict__ keep, int32_t* __restrict__ num_kept) {
+                                                         uint8_t* __restrict__ keep, int32_t* __restrict__ num_kept,
+                                                         int max_num) {
     extern __shared__ __attribute__((aligned(16))) uint64_t remv[];   // col_blocks words
     __shared__ uint64_t diag[64];
     __shared__ uint64_t kept_bits;
+    __shared__ int kept_rows[64];
+    __shared__ int kept_cnt, total;
     const int t = threadIdx.x;
     for (int j = t; j < col_blocks; j += 256) remv[j] = 0;
-    int count = 0;
+    if (t == 0) total = 0;
     __syncthreads();
-    for (int b = 0; b < col_blocks; ++b) {
+    int b = 0;
+    for (; b < col_blocks; ++b) {
         const int lim = min(64, n - b * 64);
         if (t < lim) diag[t] = mask[(int64_t)(b * 64 + t) * col_blocks + b];
         __syncthreads();
         if (t == 0) {
             uint64_t r = remv[b], kb = 0;
-            for (int bit = 0; bit < lim; ++bit)
-                if (!((r >> bit) & 1)) { kb |= 1ull << bit; r |= diag[bit]; }
-            kept_bits = kb;
-            count += __popcll(kb);
+            int cnt = 0, tot = total;
+            for (int bit = 0; bit < lim; ++bit) {
+                if ((r >> bit) & 1) continue;
+                if (max_num > 0 && tot + cnt >= max_num) break;
+                kb |= 1ull << bit; r |= diag[bit];
+                kept_rows[cnt++] = b * 64 + bit;
+            }
+            kept_bits = kb; kept_cnt = cnt; total = tot + cnt;
         }
         __syncthreads();
         const uint64_t kb = kept_bits;
+        const int cnt = kept_cnt;
         if (t < lim) keep[b * 64 + t] = (uint8_t)((kb >> t) & 1);
+        if (max_num > 0 && total >= max_num) { ++b; break; }
         for (int j = b + 1 + t; j < col_blocks; j += 256) {
             uint64_t acc = remv[j];
-            uint64_t rest = kb;
-            while (rest) {
-                int bit = __ffsll((long long)rest) - 1;
-                rest &= rest - 1;
-                acc |= mask[(int64_t)(b * 64 + bit) * col_blocks + j];
+            int k = 0;
+            for (; k + 4 <= cnt; k += 4) {
+                uint64_t a0 = mask[(int64_t)kept_rows[k] * col_blocks + j];
+                uint64_t a1 = mask[(int64_t)kept_rows[k + 1] * col_blocks + j];
+                uint64_t a2 = mask[(int64_t)kept_rows[k + 2] * col_blocks + j];
+                uint64_t a3 = mask[(int64_t)kept_rows[k + 3] * col_blocks + j];
+                acc |= (a0 | a1) | (a2 | a3);
             }
+            for (; k < cnt; ++k) acc |= mask[(int64_t)kept_rows[k] * col_blocks + j];
             remv[j] = acc;
         }
         __syncthreads();
     }
-    if (t == 0) *num_kept = count;
+    // early stop: everything after the last processed block is dropped
+    for (int i = b * 64 + t; i < n; i += 256) keep[i] = 0;
+    __syncthreads();
+    if (t == 0) *num_kept = total;
 }
 
 extern "C" int64_t swin_nms_workspace_bytes(int64_t n) {
@@ -85,8 +103,8 @@ extern "C" int64_t swin_nms_workspace_bytes(int64_t n) {
     return n * cb * 8;
 }
 
-extern "C" int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int offset, uint8_t* keep_flags,
-                          int32_t* num_kept, void* workspace, void* stream) {
+extern "C" int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int offset, int max_num,
+                          uint8_t* keep_flags, int32_t* num_kept, void* workspace, void* stream) {
     if (n < 0 || !num_kept) return SWIN_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
@@ -100,6 +118,6 @@ extern "C" int nms_sorted(const float* boxes_sorted, int64_t n, float iou_thresh
     nms_mask_kernel<<<grid, 64, 0, s>>>((const float4*)boxes_sorted, (int)n, iou_threshold, (float)offset,
                                         (uint64_t*)workspace, col_blocks);
     nms_reduce_kernel<<<1, 256, (size_t)col_blocks * 8, s>>>((const uint64_t*)workspace, (int)n, col_blocks, keep_flags,
-                                                            num_kept);
+                                                            num_kept, max_num);
     return swin_launch_status();
 }

@@ -4,14 +4,17 @@ Replaces the reference's ``MMDistributedDataParallel`` wrap (``mmdet/apis/train.
 ``broadcast_buffers=False``) and its per-scalar loss all-reduce (``mmdet/models/detectors/base.py:211-216``).
 
 Design for MI355X / xGMI (one process per GPU, backend "nccl" == RCCL):
-  * gradients live in a few large flat fp32 buffers (``param.grad`` are views), so a bucket is reduced
-    in place with no gather/scatter copies;
-  * buckets are formed in reverse registration order (heads -> FPN -> Swin stage 4..1), which is the
-    order backward produces them; a post-accumulate hook counts arrivals and launches the bucket's
-    async all-reduce as soon as it is complete, so communication hides under the remaining backward;
-  * bucket size defaults to 48 MiB: xGMI links are point-to-point (~153 GB/s each), a few large
-    messages keep every link busy and the per-collective launch cost negligible (Mask R-CNN Swin-T:
-    192 MB of fp32 gradients -> 4 buckets);
+  * the fp32 gradients of all parameters live in a few large flat buffers (``param.grad`` are views), so a
+    bucket is all-reduced in place with no gather/scatter copies and the fused optimizer reads them directly;
+  * autograd leaves may be bf16 shadow copies of the fp32 masters (``mixed.ShadowParams``): when the last
+    gradient of a bucket has been produced, ONE multi-tensor copy moves (and up-converts) the bucket's fresh
+    gradients into the flat fp32 buffer -- no per-parameter cast / accumulate / zero-fill kernels;
+  * buckets are formed in reverse registration order (heads -> FPN -> Swin stage 4..1), the order backward
+    produces them; a post-accumulate hook counts arrivals and launches the bucket's async all-reduce as soon
+    as it is complete, so communication hides under the remaining backward;
+  * bucket size defaults to 48 MiB: xGMI links are point-to-point (~153 GB/s each), a few large messages keep
+    every link busy and the per-collective launch cost negligible (Mask R-CNN Swin-T: 192 MB of fp32
+    gradients -> 4 buckets);
   * the loss scalars for logging are packed into ONE tensor and reduced once, without .item().
 Works unchanged on CPU with the gloo backend (tests/test_ddp_gloo.py, world_size 2).
 """
@@ -20,13 +23,16 @@ import torch.distributed as dist
 
 
 class BucketedGradReducer:
-    def __init__(self, params, bucket_bytes=48 << 20, process_group=None, average=True):
+    def __init__(self, params, bucket_bytes=48 << 20, process_group=None, average=True, leaf_of=None):
+        """params: the fp32 master parameters (what the optimizer updates).  leaf_of(p) -> the tensor autograd
+        accumulates into for p (p itself, or its bf16 shadow)."""
         self.params = [p for p in params if p.requires_grad]
+        self.leaf_of = leaf_of or (lambda p: p)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.average = average
-        self.buckets = []          # list of dict(flat, params, pending, handle)
-        self._p2b = {}
+        self.buckets = []
+        self._l2b = {}
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
             cur.append(p)
@@ -36,52 +42,62 @@ class BucketedGradReducer:
                 cur, cur_bytes = [], 0
         if cur:
             self._make_bucket(cur)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._hooks = []
+        for b in self.buckets:
+            for leaf in b['leaves']:
+                self._hooks.append(leaf.register_post_accumulate_grad_hook(self._on_grad))
 
     def _make_bucket(self, plist):
         n = sum(p.numel() for p in plist)
-        dev = plist[0].device
-        flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
+        flat = torch.zeros(n, device=plist[0].device, dtype=torch.float32)
+        views, off = [], 0
         for p in plist:
-            p.grad = flat[off:off + p.numel()].view_as(p)
+            views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        b = dict(flat=flat, params=list(plist), pending=len(plist), handle=None)
-        for p in plist:
-            self._p2b[p] = b
+        leaves = [self.leaf_of(p) for p in plist]
+        b = dict(flat=flat, params=list(plist), leaves=leaves, views=views, pending=len(plist), handle=None,
+                 arrived=[False] * len(plist), index={id(l): i for i, l in enumerate(leaves)})
+        for l in leaves:
+            self._l2b[id(l)] = b
+        for p, v in zip(plist, views):
+            p.grad = v
         self.buckets.append(b)
 
+    def _gather(self, b):
+        """fresh leaf gradients -> flat fp32 bucket (one multi-tensor copy; converts bf16 -> fp32)."""
+        src, dst = [], []
+        for i, (leaf, p, v) in enumerate(zip(b['leaves'], b['params'], b['views'])):
+            if not b['arrived'][i]:
+                v.zero_()                                   # parameter got no gradient this step
+                continue
+            g = leaf.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                src.append(g); dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for leaf, p, v in zip(b['leaves'], b['params'], b['views']):
+            if leaf is not p:
+                leaf.grad = None
+            p.grad = v
+
     def _launch(self, b):
+        self._gather(b)
         if self.world > 1 and b['handle'] is None:
             if self.average:
                 b['flat'].div_(self.world)
             b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def _on_grad(self, p):
-        b = self._p2b[p]
-        if p.grad.data_ptr() != b['flat'].data_ptr() + self._offset(b, p):
-            # autograd replaced the view (first accumulation into a None grad): copy back into the bucket
-            self._view(b, p).copy_(p.grad)
-            p.grad = self._view(b, p)
-        b['pending'] -= 1
-        if b['pending'] == 0:
-            self._launch(b)
-
-    @staticmethod
-    def _offset(b, p):
-        off = 0
-        for q in b['params']:
-            if q is p:
-                return off * 4
-            off += q.numel()
-        raise KeyError
-
-    def _view(self, b, p):
-        off = self._offset(b, p) // 4
-        return b['flat'][off:off + p.numel()].view_as(p)
+    def _on_grad(self, leaf):
+        b = self._l2b[id(leaf)]
+        i = b['index'][id(leaf)]
+        if not b['arrived'][i]:
+            b['arrived'][i] = True
+            b['pending'] -= 1
+            if b['pending'] == 0:
+                self._launch(b)
 
     def finish(self):
-        """Call after backward: launches buckets whose parameters got no gradient this step and waits."""
+        """Call after backward: handles buckets with parameters that got no gradient, waits for the collectives."""
         for b in self.buckets:
             if b['pending'] > 0:
                 self._launch(b)
@@ -90,10 +106,13 @@ class BucketedGradReducer:
                 b['handle'].wait()
                 b['handle'] = None
             b['pending'] = len(b['params'])
+            b['arrived'] = [False] * len(b['params'])
 
     def zero_grad(self):
+        """Before forward: drop the leaves' gradients (no fill kernels: the buckets are overwritten by _gather)."""
         for b in self.buckets:
-            b['flat'].zero_()
+            for leaf in b['leaves']:
+                leaf.grad = None
 
     def broadcast_parameters(self, src=0):
         """Initial parameter sync (DDP does the same at construction)."""

@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import mixed, ops
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS, ROI_EXTRACTORS, build_from_cfg, build_roi_extractor
 
 
@@ -170,7 +170,8 @@ def random_sample(assigned, num, pos_fraction):
 
 
 def _cast(t, dtype):
-    return t if t.dtype == dtype else t.to(dtype)
+    """compute-dtype view of a tensor; parameters resolve to their bf16 shadow (mixed.py)"""
+    return mixed.weight(t, dtype)
 
 
 def _conv(x, conv, dtype, padding=0, relu=False):
@@ -183,7 +184,7 @@ def _conv(x, conv, dtype, padding=0, relu=False):
         y = F.linear(tok, _cast(conv.weight, dtype).view(conv.out_channels, C), _cast(conv.bias, dtype))
         y = y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
     elif dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and padding == 1 and C % 64 == 0:
-        return ops.conv3x3(x, conv.weight, conv.bias, relu)              # HIP implicit-GEMM kernel (ReLU fused)
+        return ops.conv3x3(x, _cast(conv.weight, dtype), conv.bias, relu)  # HIP implicit-GEMM kernel (ReLU fused)
     else:
         x = x.contiguous(memory_format=torch.channels_last)
         w = _cast(conv.weight, dtype).contiguous(memory_format=torch.channels_last)
@@ -293,7 +294,9 @@ class RPNHead(nn.Module):
                 props, sc, idl = props[v], scores[i][v], ids[i][v]
             else:
                 sc, idl = scores[i], ids[i]
-            dets, _ = ops.batched_nms(props, sc, idl, cfg['nms'])               # HIP nms
+            # max_num == the reference's `dets[:cfg.max_per_img]` (rpn_head.py:235); lets the device reduction stop early
+            nms_cfg = dict(cfg['nms'], max_num=cfg['max_per_img'])
+            dets, _ = ops.batched_nms(props, sc, idl, nms_cfg)                  # HIP nms
             out.append(dets[:cfg['max_per_img']])
         return out
 

@@ -360,7 +360,7 @@ class _Conv3x3(torch.autograd.Function):
         if x.dtype != torch.bfloat16 or not x.is_cuda:
             raise SwinHipError("conv3x3: bf16 GPU activations only (fp32 parity runs use the library conv)")
         x = x.contiguous(memory_format=torch.channels_last)
-        w = weight.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()               # (Cout,3,3,Cin)
+        w = weight.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()               # (Cout,3,3,Cin); no-op cast for a shadow
         b = None if bias is None else _f32(bias.float()).contiguous()
         y = _conv3x3_raw(x, w, b, relu)
         ctx.save_for_backward(x, weight, y if relu else None)

@@ -34,7 +34,8 @@ def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
         ws = torch.empty(lib().swin_nms_workspace_bytes(n), dtype=torch.uint8, device=boxes.device)
         flags = torch.empty(n, dtype=torch.uint8, device=boxes.device)
         cnt = torch.empty(1, dtype=torch.int32, device=boxes.device)
-        call("nms_sorted", _p(bs), n, float(iou_threshold), int(offset), _p(flags), _p(cnt), _p(ws), _s())
+        call("nms_sorted", _p(bs), n, float(iou_threshold), int(offset), int(max(max_num, 0)), _p(flags), _p(cnt), _p(ws),
+             _s())
         inds = order[flags.bool()]
     if max_num > 0:
         inds = inds[:max_num]

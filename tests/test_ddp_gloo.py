@@ -50,7 +50,8 @@ def _worker(rank, world, port, q):
         sum(ref(x).square().mean() for x in xs).div(world).backward()
         for p, r in zip(model.parameters(), ref.parameters()):
             ok &= torch.allclose(p.grad, r.grad, atol=1e-6)
-            ok &= p.grad.data_ptr() >= red._p2b[p]['flat'].data_ptr()      # still a view of the bucket
+            flat = red._l2b[id(p)]['flat']
+            ok &= flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4   # a view of the bucket
         for p in unused.parameters():
             ok &= float(p.grad.abs().max()) == 0.0
     logs = ddp.reduce_log_vars({"loss_a": torch.tensor(float(rank)), "loss_b": torch.tensor(2.0)})

@@ -382,3 +382,17 @@ def test_conv3x3_bf16(ops, N, H, W, Cin, Cout, relu):
     close(x1.grad, x0.grad, bf16_tol(x0.grad, 3), msg="dx")
     close(w1.grad, w0.grad, bf16_tol(w0.grad, 3), msg="dw")
     close(b1.grad, b0.grad, bf16_tol(b0.grad, 3) + 1e-2, msg="db")
+
+
+def test_nms_max_num_early_stop(ops):
+    """max_num (mmcv nms) == slicing the full result; exercised across 64-box block boundaries."""
+    rng = np.random.RandomState(21)
+    n = 3000
+    xy = rng.rand(n, 2).astype(np.float32) * 600
+    boxes = np.concatenate([xy, xy + rng.rand(n, 2).astype(np.float32) * 60 + 1], 1)
+    scores = rng.rand(n).astype(np.float32)
+    dref, kref = D.nms_c(boxes, scores, 0.5)
+    for m in (1, 63, 64, 65, 500, len(kref), len(kref) + 10):
+        dets, keep = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.5, 0, 0, m)
+        np.testing.assert_array_equal(keep.cpu().numpy(), kref[:m])
+        np.testing.assert_array_equal(dets.cpu().numpy(), dref[:m])

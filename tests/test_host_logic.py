@@ -134,3 +134,42 @@ def test_max_iou_assigner_semantics():
     assert pos.numel() == 128 and neg.numel() == 128 and (big[pos] > 0).all() and (big[neg] == 0).all()
     pos, neg = detector.random_sample(big[280:], 512, 0.25)
     assert pos.numel() == 20 and neg.numel() == 492
+
+
+def test_shadow_params_and_gradient_gather():
+    """bf16 shadow leaves (mixed.ShadowParams) + the reducer's bucket gather: masters receive fp32 gradients in
+    the flat buckets, shadows follow the masters after refresh(), fp32 small parameters keep direct gradients."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from swin_transformer_object_detection_amd import ddp, mixed
+    torch.manual_seed(0)
+    lin1, lin2 = nn.Linear(64, 32), nn.Linear(32, 64)          # weights 2048 elements -> shadowed; biases are not
+    model = nn.ModuleList([lin1, lin2])
+    sh = mixed.ShadowParams(model, torch.bfloat16)
+    try:
+        assert len(sh.shadows) == 2 and sh.flat.dtype == torch.bfloat16
+        assert mixed.weight(lin1.weight, torch.bfloat16) is sh.shadows[0]
+        assert mixed.weight(lin1.bias, torch.bfloat16).dtype == torch.bfloat16      # plain cast
+        red = ddp.BucketedGradReducer(model.parameters(), bucket_bytes=4096, leaf_of=sh.leaf_of)
+        x = torch.randn(5, 64)
+        for _ in range(2):
+            red.zero_grad()
+            h = F.linear(x.bfloat16(), mixed.weight(lin1.weight, torch.bfloat16), mixed.weight(lin1.bias, torch.bfloat16))
+            y = F.linear(h, mixed.weight(lin2.weight, torch.bfloat16), mixed.weight(lin2.bias, torch.bfloat16))
+            y.float().square().mean().backward()
+            red.finish()
+            # reference gradient in fp32 on the same (bf16-rounded) weights
+            w1, w2 = sh.shadows[0].detach().float().requires_grad_(True), sh.shadows[1].detach().float().requires_grad_(True)
+            yr = F.linear(F.linear(x.bfloat16().float(), w1, lin1.bias.detach()), w2, lin2.bias.detach())
+            yr.square().mean().backward()
+            for p, r in ((lin1.weight, w1), (lin2.weight, w2)):
+                assert p.grad.dtype == torch.float32
+                np.testing.assert_allclose(p.grad.numpy(), r.grad.numpy(), atol=0.05 * float(r.grad.abs().max()) + 1e-4)
+            assert lin1.bias.grad is not None and lin1.bias.grad.dtype == torch.float32
+            assert all(s.grad is None for s in sh.shadows)
+        with torch.no_grad():
+            lin1.weight.add_(1.0)
+        sh.refresh()
+        np.testing.assert_allclose(sh.shadows[0].detach().float().numpy(), lin1.weight.detach().bfloat16().float().numpy())
+    finally:
+        sh.release()
