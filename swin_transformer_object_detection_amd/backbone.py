@@ -118,7 +118,7 @@ class PatchEmbed(_Params):
 
 def _lin(x, weight, bias, dtype):
     """Plain library GEMM (hipBLASLt through torch) on the compute-dtype copy of the fp32 master weight."""
-    return F.linear(x, mixed.weight(weight, dtype), mixed.weight(bias, dtype))
+    return ops.linear(x, mixed.weight(weight, dtype), mixed.weight(bias, dtype))
 
 
 @BACKBONES.register_module()

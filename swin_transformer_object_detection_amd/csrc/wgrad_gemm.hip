@@ -1,0 +1,171 @@
+// Weight-gradient GEMM for gfx950: dW[n1][n2] (+)= sum_t dY[t][n1] * X[t][n2], bf16 in, fp32 out.
+// The contraction runs over the TOKEN / PIXEL index t (10^4..10^5 long) while n1, n2 are a few hundred, so
+//   * the t range is split over grid.z and the partial tiles are combined with contiguous fp32 atomics
+//     (a 128x128 tile = 64 KB per split: far below the atomic-rate budget, guide G12);
+//   * both MFMA operands are "column" reads of row-major [t][n] LDS tiles -> ds_read_b64_tr_b16.
+// X is either a plain (T, N2) matrix (Linear layers: dW = dY^T X) or the implicit im2col of a channels-last
+// activation for a 3x3/pad-1 convolution (N2 = 9*Cin ordered (ky,kx,cin); replaces torch.cat + library GEMM).
+// Reference sites: the autograd of nn.Linear at swin_transformer.py:129,151,33,36,296 and of the 3x3 convs at
+// fpn.py:195-197, rpn_head.py:43, fcn_mask_head.py:119-121.
+#include "common.h"
+
+#define WT 64          // t rows per stage
+#define WN 128         // tile width (n1 and n2)
+#define WROW 160       // LDS row stride in bf16 (320 B: conflict-free 4-row transposed reads)
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_w;
+
+struct PlainX {
+    const bf16* x; int64_t T; int N2;
+    __device__ __forceinline__ uint4 load(int64_t t, int n) const {        // 8 consecutive n at row t
+        uint4 z = {0, 0, 0, 0};
+        if (t >= T || n >= N2) return z;
+        return *(const uint4*)(x + t * N2 + n);
+    }
+};
+
+struct ConvX {
+    const bf16* x; int64_t T; int H, W, Cin;
+    __device__ __forceinline__ uint4 load(int64_t t, int n) const {
+        uint4 z = {0, 0, 0, 0};
+        if (t >= T) return z;
+        int tap = n / Cin, c = n - tap * Cin;
+        if (tap >= 9) return z;
+        int xx = (int)(t % W); int64_t r = t / W; int yy = (int)(r % H);
+        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        yy += dy; xx += dx;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) return z;
+        return *(const uint4*)(x + (t + (int64_t)dy * W + dx) * Cin + c);
+    }
+};
+
+// transposed fragment: rows t0 + 8*h + j (j = 0..7) of column (col0 + lane&31) of a [WT][WROW] tile
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t0, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int h = g >> 1, dh = g & 1;
+    const bf16* a0 = tile + (t0 + 8 * h + q) * WROW + col0 + 16 * dh + 4 * p;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_w*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_w*)(a0 + 4 * WROW));
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    return f;
+}
+
+template <typename XLoader>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ dy, XLoader X, float* __restrict__ dw, int64_t T,
+                                                       int N1, int N2, int64_t t_per_split, int use_atomic) {
+    __shared__ __attribute__((aligned(16))) bf16 lds[2][WT * WROW];        // [dY|X], single stage (40 KB -> 2 blocks/CU);
+                                                                           // the next stage waits in registers
+    const int n1_0 = blockIdx.y * WN, n2_0 = blockIdx.x * WN;
+    const int64_t t_begin = (int64_t)blockIdx.z * t_per_split;
+    const int64_t t_end = min(T, t_begin + t_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w1 = wave >> 1, w2 = wave & 1;                 // wave -> 64x64 sub-tile (n1, n2)
+    const int c = lane & 31, h = lane >> 5;
+    // staging: tile = 64 rows x 16 pieces of 16 B; thread handles rows (tid/16 + 16 i), piece tid%16
+    const int srow = tid >> 4, spiece = tid & 15;
+    uint4 ra[4], rb[4];
+    auto gload = [&](int64_t t0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t t = t0 + srow + 16 * i;
+            int n1 = n1_0 + spiece * 8;
+            uint4 z = {0, 0, 0, 0};
+            ra[i] = (t < t_end && n1 < N1) ? *(const uint4*)(dy + t * N1 + n1) : z;
+            rb[i] = t < t_end ? X.load(t, n2_0 + spiece * 8) : z;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = srow + 16 * i;
+            *(uint4*)&lds[0][row * WROW + spiece * 8] = ra[i];
+            *(uint4*)&lds[1][row * WROW + spiece * 8] = rb[i];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
+
+    if (t_begin < t_end) {
+        gload(t_begin);
+        lstore();
+        __syncthreads();
+        for (int64_t t0 = t_begin; t0 < t_end; t0 += WT) {
+            const bool more = t0 + WT < t_end;
+            if (more) gload(t0 + WT);
+            const bf16* As = lds[0];
+            const bf16* Bs = lds[1];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                     // 16 t per MFMA k-step
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = tr_frag(As, 16 * s, w1 * 64 + 32 * i, lane);     // A[row n1][k = t]
+                    bfr[i] = tr_frag(Bs, 16 * s, w2 * 64 + 32 * i, lane);    // B[k = t][col n2]
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();                                  // everyone is done reading this stage
+            if (more) lstore();
+            __syncthreads();
+        }
+    }
+    // D[row n1][col n2]: lane = n2 column, registers = n1 rows -> 32 consecutive n2 per half-wave: 128-B segments
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int n2 = n2_0 + w2 * 64 + 32 * j + c;
+            if (n2 >= N2) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int n1 = n1_0 + w1 * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (n1 >= N1) continue;
+                float* p = dw + (int64_t)n1 * N2 + n2;
+                if (use_atomic) atomicAdd(p, acc[i][j][reg]);
+                else *p = acc[i][j][reg];
+            }
+        }
+}
+
+template <typename XLoader>
+static int wgrad_launch(const bf16* dy, XLoader X, float* dw, int64_t T, int N1, int N2, hipStream_t s) {
+    int g1 = (N1 + WN - 1) / WN, g2 = (N2 + WN - 1) / WN;
+    // enough splits to fill the chip (~2 blocks per CU), each split a multiple of the t-stage
+    int64_t stages = (T + WT - 1) / WT;
+    int splits = (int)((512 + (int64_t)g1 * g2 - 1) / ((int64_t)g1 * g2));
+    if (splits > stages) splits = (int)stages;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    int64_t per = ((stages + splits - 1) / splits) * WT;
+    splits = (int)((T + per - 1) / per);
+    dim3 grid(g2, g1, splits);
+    wgrad_kernel<XLoader><<<grid, 256, 0, s>>>(dy, X, dw, T, N1, N2, per, 1);
+    return swin_launch_status();
+}
+
+// dw (N1, N2) f32 += dy(T, N1)^T x(T, N2).   N1 % 8 == 0, N2 % 8 == 0.  ACCUMULATES (caller zeroes).
+extern "C" int wgrad_linear_bf16(const void* dy, const void* x, float* dw, int64_t T, int N1, int N2, void* stream) {
+    if (!dy || !x || !dw || T <= 0 || N1 <= 0 || N2 <= 0) return SWIN_ERR_BAD_ARG;
+    if (N1 % 8 || N2 % 8) return SWIN_ERR_UNSUPPORTED;
+    PlainX X{(const bf16*)x, T, N2};
+    return wgrad_launch((const bf16*)dy, X, dw, T, N1, N2, (hipStream_t)stream);
+}
+
+// dw (Cout, 3, 3, Cin) f32 += conv-weight gradient; dy (N,H,W,Cout), x (N,H,W,Cin) bf16 channels-last.
+extern "C" int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
+                                       void* stream) {
+    if (!dy || !x || !dw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SWIN_ERR_BAD_ARG;
+    if (Cin % 8 || Cout % 8) return SWIN_ERR_UNSUPPORTED;
+    int64_t T = (int64_t)N * H * W;
+    ConvX X{(const bf16*)x, T, H, W, Cin};
+    return wgrad_launch((const bf16*)dy, X, dw, T, Cout, 9 * Cin, (hipStream_t)stream);
+}

@@ -4,7 +4,7 @@
 ``mmcv.ops`` because the reference looks them up by name
 (``getattr(ops, 'RoIAlign')``, base_roi_extractor.py:51-52).
 """
-from .functional import (add_layer_norm, add_scaled, bias_gelu, conv3x3, layer_norm, patch_im2row,  # noqa: F401
+from .functional import (add_layer_norm, add_scaled, bias_gelu, conv3x3, layer_norm, linear, patch_im2row,  # noqa: F401
                          patch_merge_layer_norm, rel_bias_expand, upsample_add, window_attention)
 from .nms import batched_nms, nms  # noqa: F401
 from .roi_align import RoIAlign, roi_align  # noqa: F401

@@ -381,9 +381,9 @@ class _Conv3x3(torch.autograd.Function):
             wt = weight.to(torch.bfloat16).flip(2, 3).permute(1, 2, 3, 0).contiguous()
             dx = _conv3x3_raw(dy, wt, None, False)
         if ctx.needs_input_grad[1]:
-            cols = _im2col3x3(x)                                                       # (M, 9*Cin)
-            dyt = dy.permute(0, 2, 3, 1).reshape(N * H * W, Cout)
-            dw = (dyt.t() @ cols).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).to(weight.dtype)
+            dwf = torch.zeros(Cout, 3, 3, Cin, device=x.device, dtype=torch.float32)
+            call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), N, H, W, Cin, Cout, _s())   # implicit im2col
+            dw = dwf.permute(0, 3, 1, 2).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.permute(0, 2, 3, 1).reshape(-1, Cout).sum(0, dtype=torch.float32)
         return dx, dw, db, None
@@ -392,3 +392,45 @@ class _Conv3x3(torch.autograd.Function):
 def conv3x3(x, weight, bias=None, relu=False):
     """3x3, padding 1, stride 1 conv of a logically-NCHW bf16 tensor (channels-last memory)."""
     return _Conv3x3.apply(x, weight, bias, relu)
+
+
+# --------------------------------------------------------------------------------------
+# Linear layer with the weight gradient on the split-T MFMA kernel
+# --------------------------------------------------------------------------------------
+class _LinearBf16(torch.autograd.Function):
+    """y = x w^T + b.  Forward / data gradient: library GEMM.  Weight gradient dW = dY^T X contracts over the
+    token index (up to 128 000 long, outputs a few hundred wide): the split-T kernel (wgrad_gemm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N1, N2 = w.shape
+        dy2 = dy.reshape(-1, N1)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        x2 = x.reshape(-1, N2)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ w).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dwf = torch.zeros(N1, N2, device=x.device, dtype=torch.float32)
+            call("wgrad_linear_bf16", _p(dy2), _p(x2.contiguous()), _p(dwf), dy2.shape[0], N1, N2, _s())
+            dw = dwf.to(w.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """nn.Linear forward on compute-dtype operands; bf16 GPU tensors with 8-aligned widths and a long token axis
+    use the hand-written weight-gradient kernel, anything else is the plain library path."""
+    if (x.dtype == torch.bfloat16 and x.is_cuda and w.dtype == torch.bfloat16 and w.shape[0] % 8 == 0
+            and w.shape[1] % 8 == 0 and x.numel() // w.shape[1] >= 2048):
+        return _LinearBf16.apply(x, w, b)
+    return torch.nn.functional.linear(x, w, b)

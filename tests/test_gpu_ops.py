@@ -396,3 +396,22 @@ def test_nms_max_num_early_stop(ops):
         dets, keep = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.5, 0, 0, m)
         np.testing.assert_array_equal(keep.cpu().numpy(), kref[:m])
         np.testing.assert_array_equal(dets.cpu().numpy(), dref[:m])
+
+
+@pytest.mark.parametrize("T,N1,N2", [(5000, 288, 96), (2048, 96, 384), (9000, 768, 192), (2500, 1536, 384), (4100, 256, 48)])
+def test_linear_wgrad_bf16(ops, T, N1, N2):
+    """ops.linear: forward/dx through the library, dW through the split-T MFMA kernel; oracle = fp32 autograd on CPU."""
+    g = torch.Generator().manual_seed(T + N1)
+    x = torch.randn(T, N2, generator=g).bfloat16().float()
+    w = (torch.randn(N1, N2, generator=g) * 0.05).bfloat16().float()
+    b = torch.randn(N1, generator=g).bfloat16().float()
+    gy = torch.randn(T, N1, generator=g).bfloat16().float()
+    x0, w0, b0 = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (F.linear(x0, w0, b0) * gy).sum().backward()
+    x1 = x.cuda().bfloat16().requires_grad_(True)
+    w1, b1 = w.cuda().bfloat16().requires_grad_(True), b.cuda().bfloat16().requires_grad_(True)
+    y = ops.linear(x1, w1, b1)
+    (y.float() * gy.cuda()).sum().backward()
+    close(w1.grad, w0.grad, bf16_tol(w0.grad, 2), msg="dW")      # fp32 accumulation, one bf16 rounding at the end
+    close(x1.grad, x0.grad, bf16_tol(x0.grad, 3), msg="dx")
+    close(b1.grad, b0.grad, bf16_tol(b0.grad, 2), msg="db")
