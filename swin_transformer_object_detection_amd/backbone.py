@@ -241,7 +241,7 @@ class SwinTransformer(nn.Module):
         pe = self.patch_embed
         rows = ops.patch_im2row(x.float().contiguous(), dt)                              # :433-438
         Wh, Ww = (Hi + 3) // 4, (Wi + 3) // 4
-        t = _lin(rows, pe.proj.weight.view(self.embed_dim, 48), pe.proj.bias, dt)
+        t = ops.linear(rows, mixed.weight(pe.proj.weight, dt).view(self.embed_dim, 48), mixed.weight(pe.proj.bias, dt))
         if pe.norm is not None:
             t = ops.layer_norm(t, pe.norm.weight, pe.norm.bias)                          # :441-443
         t = t.view(B, Wh * Ww, self.embed_dim)

@@ -19,14 +19,14 @@
 
 struct ConvGeom { int N, H, W, Cin; };
 
-// ---- A-operand loaders: 16-byte piece `piece` (0..7) of row `m` for K-tile `kt` --------------------
+// ---- A-operand loaders: element offset of 16-byte piece `piece` (0..7) of row `m` for K-tile `kt`, or -1 when
+// the piece is zero padding.  (The load itself is done by the kernel from a CLAMPED address and masked by value:
+// selecting between a global pointer and a local zero makes hipcc emit flat loads with a full wait after each.)
 struct PlainA {
     const bf16* a; int64_t M; int K;
     __device__ __forceinline__ void prep(int64_t m, int64_t& base, int& y, int& x) const { base = m < M ? m * K : -1; y = x = 0; }
-    __device__ __forceinline__ uint4 load(int64_t base, int y, int x, int kt, int piece) const {
-        uint4 z = {0, 0, 0, 0};
-        if (base < 0) return z;
-        return *(const uint4*)(a + base + kt * BK + piece * 8);
+    __device__ __forceinline__ int64_t offset(int64_t base, int y, int x, int kt, int piece) const {
+        return base < 0 ? -1 : base + kt * BK + piece * 8;
     }
 };
 
@@ -37,16 +37,21 @@ struct ConvA {
         x = (int)(m % g.W); int64_t t = m / g.W; y = (int)(t % g.H);
         base = m * g.Cin;                              // pixel (n,y,x) itself
     }
-    __device__ __forceinline__ uint4 load(int64_t base, int y, int x, int kt, int piece) const {
-        uint4 z = {0, 0, 0, 0};
-        if (base < 0) return z;
+    __device__ __forceinline__ int64_t offset(int64_t base, int y, int x, int kt, int piece) const {
         int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
         int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         int yy = y + dy, xx = x + dx;
-        if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) return z;
-        return *(const uint4*)(a + base + ((int64_t)dy * g.W + dx) * g.Cin + c0 + piece * 8);
+        bool ok = base >= 0 && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+        return ok ? base + ((int64_t)dy * g.W + dx) * g.Cin + c0 + piece * 8 : -1;
     }
 };
+
+__device__ __forceinline__ uint4 masked_load16(const bf16* p, int64_t off) {
+    const bool ok = off >= 0;
+    uint4 v = *(const uint4*)(p + (ok ? off : 0));
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    return v;
+}
 
 __device__ __forceinline__ int swz(int row, int piece) { return piece ^ (row & 7); }
 
@@ -73,23 +78,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
     int64_t abase[4]; int ay[4], ax[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) A.prep(m0 + srow + 32 * i, abase[i], ay[i], ax[i]);
-    const bf16* wrow[4];
+    int64_t woff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int n = n0 + srow + 32 * i;
-        wrow[i] = n < Nn ? Wt + (int64_t)n * K + spiece * 8 : nullptr;
+        woff[i] = n < Nn ? (int64_t)n * K + spiece * 8 : -1;
     }
     const int nk = K / BK;
-    uint4 ra[4], rw[4];
-    auto gload = [&](int kt) {
+    // two register stages: while tile kt is consumed from LDS, tile kt+1 sits in one register set (landed or
+    // landing) and the loads of tile kt+2 are issued into the other, so ~2 tiles of MFMA work cover the L2/HBM
+    // latency (with one stage the waves sat on s_waitcnt 65 % of the time: profiles/r01_pmc_conv_v1.txt)
+    uint4 ra0[4], rw0[4], ra1[4], rw1[4];
+    auto gload = [&](int kt, uint4 (&ra)[4], uint4 (&rw)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = A.load(abase[i], ay[i], ax[i], kt, spiece);
-            uint4 z = {0, 0, 0, 0};
-            rw[i] = wrow[i] ? *(const uint4*)(wrow[i] + kt * BK) : z;
+            ra[i] = masked_load16(A.a, A.offset(abase[i], ay[i], ax[i], kt, spiece));
+            rw[i] = masked_load16(Wt, woff[i] < 0 ? -1 : woff[i] + kt * BK);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const uint4 (&ra)[4], const uint4 (&rw)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int row = srow + 32 * i;
@@ -97,21 +104,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
             lds[buf][1][row * 8 + swz(row, spiece)] = rw[i];
         }
     };
-
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
-        const uint4* As = lds[cur][0];
-        const uint4* Ws = lds[cur][1];
+    auto compute = [&](int buf) {
+        const uint4* As = lds[buf][0];
+        const uint4* Ws = lds[buf][1];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 wf[2], af[2];
@@ -129,9 +129,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
                 for (int mt = 0; mt < 2; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+    };
+
+    gload(0, ra0, rw0);
+    if (nk > 1) gload(1, ra1, rw1);
+    lstore(0, ra0, rw0);
+    __syncthreads();
+    // top of an (even) iteration: LDS[0] = tile kt, register set 1 = tile kt+1, register set 0 free
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) gload(kt + 2, ra0, rw0);
+        compute(0);
+        if (kt + 1 < nk) lstore(1, ra1, rw1);
         __syncthreads();
-        cur ^= 1;
+        if (kt + 1 >= nk) break;
+        if (kt + 3 < nk) gload(kt + 3, ra1, rw1);
+        compute(1);
+        if (kt + 2 < nk) lstore(0, ra0, rw0);
+        __syncthreads();
     }
 
     // epilogue: lane = pixel m, registers = output channels

@@ -15,29 +15,33 @@
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_w;
 
+// loaders return the ELEMENT OFFSET of 8 consecutive n at row t, or -1 for zero padding; the kernel loads from a
+// clamped address and masks by value (a pointer select against a local zero becomes a flat load + full wait)
 struct PlainX {
     const bf16* x; int64_t T; int N2;
-    __device__ __forceinline__ uint4 load(int64_t t, int n) const {        // 8 consecutive n at row t
-        uint4 z = {0, 0, 0, 0};
-        if (t >= T || n >= N2) return z;
-        return *(const uint4*)(x + t * N2 + n);
+    __device__ __forceinline__ int64_t offset(int64_t t, int n) const {
+        return (t >= T || n >= N2) ? -1 : t * N2 + n;
     }
 };
 
 struct ConvX {
     const bf16* x; int64_t T; int H, W, Cin;
-    __device__ __forceinline__ uint4 load(int64_t t, int n) const {
-        uint4 z = {0, 0, 0, 0};
-        if (t >= T) return z;
+    __device__ __forceinline__ int64_t offset(int64_t t, int n) const {
         int tap = n / Cin, c = n - tap * Cin;
-        if (tap >= 9) return z;
         int xx = (int)(t % W); int64_t r = t / W; int yy = (int)(r % H);
         int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         yy += dy; xx += dx;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) return z;
-        return *(const uint4*)(x + (t + (int64_t)dy * W + dx) * Cin + c);
+        bool ok = t < T && tap < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        return ok ? (t + (int64_t)dy * W + dx) * Cin + c : -1;
     }
 };
+
+__device__ __forceinline__ uint4 masked_load16w(const bf16* p, int64_t off) {
+    const bool ok = off >= 0;
+    uint4 v = *(const uint4*)(p + (ok ? off : 0));
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    return v;
+}
 
 // transposed fragment: rows t0 + 8*h + j (j = 0..7) of column (col0 + lane&31) of a [WT][WROW] tile
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t0, int col0, int lane) {
@@ -71,9 +75,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ 
         for (int i = 0; i < 4; ++i) {
             int64_t t = t0 + srow + 16 * i;
             int n1 = n1_0 + spiece * 8;
-            uint4 z = {0, 0, 0, 0};
-            ra[i] = (t < t_end && n1 < N1) ? *(const uint4*)(dy + t * N1 + n1) : z;
-            rb[i] = t < t_end ? X.load(t, n2_0 + spiece * 8) : z;
+            ra[i] = masked_load16w(dy, (t < t_end && n1 < N1) ? t * N1 + n1 : -1);
+            rb[i] = masked_load16w(X.x, t < t_end ? X.offset(t, n2_0 + spiece * 8) : -1);
         }
     };
     auto lstore = [&]() {

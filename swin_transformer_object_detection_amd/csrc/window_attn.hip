@@ -485,17 +485,22 @@ __device__ __forceinline__ void bwd_issue_loads(bf16x8 (&stg)[13], const BwdLane
         for (int i = 0; i < 13; ++i)
             if (i < 12 || L.tokr == 0) stg[i] = *(const bf16x8*)(pb + L.ld_off[i]);
     } else {
+        // general path (windows touching the wrap-around or the padding): padded tokens read qkv.bias (their q|k|v)
+        // or zero (dO of a cropped row).  Loads go to a clamped address and are fixed up by VALUE.
+        bf16x8 padv;
+        if (is_do) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) padv[e] = (bf16)0.f;
+        } else padv = bias_to_bf16x8(qkv_bias + ch);
+        const bf16* pb = is_do ? dout + ch : qkv + ch;
+        const int stride = is_do ? g.C : C3;
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
             int t = 4 * i + L.tokr;
             if (t < NTOK) {
                 int src = token_src(g, b, wr, wc, t);
-                if (src >= 0) stg[i] = is_do ? *(const bf16x8*)(dout + (size_t)src * g.C + ch)
-                                             : *(const bf16x8*)(qkv + (size_t)src * C3 + ch);
-                else if (is_do) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) stg[i][e] = (bf16)0.f;   // cropped rows get no gradient
-                } else stg[i] = bias_to_bf16x8(qkv_bias + ch);
+                bf16x8 v = *(const bf16x8*)(pb + (size_t)(src >= 0 ? src : 0) * stride);
+                stg[i] = src >= 0 ? v : padv;
             }
         }
     }
@@ -610,34 +615,35 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
             if (wr == g.nWh - 1) mbits |= mrow;
             if (wc == g.nWw - 1) mbits |= mcol;
         }
-        f32x16 pacc[2][2], dpacc[2][2];
-        {
-            bf16x8 qf[2][2], kf[2][2], vf[2][2], df[2][2];
+        bf16x8 kf[2][2], vf[2][2];
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                kf[t2][s] = *(const bf16x8*)&Ks[32 * t2 + c][16 * s + 8 * h];
+                vf[t2][s] = *(const bf16x8*)&Vs[32 * t2 + c][16 * s + 8 * h];
+            }
+        f32x16 dq[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {           // one 32-query tile at a time (register budget)
+            bf16x8 qf[2], df[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                qf[s] = *(const bf16x8*)&Qs[32 * qt + c][16 * s + 8 * h];
+                df[s] = *(const bf16x8*)&Ds[32 * qt + c][16 * s + 8 * h];
+            }
+            f32x16 pacc[2], dpacc[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 a = {0}, d = {0};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    qf[t2][s] = *(const bf16x8*)&Qs[32 * t2 + c][16 * s + 8 * h];
-                    kf[t2][s] = *(const bf16x8*)&Ks[32 * t2 + c][16 * s + 8 * h];
-                    vf[t2][s] = *(const bf16x8*)&Vs[32 * t2 + c][16 * s + 8 * h];
-                    df[t2][s] = *(const bf16x8*)&Ds[32 * t2 + c][16 * s + 8 * h];
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], a, 0, 0, 0);   // S^T
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], df[s], d, 0, 0, 0);   // dP^T
                 }
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    f32x16 a = {0}, d = {0};
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], a, 0, 0, 0);   // S^T
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], df[qt][s], d, 0, 0, 0);   // dP^T
-                    }
-                    pacc[kt][qt] = a;
-                    dpacc[kt][qt] = d;
-                }
-        }
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+                pacc[kt] = a;
+                dpacc[kt] = d;
+            }
             const int q = 32 * qt + c;
             const bool qv = q < NTOK;
             const float l2 = lse[(size_t)task * TILE + (qv ? q : 0)] * LOG2E;
@@ -646,11 +652,11 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    float v = fmaf(pacc[kt][qt][reg], sl2, biasr[kt][qt][reg]);
+                    float v = fmaf(pacc[kt][reg], sl2, biasr[kt][qt][reg]);
                     if (edge && ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1)) v += -100.0f * LOG2E;
                     float p = qv ? __builtin_amdgcn_exp2f(v - l2) : 0.f;   // padded query columns carry garbage
-                    pacc[kt][qt][reg] = p;
-                    d4[reg & 3] = fmaf(p, dpacc[kt][qt][reg], d4[reg & 3]);
+                    pacc[kt][reg] = p;
+                    d4[reg & 3] = fmaf(p, dpacc[kt][reg], d4[reg & 3]);
                 }
             const float delta = half_swap_sum((d4[0] + d4[1]) + (d4[2] + d4[3]));
 #pragma unroll
@@ -661,33 +667,31 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int reg = 4 * gq + e;
-                        float ds = pacc[kt][qt][reg] * (dpacc[kt][qt][reg] - delta);
+                        float ds = pacc[kt][reg] * (dpacc[kt][reg] - delta);
                         dbacc[kt][qt][reg] += ds;
                         ds *= scale;                              // scale * dS^T from here on
-                        dpacc[kt][qt][reg] = ds;
-                        p4[e] = (bf16)pacc[kt][qt][reg];
+                        dpacc[kt][reg] = ds;
+                        p4[e] = (bf16)pacc[kt][reg];
                         s4[e] = (bf16)ds;
                     }
                     // [query][key] tiles: this lane's 4 consecutive keys
                     *(bf16x4*)&Lm->p[q][32 * kt + 8 * gq + 4 * h] = p4;
                     *(bf16x4*)&Lm->ds[q][32 * kt + 8 * gq + 4 * h] = s4;
                 }
-        }
-        // dQ^T = K^T (scale dS^T)
-        f32x16 dq[2] = {{0}, {0}};
+            // dQ^T = K^T (scale dS^T)
+            f32x16 dqa = {0};
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 kc = lds_tr_frag_perm(Ks, 32 * kt + 16 * s, lane);
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 kc = lds_tr_frag_perm(Ks, 32 * kt + 16 * s, lane);
                     bf16x8 sf;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) sf[j] = (bf16)dpacc[kt][qt][8 * s + j];
-                    dq[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, sf, dq[qt], 0, 0, 0);
+                    for (int j = 0; j < 8; ++j) sf[j] = (bf16)dpacc[kt][8 * s + j];
+                    dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, sf, dqa, 0, 0, 0);
                 }
-            }
+            dq[qt] = dqa;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 

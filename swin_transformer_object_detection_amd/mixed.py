@@ -23,11 +23,18 @@ def weight(p, dtype):
 
 class ShadowParams:
     def __init__(self, module, dtype=torch.bfloat16, min_numel=1024):
-        """Shadows are created for floating-point parameters with >= min_numel elements (the GEMM / conv
-        weights); small vectors (LayerNorm affine, biases, bias tables) are consumed in fp32 by the kernels."""
+        """Shadows are created for the ``weight`` of Linear / Conv2d / ConvTranspose2d layers with >= min_numel
+        elements (the GEMM / conv operands).  Everything else (LayerNorm affine, biases, relative-position bias
+        tables, position embeddings) is consumed in fp32 by the kernels and keeps its direct gradient."""
+        import torch.nn as nn
         self.dtype = dtype
-        self.masters = [p for p in module.parameters() if p.requires_grad and p.dtype == torch.float32
-                        and p.numel() >= min_numel and p.dim() >= 2]
+        seen, self.masters = set(), []
+        for m in module.modules():
+            if isinstance(m, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)):
+                p = m.weight
+                if p.requires_grad and p.dtype == torch.float32 and p.numel() >= min_numel and id(p) not in seen:
+                    seen.add(id(p))
+                    self.masters.append(p)
         n = sum(p.numel() for p in self.masters)
         dev = self.masters[0].device if self.masters else torch.device("cpu")
         self.flat = torch.empty(n, device=dev, dtype=dtype)

@@ -175,3 +175,32 @@ def test_mask_head_deconv_as_gemm(pkg):
     ref = F.relu(F.conv_transpose2d(x, h.upsample.weight, h.upsample.bias, stride=2))
     got = h.cuda()._deconv2x2_relu(x.cuda().contiguous(memory_format=torch.channels_last), torch.float32)
     _cmp(got, ref.detach().numpy(), 1e-4)
+
+
+def test_training_step_every_parameter_gets_gradient(pkg):
+    """One bf16 Mask R-CNN step with shadow parameters + the bucketed reducer: every master parameter must end up
+    with a finite, non-zero fp32 gradient in its flat bucket (catches a weight consumed outside its shadow)."""
+    from swin_transformer_object_detection_amd import data, ddp, detector, mixed, presets
+    torch.manual_seed(0)
+    cfg = presets.mask_rcnn_swin("tiny")
+    cfg["backbone"]["drop_path_rate"] = 0.0          # a dropped branch legitimately has zero gradient
+    model = detector.build_detector(cfg, compute_dtype=torch.bfloat16).cuda().train()
+    sh = mixed.ShadowParams(model, torch.bfloat16)
+    try:
+        red = ddp.BucketedGradReducer(model.parameters(), leaf_of=sh.leaf_of)
+        batch = data.synthetic_batch(1, 256, 320, torch.device("cuda"), seed=3, num_boxes=4)
+        red.zero_grad()
+        loss, _ = model.parse_losses(model.forward_train(**batch))
+        loss.backward()
+        red.finish()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss)
+        bad = []
+        for n, p in model.named_parameters():
+            g = p.grad
+            if g is None or g.dtype != torch.float32 or not torch.isfinite(g).all() or float(g.abs().max()) == 0.0:
+                bad.append(n)
+        # the relative_position_index buffers are not parameters; every parameter takes part in the loss
+        assert not bad, f"parameters without a usable gradient: {bad[:10]} ({len(bad)} total)"
+    finally:
+        sh.release()

@@ -73,6 +73,18 @@ def conv():
         print(f"conv3x3 {N}x{H}x{W}x256->256: {med:8.1f} us  {fl / med / 1e6:7.1f} TFLOP/s")
 
 
+def gemm():
+    for (M, N, K) in [(128000, 256, 2304), (32000, 256, 2304), (128000, 384, 128), (128000, 256, 256)]:
+        a = torch.randn(M, K, device="cuda").bfloat16()
+        w = torch.randn(N, K, device="cuda").bfloat16() * 0.02
+        b = torch.zeros(N, device="cuda")
+        c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        med, _ = timeit(lambda: Fn.call("gemm_nt_bf16", Fn._p(a), Fn._p(w), Fn._p(b), Fn._p(c), M, N, K, 0, Fn._s()))
+        medt, _ = timeit(lambda: torch.nn.functional.linear(a, w))
+        fl = 2.0 * M * N * K
+        print(f"gemm_nt {M}x{N}x{K}: mine {med:8.1f} us {fl / med / 1e6:7.1f} TF   hipBLASLt {medt:8.1f} us {fl / medt / 1e6:7.1f} TF")
+
+
 def ln():
     for (H, W, C, nH) in STAGES:
         x = torch.randn(2 * H * W, C, device="cuda").bfloat16()
