@@ -156,10 +156,11 @@ int gemm_nt_bf16(const void* a, const void* w, const float* bias, void* c, int64
  *   wgrad_linear_bf16      : dw (N1,N2) f32 += dy (T,N1)^T x (T,N2)   -- autograd of nn.Linear
  *                            (swin_transformer.py:129,151,33,36,296); N1 % 8 == 0, N2 % 8 == 0
  *   wgrad_conv3x3_nhwc_bf16: dw (Cout,3,3,Cin) f32 += gradient of conv3x3_nhwc_bf16's weight (implicit im2col)
- * Both ACCUMULATE into dw (the caller zeroes it). */
-int wgrad_linear_bf16(const void* dy, const void* x, float* dw, int64_t T, int N1, int N2, void* stream);
-int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
-                            void* stream);
+ * dbias (N1 | Cout) f32 += column sums of dy (the bias gradient), NULL to skip.
+ * All outputs ACCUMULATE (the caller zeroes them, or passes the parameter's fp32 gradient buffer). */
+int wgrad_linear_bf16(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2, void* stream);
+int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W, int Cin,
+                            int Cout, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * mmcv.ops.RoIAlign / roi_align ('avg', aligned flag) -- call sites

@@ -117,8 +117,9 @@ class PatchEmbed(_Params):
 
 
 def _lin(x, weight, bias, dtype):
-    """Plain library GEMM (hipBLASLt through torch) on the compute-dtype copy of the fp32 master weight."""
-    return ops.linear(x, mixed.weight(weight, dtype), mixed.weight(bias, dtype))
+    """Linear on the compute-dtype copies of the fp32 master parameters (library GEMM forward / dgrad,
+    hand-written weight+bias gradient kernel)."""
+    return ops.linear(x, weight, bias, dtype)
 
 
 @BACKBONES.register_module()
@@ -241,7 +242,7 @@ class SwinTransformer(nn.Module):
         pe = self.patch_embed
         rows = ops.patch_im2row(x.float().contiguous(), dt)                              # :433-438
         Wh, Ww = (Hi + 3) // 4, (Wi + 3) // 4
-        t = ops.linear(rows, mixed.weight(pe.proj.weight, dt).view(self.embed_dim, 48), mixed.weight(pe.proj.bias, dt))
+        t = F.linear(rows, mixed.weight(pe.proj.weight, dt).view(self.embed_dim, 48), mixed.weight(pe.proj.bias, dt))
         if pe.norm is not None:
             t = ops.layer_norm(t, pe.norm.weight, pe.norm.bias)                          # :441-443
         t = t.view(B, Wh * Ww, self.embed_dim)

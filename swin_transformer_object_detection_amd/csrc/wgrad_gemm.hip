@@ -57,8 +57,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t0, int col0, in
 }
 
 template <typename XLoader>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ dy, XLoader X, float* __restrict__ dw, int64_t T,
-                                                       int N1, int N2, int64_t t_per_split, int use_atomic) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ dy, XLoader X, float* __restrict__ dw,
+                                                       float* __restrict__ dbias, int64_t T, int N1, int N2,
+                                                       int64_t t_per_split, int use_atomic) {
     __shared__ __attribute__((aligned(16))) bf16 lds[2][WT * WROW];        // [dY|X], single stage (40 KB -> 2 blocks/CU);
                                                                            // the next stage waits in registers
     const int n1_0 = blockIdx.y * WN, n2_0 = blockIdx.x * WN;
@@ -92,14 +93,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ 
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
+    // bias gradient = column sums of dY: taken by the n2-tile-0 blocks from the pieces they stage anyway
+    const bool do_bias = dbias != nullptr && blockIdx.x == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto bias_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 v = *(const bf16x8*)&ra[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
+        }
+    };
 
     if (t_begin < t_end) {
         gload(t_begin);
+        if (do_bias) bias_acc();
         lstore();
         __syncthreads();
         for (int64_t t0 = t_begin; t0 < t_end; t0 += WT) {
             const bool more = t0 + WT < t_end;
-            if (more) gload(t0 + WT);
+            if (more) { gload(t0 + WT); if (do_bias) bias_acc(); }
             const bf16* As = lds[0];
             const bf16* Bs = lds[1];
 #pragma unroll
@@ -121,6 +134,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ 
             __syncthreads();
         }
     }
+    if (do_bias) {           // 16 threads (srow) share a piece column: reduce through LDS, one atomic per channel
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(&lds[0][0]);          // [16 srow][128 cols]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[srow * WN + spiece * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < WN) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a += red[r * WN + tid];
+            if (n1_0 + tid < N1) atomicAdd(dbias + n1_0 + tid, a);
+        }
+    }
     // D[row n1][col n2]: lane = n2 column, registers = n1 rows -> 32 consecutive n2 per half-wave: 128-B segments
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -140,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ 
 }
 
 template <typename XLoader>
-static int wgrad_launch(const bf16* dy, XLoader X, float* dw, int64_t T, int N1, int N2, hipStream_t s) {
+static int wgrad_launch(const bf16* dy, XLoader X, float* dw, float* dbias, int64_t T, int N1, int N2, hipStream_t s) {
     int g1 = (N1 + WN - 1) / WN, g2 = (N2 + WN - 1) / WN;
     // enough splits to fill the chip (~2 blocks per CU), each split a multiple of the t-stage
     int64_t stages = (T + WT - 1) / WT;
@@ -151,24 +177,26 @@ static int wgrad_launch(const bf16* dy, XLoader X, float* dw, int64_t T, int N1,
     int64_t per = ((stages + splits - 1) / splits) * WT;
     splits = (int)((T + per - 1) / per);
     dim3 grid(g2, g1, splits);
-    wgrad_kernel<XLoader><<<grid, 256, 0, s>>>(dy, X, dw, T, N1, N2, per, 1);
+    wgrad_kernel<XLoader><<<grid, 256, 0, s>>>(dy, X, dw, dbias, T, N1, N2, per, 1);
     return swin_launch_status();
 }
 
-// dw (N1, N2) f32 += dy(T, N1)^T x(T, N2).   N1 % 8 == 0, N2 % 8 == 0.  ACCUMULATES (caller zeroes).
-extern "C" int wgrad_linear_bf16(const void* dy, const void* x, float* dw, int64_t T, int N1, int N2, void* stream) {
+// dw (N1, N2) f32 += dy(T, N1)^T x(T, N2);  dbias (N1) f32 += column sums of dy (NULL to skip).
+// N1 % 8 == 0, N2 % 8 == 0.  ACCUMULATES (caller zeroes).
+extern "C" int wgrad_linear_bf16(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2,
+                                 void* stream) {
     if (!dy || !x || !dw || T <= 0 || N1 <= 0 || N2 <= 0) return SWIN_ERR_BAD_ARG;
     if (N1 % 8 || N2 % 8) return SWIN_ERR_UNSUPPORTED;
     PlainX X{(const bf16*)x, T, N2};
-    return wgrad_launch((const bf16*)dy, X, dw, T, N1, N2, (hipStream_t)stream);
+    return wgrad_launch((const bf16*)dy, X, dw, dbias, T, N1, N2, (hipStream_t)stream);
 }
 
 // dw (Cout, 3, 3, Cin) f32 += conv-weight gradient; dy (N,H,W,Cout), x (N,H,W,Cin) bf16 channels-last.
-extern "C" int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
-                                       void* stream) {
+extern "C" int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W, int Cin,
+                                       int Cout, void* stream) {
     if (!dy || !x || !dw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SWIN_ERR_BAD_ARG;
     if (Cin % 8 || Cout % 8) return SWIN_ERR_UNSUPPORTED;
     int64_t T = (int64_t)N * H * W;
     ConvX X{(const bf16*)x, T, H, W, Cin};
-    return wgrad_launch((const bf16*)dy, X, dw, T, Cout, 9 * Cin, (hipStream_t)stream);
+    return wgrad_launch((const bf16*)dy, X, dw, dbias, T, Cout, 9 * Cin, (hipStream_t)stream);
 }

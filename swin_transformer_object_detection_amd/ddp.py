@@ -46,6 +46,14 @@ class BucketedGradReducer:
         for b in self.buckets:
             for leaf in b['leaves']:
                 self._hooks.append(leaf.register_post_accumulate_grad_hook(self._on_grad))
+        # gradient sinks: weight-gradient kernels may accumulate straight into the fp32 bucket views
+        from . import mixed
+        table = {}
+        for b in self.buckets:
+            for i, (p, v, leaf) in enumerate(zip(b['params'], b['views'], b['leaves'])):
+                table[id(p)] = (v, (lambda b=b, i=i: self._on_direct(b, i)))
+        mixed.register_sinks(table)
+        self._sink_ids = list(table)
 
     def _make_bucket(self, plist):
         n = sum(p.numel() for p in plist)
@@ -56,7 +64,8 @@ class BucketedGradReducer:
             off += p.numel()
         leaves = [self.leaf_of(p) for p in plist]
         b = dict(flat=flat, params=list(plist), leaves=leaves, views=views, pending=len(plist), handle=None,
-                 arrived=[False] * len(plist), index={id(l): i for i, l in enumerate(leaves)})
+                 arrived=[False] * len(plist), direct=[False] * len(plist),
+                 index={id(l): i for i, l in enumerate(leaves)})
         for l in leaves:
             self._l2b[id(l)] = b
         for p, v in zip(plist, views):
@@ -65,16 +74,19 @@ class BucketedGradReducer:
 
     def _gather(self, b):
         """fresh leaf gradients -> flat fp32 bucket (one multi-tensor copy; converts bf16 -> fp32)."""
-        src, dst = [], []
+        src, dst, asrc, adst = [], [], [], []
         for i, (leaf, p, v) in enumerate(zip(b['leaves'], b['params'], b['views'])):
-            if not b['arrived'][i]:
-                v.zero_()                                   # parameter got no gradient this step
-                continue
             g = leaf.grad
-            if g is not None and g.data_ptr() != v.data_ptr():
+            if g is None or g.data_ptr() == v.data_ptr():
+                continue                                    # nothing from autograd (view is zero or sink-written)
+            if b['direct'][i]:
+                asrc.append(g); adst.append(v)              # a kernel already accumulated into the view: add
+            else:
                 src.append(g); dst.append(v)
         if src:
             torch._foreach_copy_(dst, src)
+        for d_, s_ in zip(adst, asrc):
+            d_.add_(s_)
         for leaf, p, v in zip(b['leaves'], b['params'], b['views']):
             if leaf is not p:
                 leaf.grad = None
@@ -87,14 +99,21 @@ class BucketedGradReducer:
                 b['flat'].div_(self.world)
             b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def _on_grad(self, leaf):
-        b = self._l2b[id(leaf)]
-        i = b['index'][id(leaf)]
+    def _arrive(self, b, i):
         if not b['arrived'][i]:
             b['arrived'][i] = True
             b['pending'] -= 1
             if b['pending'] == 0:
                 self._launch(b)
+
+    def _on_grad(self, leaf):
+        b = self._l2b[id(leaf)]
+        self._arrive(b, b['index'][id(leaf)])
+
+    def _on_direct(self, b, i):
+        """A kernel accumulated parameter i's gradient straight into its bucket view (mixed.grad_sink)."""
+        b['direct'][i] = True
+        self._arrive(b, i)
 
     def finish(self):
         """Call after backward: handles buckets with parameters that got no gradient, waits for the collectives."""
@@ -107,12 +126,20 @@ class BucketedGradReducer:
                 b['handle'] = None
             b['pending'] = len(b['params'])
             b['arrived'] = [False] * len(b['params'])
+            b['direct'] = [False] * len(b['params'])
 
     def zero_grad(self):
-        """Before forward: drop the leaves' gradients (no fill kernels: the buckets are overwritten by _gather)."""
+        """Before forward: ONE memset per bucket (kernels accumulate into the views) and drop the leaves' grads."""
         for b in self.buckets:
+            b['flat'].zero_()
             for leaf in b['leaves']:
                 leaf.grad = None
+
+    def release(self):
+        from . import mixed
+        mixed.clear_sinks(self._sink_ids)
+        for h in self._hooks:
+            h.remove()
 
     def broadcast_parameters(self, src=0):
         """Initial parameter sync (DDP does the same at construction)."""

@@ -9,6 +9,26 @@ the autograd leaves (their bf16 gradients are gathered into the flat fp32 gradie
 import torch
 
 _SHADOW = {}          # id(master parameter) -> bf16 leaf tensor (a view of the flat shadow buffer)
+_SINK = {}            # id(master parameter) -> (fp32 gradient view in a flat bucket, notify())  -- set by ddp.py
+
+
+def grad_sink(p):
+    """Where a weight-gradient kernel may ACCUMULATE the fp32 gradient of master parameter ``p`` directly
+    (the flat all-reduce bucket), plus the callback that tells the reducer the gradient has arrived.
+    None when no reducer is active: the op then returns the gradient through autograd as usual."""
+    return None if p is None else _SINK.get(id(p))
+
+
+def register_sinks(table):
+    _SINK.update(table)
+
+
+def clear_sinks(ids=None):
+    if ids is None:
+        _SINK.clear()
+    else:
+        for i in ids:
+            _SINK.pop(i, None)
 
 
 def weight(p, dtype):

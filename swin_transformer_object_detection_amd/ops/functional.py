@@ -356,7 +356,7 @@ def _im2col3x3(x_cl):
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, bias_master=None):
         if x.dtype != torch.bfloat16 or not x.is_cuda:
             raise SwinHipError("conv3x3: bf16 GPU activations only (fp32 parity runs use the library conv)")
         x = x.contiguous(memory_format=torch.channels_last)
@@ -365,6 +365,7 @@ class _Conv3x3(torch.autograd.Function):
         y = _conv3x3_raw(x, w, b, relu)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.relu, ctx.has_bias = relu, bias is not None
+        ctx.bias_master = bias_master
         return y
 
     @staticmethod
@@ -380,57 +381,91 @@ class _Conv3x3(torch.autograd.Function):
             # dx = conv(dy, rot180(w) with in/out swapped): (Cin, 3, 3, Cout)
             wt = weight.to(torch.bfloat16).flip(2, 3).permute(1, 2, 3, 0).contiguous()
             dx = _conv3x3_raw(dy, wt, None, False)
-        if ctx.needs_input_grad[1]:
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or need_b:
+            from .. import mixed
             dwf = torch.zeros(Cout, 3, 3, Cin, device=x.device, dtype=torch.float32)
-            call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), N, H, W, Cin, Cout, _s())   # implicit im2col
-            dw = dwf.permute(0, 3, 1, 2).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.permute(0, 2, 3, 1).reshape(-1, Cout).sum(0, dtype=torch.float32)
-        return dx, dw, db, None
+            bs = mixed.grad_sink(ctx.bias_master) if need_b else None
+            dbf = None
+            if need_b:
+                dbf = bs[0] if bs is not None else torch.zeros(Cout, device=x.device, dtype=torch.float32)
+            call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), _p(dbf), N, H, W, Cin, Cout, _s())   # implicit im2col
+            if ctx.needs_input_grad[1]:
+                dw = dwf.permute(0, 3, 1, 2).to(weight.dtype)
+            if need_b:
+                if bs is not None:
+                    bs[1]()
+                else:
+                    db = dbf
+        return dx, dw, db, None, None
 
 
 def conv3x3(x, weight, bias=None, relu=False):
-    """3x3, padding 1, stride 1 conv of a logically-NCHW bf16 tensor (channels-last memory)."""
-    return _Conv3x3.apply(x, weight, bias, relu)
+    """3x3, padding 1, stride 1 conv of a logically-NCHW bf16 tensor (channels-last memory).  ``bias`` is the fp32
+    master parameter (its gradient may be accumulated straight into the reducer's bucket)."""
+    return _Conv3x3.apply(x, weight, bias, relu, bias)
 
 
 # --------------------------------------------------------------------------------------
 # Linear layer with the weight gradient on the split-T MFMA kernel
 # --------------------------------------------------------------------------------------
 class _LinearBf16(torch.autograd.Function):
-    """y = x w^T + b.  Forward / data gradient: library GEMM.  Weight gradient dW = dY^T X contracts over the
-    token index (up to 128 000 long, outputs a few hundred wide): the split-T kernel (wgrad_gemm.hip)."""
+    """y = x w^T + b.  Forward / data gradient: library GEMM.  Weight AND bias gradient: the split-T kernel
+    (wgrad_gemm.hip), accumulating in fp32 -- straight into the parameters' all-reduce buckets when a reducer
+    has registered gradient sinks (mixed.grad_sink), else into fresh buffers returned through autograd."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, w_master, b_master):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.masters = (w_master, b_master)
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
+        from .. import mixed
         x, w = ctx.saved_tensors
+        w_master, b_master = ctx.masters
         N1, N2 = w.shape
         dy2 = dy.reshape(-1, N1)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         x2 = x.reshape(-1, N2)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = (dy2 @ w).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            dwf = torch.zeros(N1, N2, device=x.device, dtype=torch.float32)
-            call("wgrad_linear_bf16", _p(dy2), _p(x2.contiguous()), _p(dwf), dy2.shape[0], N1, N2, _s())
-            dw = dwf.to(w.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0, dtype=torch.float32).to(dy.dtype)
-        return dx, dw, db
+        need_w = ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            ws, bs = mixed.grad_sink(w_master), mixed.grad_sink(b_master) if need_b else None
+            dwf = ws[0] if ws is not None else torch.zeros(N1, N2, device=x.device, dtype=torch.float32)
+            dbf = None
+            if need_b:
+                dbf = bs[0] if bs is not None else torch.zeros(N1, device=x.device, dtype=torch.float32)
+            call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2, _s())
+            if ws is not None:
+                ws[1]()
+            elif need_w:
+                dw = dwf.to(w.dtype)
+            if need_b:
+                if bs is not None:
+                    bs[1]()
+                else:
+                    db = dbf.to(dy.dtype)
+        return dx, dw, db, None, None
 
 
-def linear(x, w, b=None):
-    """nn.Linear forward on compute-dtype operands; bf16 GPU tensors with 8-aligned widths and a long token axis
-    use the hand-written weight-gradient kernel, anything else is the plain library path."""
-    if (x.dtype == torch.bfloat16 and x.is_cuda and w.dtype == torch.bfloat16 and w.shape[0] % 8 == 0
+def linear(x, weight, bias=None, dtype=None):
+    """nn.Linear on the compute-dtype copies of fp32 master parameters ``weight`` / ``bias`` (resolved through
+    mixed.weight).  bf16 GPU tensors with 8-aligned widths and a long token axis use the hand-written
+    weight/bias-gradient kernel; anything else is the plain library path."""
+    from .. import mixed
+    dtype = dtype or x.dtype
+    w = mixed.weight(weight, dtype)
+    b = mixed.weight(bias, dtype)
+    if (x.dtype == torch.bfloat16 and x.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[0] % 8 == 0
             and w.shape[1] % 8 == 0 and x.numel() // w.shape[1] >= 2048):
-        return _LinearBf16.apply(x, w, b)
+        return _LinearBf16.apply(x, w, b, weight, bias)
     return torch.nn.functional.linear(x, w, b)

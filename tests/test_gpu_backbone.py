@@ -204,3 +204,43 @@ def test_training_step_every_parameter_gets_gradient(pkg):
         assert not bad, f"parameters without a usable gradient: {bad[:10]} ({len(bad)} total)"
     finally:
         sh.release()
+
+
+def test_gradient_sinks_match_autograd(pkg):
+    """The weight/bias gradients that the split-T kernel accumulates straight into the reducer's fp32 buckets
+    (mixed.grad_sink) equal the ones plain autograd delivers without a reducer (same seeds, DropPath off)."""
+    from swin_transformer_object_detection_amd import data, ddp, detector, mixed, presets
+    cfg = presets.mask_rcnn_swin("tiny")
+    cfg["backbone"]["drop_path_rate"] = 0.0
+    torch.manual_seed(0)
+    model = detector.build_detector(cfg, compute_dtype=torch.bfloat16).cuda().train()
+    batch = data.synthetic_batch(1, 256, 320, torch.device("cuda"), seed=3, num_boxes=4)
+    names = ["backbone.layers.0.blocks.1.attn.qkv.weight", "backbone.layers.0.blocks.1.attn.qkv.bias",
+             "backbone.layers.1.blocks.0.mlp.fc1.weight", "backbone.layers.1.blocks.0.mlp.fc2.bias",
+             "backbone.layers.0.downsample.reduction.weight", "neck.fpn_convs.1.conv.bias", "neck.fpn_convs.1.conv.weight",
+             "rpn_head.rpn_conv.bias", "backbone.layers.2.blocks.3.attn.proj.weight"]
+    params = dict(model.named_parameters())
+    # (a) plain autograd
+    torch.manual_seed(123)
+    for p in model.parameters():
+        p.grad = None
+    loss, _ = model.parse_losses(model.forward_train(**batch))
+    loss.backward()
+    ref = {n: params[n].grad.detach().float().clone() for n in names}
+    # (b) shadows + reducer with sinks
+    sh = mixed.ShadowParams(model, torch.bfloat16)
+    red = ddp.BucketedGradReducer(model.parameters(), leaf_of=sh.leaf_of)
+    try:
+        torch.manual_seed(123)
+        red.zero_grad()
+        loss2, _ = model.parse_losses(model.forward_train(**batch))
+        loss2.backward()
+        red.finish()
+        assert abs(float(loss) - float(loss2)) < 2e-2 * max(1.0, abs(float(loss)))
+        for n in names:
+            g, r = params[n].grad.float(), ref[n]
+            tol = 0.03 * float(r.abs().max()) + 1e-6       # bf16 GEMM operands in both runs; fp32 vs bf16 accumulation
+            assert float((g - r).abs().max()) <= tol, (n, float((g - r).abs().max()), tol)
+    finally:
+        red.release()
+        sh.release()
