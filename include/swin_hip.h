@@ -109,8 +109,8 @@ int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int nH, void* st
  * ---------------------------------------------------------------------------------- */
 /* y = gelu_erf(x + bias)  (nn.GELU, swin_transformer.py:34; bias = fc1.bias, may be NULL). */
 int swin_bias_gelu_fwd(const void* x, const float* bias, void* y, int64_t rows, int C, int dtype, void* stream);
-/* dx = dy * gelu'(x + bias) */
-int swin_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, int64_t rows, int C,
+/* dx = dy * gelu'(x + bias);  dbias (C) f32 += column sums of dx (NULL to skip; ACCUMULATES) */
+int swin_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias, int64_t rows, int C,
                        int dtype, void* stream);
 
 /* PatchMerging gather + LayerNorm: swin_transformer.py:284-295.

@@ -23,7 +23,7 @@ SIGNATURES = {
     "swin_rel_bias_expand": [_p, _p, _i, _p],
     "swin_rel_bias_reduce": [_p, _p, _i, _p],
     "swin_bias_gelu_fwd": [_p, _p, _p, _i64, _i, _i, _p],
-    "swin_bias_gelu_bwd": [_p, _p, _p, _p, _i64, _i, _i, _p],
+    "swin_bias_gelu_bwd": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
     "swin_patch_merge_ln_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
     "swin_patch_merge_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "swin_patch_im2row": [_p, _p, _i, _i, _i, _i, _p],

@@ -17,9 +17,17 @@ __device__ __forceinline__ float gelu_grad_f(float v) {
 
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void bias_gelu_kernel(const T* __restrict__ x, const float* __restrict__ bias,
-                                                        const T* __restrict__ dy, T* __restrict__ out, int64_t nvec,
-                                                        int vec_per_row) {
+                                                        const T* __restrict__ dy, T* __restrict__ out, float* __restrict__ dbias,
+                                                        int64_t nvec, int vec_per_row) {
+    // backward with dbias: a block walks rows with a fixed column slot per thread (256 % vec_per_row == 0 or the
+    // generic LDS-atomic path), accumulates its column sums in LDS and issues one global atomic per channel.
     constexpr int VEC = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float colsum[];       // vec_per_row * VEC floats (BWD && dbias)
+    const bool want_db = BWD && dbias != nullptr;
+    if (want_db) {
+        for (int i = threadIdx.x; i < vec_per_row * VEC; i += 256) colsum[i] = 0.f;
+        __syncthreads();
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         int col = (int)(i % vec_per_row) * VEC;
         Vec16<T> v, o, g;
@@ -28,37 +36,47 @@ __global__ __launch_bounds__(256) void bias_gelu_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             float a = v.get(e) + (bias ? bias[col + e] : 0.f);
-            o.set(e, BWD ? g.get(e) * gelu_grad_f(a) : gelu_f(a));
+            float r = BWD ? g.get(e) * gelu_grad_f(a) : gelu_f(a);
+            o.set(e, r);
+            if (want_db) atomicAdd(&colsum[col + e], r);
         }
         o.store(out + i * VEC);
+    }
+    if (want_db) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < vec_per_row * VEC; i += 256) atomicAdd(dbias + i, colsum[i]);
     }
 }
 
 template <bool BWD>
-static int bias_gelu_launch(const void* x, const float* bias, const void* dy, void* out, int64_t rows, int C, int dtype,
-                            void* stream) {
+static int bias_gelu_launch(const void* x, const float* bias, const void* dy, void* out, float* dbias, int64_t rows, int C,
+                            int dtype, void* stream) {
     if (!x || !out || rows <= 0 || C <= 0 || (BWD && !dy)) return SWIN_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    size_t shm = (BWD && dbias) ? (size_t)C * sizeof(float) : 0;
+    if (shm > 60000) return SWIN_ERR_UNSUPPORTED;
     if (dtype == SWIN_BF16) {
         if (C % 8) return SWIN_ERR_UNSUPPORTED;
         int64_t nvec = rows * (C / 8);
-        bias_gelu_kernel<bf16, BWD><<<ew_blocks(nvec), 256, 0, s>>>((const bf16*)x, bias, (const bf16*)dy, (bf16*)out, nvec,
-                                                                   C / 8);
+        int blocks = dbias ? (ew_blocks(nvec) < 1024 ? ew_blocks(nvec) : 1024) : ew_blocks(nvec);
+        bias_gelu_kernel<bf16, BWD><<<blocks, 256, shm, s>>>((const bf16*)x, bias, (const bf16*)dy, (bf16*)out, dbias, nvec,
+                                                            C / 8);
     } else if (dtype == SWIN_F32) {
         if (C % 4) return SWIN_ERR_UNSUPPORTED;
         int64_t nvec = rows * (C / 4);
-        bias_gelu_kernel<float, BWD><<<ew_blocks(nvec), 256, 0, s>>>((const float*)x, bias, (const float*)dy, (float*)out,
-                                                                    nvec, C / 4);
+        int blocks = dbias ? (ew_blocks(nvec) < 1024 ? ew_blocks(nvec) : 1024) : ew_blocks(nvec);
+        bias_gelu_kernel<float, BWD><<<blocks, 256, shm, s>>>((const float*)x, bias, (const float*)dy, (float*)out, dbias,
+                                                              nvec, C / 4);
     } else return SWIN_ERR_UNSUPPORTED;
     return swin_launch_status();
 }
 
 extern "C" int swin_bias_gelu_fwd(const void* x, const float* bias, void* y, int64_t rows, int C, int dtype, void* stream) {
-    return bias_gelu_launch<false>(x, bias, nullptr, y, rows, C, dtype, stream);
+    return bias_gelu_launch<false>(x, bias, nullptr, y, nullptr, rows, C, dtype, stream);
 }
-extern "C" int swin_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, int64_t rows, int C,
-                                  int dtype, void* stream) {
-    return bias_gelu_launch<true>(x, bias, dy, dx, rows, C, dtype, stream);
+extern "C" int swin_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias, int64_t rows,
+                                  int C, int dtype, void* stream) {
+    return bias_gelu_launch<true>(x, bias, dy, dx, dbias, rows, C, dtype, stream);
 }
 
 // ---------------------------------------------------------------- PatchEmbed im2row (k=4, s=4, 3 channels)

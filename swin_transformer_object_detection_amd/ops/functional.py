@@ -47,6 +47,20 @@ def _f32(t):
     return t
 
 
+def _grad_buf(param):
+    """(fp32 buffer a kernel ACCUMULATES param's gradient into, value to return through autograd, notify()).
+
+    With a reducer active (mixed.grad_sink) the buffer is the parameter's slice of the flat all-reduce bucket
+    (zeroed once per step), autograd gets None and notify() tells the reducer; otherwise a fresh zero tensor
+    that is returned to autograd."""
+    from .. import mixed
+    s = mixed.grad_sink(param)
+    if s is not None:
+        return s[0], None, s[1]
+    z = torch.zeros_like(param, dtype=torch.float32)
+    return z, z, (lambda: None)
+
+
 # --------------------------------------------------------------------------------------
 # LayerNorm
 # --------------------------------------------------------------------------------------
@@ -61,6 +75,7 @@ class _LayerNorm(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         call("swin_layernorm_fwd", _p(x), _p(_f32(w)), _p(_f32(b)), _p(y), _p(mean), _p(rstd), rows, C, eps, _dt(x), _s())
         ctx.save_for_backward(x, w, mean, rstd)
+        ctx.bias = b
         return y
 
     @staticmethod
@@ -70,10 +85,11 @@ class _LayerNorm(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(w)
+        dwb, dw, nw = _grad_buf(w)
+        dbb, db, nb = _grad_buf(ctx.bias)
         call("swin_layernorm_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), None, _p(dx), None, None, 1,
-             _p(dw), _p(db), rows, C, _dt(x), _s())
+             _p(dwb), _p(dbb), rows, C, _dt(x), _s())
+        nw(); nb()
         return dx, dw, db, None
 
 
@@ -97,6 +113,7 @@ class _AddLayerNorm(torch.autograd.Function):
              _p(mean), _p(rstd), rows, C, eps, _dt(x), _s())
         ctx.save_for_backward(xo, w, mean, rstd, scale)
         ctx.rps = rows_per_sample
+        ctx.bias = b
         return xo, n
 
     @staticmethod
@@ -108,10 +125,11 @@ class _AddLayerNorm(torch.autograd.Function):
         dxo = None if dxo is None else dxo.contiguous()
         dx = torch.empty_like(xo)
         dyb = torch.empty_like(xo) if scale is not None else None
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(w)
+        dwb, dw, nw = _grad_buf(w)
+        dbb, db, nb = _grad_buf(ctx.bias)
         call("swin_layernorm_bwd", _p(dn), _p(xo), _p(w), _p(mean), _p(rstd), _p(dxo), _p(dx), _p(dyb), _p(scale),
-             ctx.rps, _p(dw), _p(db), rows, C, _dt(xo), _s())
+             ctx.rps, _p(dwb), _p(dbb), rows, C, _dt(xo), _s())
+        nw(); nb()
         return dx, (dyb if scale is not None else dx), None, None, dw, db, None
 
 
@@ -174,6 +192,7 @@ class _WindowAttention(torch.autograd.Function):
              _dt(qkv), _s())
         ctx.save_for_backward(qkv, qkv_bias, bias_exp, lse)
         ctx.geom = (B, H, W, C, nH, shift, scale)
+        ctx.table = table
         return out
 
     @staticmethod
@@ -183,13 +202,16 @@ class _WindowAttention(torch.autograd.Function):
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         dbexp = torch.zeros_like(bias_exp)
-        dpad = torch.zeros(3 * C, device=qkv.device, dtype=torch.float32)
+        padded = (H % 7 != 0) or (W % 7 != 0)
+        dpb, dpad, npad = _grad_buf(qkv_bias) if padded else (None, None, lambda: None)
         ws_bytes = _lib.lib().swin_window_attn_bwd_workspace_bytes(B, H, W, nH, _dt(qkv))
         ws = torch.empty(max(ws_bytes, 16), device=qkv.device, dtype=torch.uint8)
-        call("swin_window_attn_bwd", _p(qkv), _p(qkv_bias), _p(bias_exp), _p(lse), _p(dout), _p(dqkv), _p(dbexp), _p(dpad),
+        call("swin_window_attn_bwd", _p(qkv), _p(qkv_bias), _p(bias_exp), _p(lse), _p(dout), _p(dqkv), _p(dbexp), _p(dpb),
              _p(ws), B, H, W, C, nH, shift, scale, _dt(qkv), _s())
-        dtable = torch.zeros(169, nH, device=qkv.device, dtype=torch.float32)
-        call("swin_rel_bias_reduce", _p(dbexp), _p(dtable), nH, _s())
+        dtb, dtable, nt = _grad_buf(ctx.table)
+        call("swin_rel_bias_reduce", _p(dbexp), _p(dtb), nH, _s())
+        nt()
+        # qkv.bias also receives a gradient from the qkv Linear: its arrival is signalled there, not here
         return dqkv, dpad, dtable, None, None, None, None, None
 
 
@@ -221,10 +243,9 @@ class _BiasGelu(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C
         dx = torch.empty_like(x)
-        call("swin_bias_gelu_bwd", _p(dy), _p(x), _p(bias), _p(dx), rows, C, _dt(x), _s())
-        dbias = None
-        if bias is not None:
-            dbias = dx.reshape(rows, C).sum(0, dtype=torch.float32)
+        dbb, dbias, nb = _grad_buf(bias) if bias is not None else (None, None, lambda: None)
+        call("swin_bias_gelu_bwd", _p(dy), _p(x), _p(bias), _p(dx), _p(dbb), rows, C, _dt(x), _s())
+        nb()
         return dx, dbias
 
 
@@ -248,6 +269,7 @@ class _PatchMergeLN(torch.autograd.Function):
              _dt(x), _s())
         ctx.save_for_backward(x, w, mean, rstd)
         ctx.geom = (B, H, W, C)
+        ctx.bias = b
         return y
 
     @staticmethod
@@ -256,10 +278,11 @@ class _PatchMergeLN(torch.autograd.Function):
         B, H, W, C = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(w)
-        call("swin_patch_merge_ln_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db), B, H, W, C,
+        dwb, dw, nw = _grad_buf(w)
+        dbb, db, nb = _grad_buf(ctx.bias)
+        call("swin_patch_merge_ln_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dwb), _p(dbb), B, H, W, C,
              _dt(x), _s())
+        nw(); nb()
         return dx, dw, db, None, None, None, None
 
 

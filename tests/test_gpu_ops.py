@@ -102,20 +102,24 @@ def test_window_attention_fwd_bwd(ops, B, H, W, nH, shift, dtype):
     assert out.shape == (B, H * W, C) and out.dtype == dtype
     (out.float() * dev(wgt)).sum().backward()
     torch.cuda.synchronize()
+    padded = H % 7 != 0 or W % 7 != 0
+    if not padded:        # no padded token exists: qkv.bias gets no gradient from the attention op
+        assert b1.grad is None or float(b1.grad.abs().max()) == 0.0
+        assert float(b0.grad.abs().max()) == 0.0
     if dtype == torch.float32:
         close(out, ref, ATOL32, msg="out")
         close(q1.grad, q0.grad, ATOL32, 1e-4, msg="dqkv")
-        close(b1.grad, b0.grad, 2e-4, 1e-4, msg="dqkv_bias(pad)")
+        if padded:
+            close(b1.grad, b0.grad, 2e-4, 1e-4, msg="dqkv_bias(pad)")
         close(t1.grad, t0.grad, 5e-4, 1e-4, msg="dtable")
     else:
         # bf16 storage of P (8 bits) and of the outputs: 4 ulps of the output scale; the table
         # gradient sums B*nW window contributions -> scale the tolerance with its own magnitude
         close(out, ref, bf16_tol(ref), msg="out")
         close(q1.grad, q0.grad, bf16_tol(q0.grad, 6), msg="dqkv")
-        close(b1.grad, b0.grad, bf16_tol(b0.grad, 8) + 1e-3, msg="dqkv_bias(pad)")
+        if padded:
+            close(b1.grad, b0.grad, bf16_tol(b0.grad, 8) + 1e-3, msg="dqkv_bias(pad)")
         close(t1.grad, t0.grad, bf16_tol(t0.grad, 8), msg="dtable")
-    if H % 7 == 0 and W % 7 == 0:
-        assert float(b1.grad.abs().max()) == 0.0
 
 
 def test_window_attention_rejects_bad_shapes(ops):
