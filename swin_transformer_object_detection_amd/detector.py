@@ -138,9 +138,10 @@ def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou, mat
     overlaps = bbox_overlaps(gt_bboxes, bboxes)
     max_ov, argmax = overlaps.max(dim=0)
     gt_max, _ = overlaps.max(dim=1)
-    assigned[(max_ov >= 0) & (max_ov < neg_iou_thr)] = 0
-    pos = max_ov >= pos_iou_thr
-    assigned[pos] = argmax[pos] + 1
+    # masked writes as torch.where: boolean-mask assignment would cost a device->host sync each
+    zero = torch.zeros_like(assigned)
+    assigned = torch.where((max_ov >= 0) & (max_ov < neg_iou_thr), zero, assigned)
+    assigned = torch.where(max_ov >= pos_iou_thr, argmax + 1, assigned)
     if match_low_quality:
         # later gts override earlier ones, as the reference's python loop does: take the LAST gt whose
         # row attains its own maximum at this box
@@ -150,9 +151,7 @@ def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou, mat
         assigned = torch.where(last > 0, last, assigned)
     labels = None
     if gt_labels is not None:
-        labels = assigned.new_full((n,), -1)
-        p = assigned > 0
-        labels[p] = gt_labels[assigned[p] - 1]
+        labels = torch.where(assigned > 0, gt_labels[(assigned - 1).clamp(min=0)], assigned.new_full((n,), -1))
     return assigned, max_ov, labels
 
 
