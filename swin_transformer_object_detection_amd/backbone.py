@@ -150,6 +150,7 @@ class SwinTransformer(nn.Module):
         self.out_indices, self.frozen_stages = out_indices, frozen_stages
         self.compute_dtype = compute_dtype
         self._dp_replay = None
+        self._dp_pool = []
         self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, patch_norm)
         if ape:
             pis, ps = _to_2tuple(pretrain_img_size), _to_2tuple(patch_size)
@@ -212,8 +213,27 @@ class SwinTransformer(nn.Module):
         if self._dp_replay is not None:          # tests replay the factors a reference run drew
             f = self._dp_replay.pop(0)
             return None if f is None else f.to(device=device, dtype=torch.float32)
+        if self._dp_pool:                        # all draws of this forward were made by ONE rand kernel
+            return self._dp_pool.pop(0)
         keep = 1.0 - p
         return torch.floor(keep + torch.rand(B, device=device, dtype=torch.float32)) / keep
+
+    def _draw_drop_paths(self, B, device):
+        """Every DropPath factor of this forward in three kernels instead of four per draw: rows of a (n_draws, B)
+        uniform tensor, in the order the blocks consume them (two per block, swin_transformer.py:252-253)."""
+        self._dp_pool = []
+        if self._dp_replay is not None or not self.training:
+            return
+        probs = []
+        for layer in self.layers:
+            for blk in layer.blocks:
+                if blk.drop_path_prob > 0. and blk.training:
+                    probs += [blk.drop_path_prob, blk.drop_path_prob]
+        if not probs:
+            return
+        keep = 1.0 - torch.tensor(probs, device=device, dtype=torch.float32)[:, None]
+        f = torch.floor(keep + torch.rand(len(probs), B, device=device, dtype=torch.float32)) / keep
+        self._dp_pool = list(f.unbind(0))
 
     def _block(self, x, n1, blk, B, H, W, next_norm, dp):
         """x: residual stream (B,L,C); n1 = norm1(x) already computed.  Returns (x_out, n_next) where
@@ -239,6 +259,7 @@ class SwinTransformer(nn.Module):
         token-major buffers are returned as permuted views, no NCHW copy -- cf. :622)."""
         dt = self.compute_dtype
         B, _, Hi, Wi = x.shape
+        self._draw_drop_paths(B, x.device)
         pe = self.patch_embed
         rows = ops.patch_im2row(x.float().contiguous(), dt)                              # :433-438
         Wh, Ww = (Hi + 3) // 4, (Wi + 3) // 4

@@ -6,9 +6,12 @@
 // is the (Cout, ky, kx, Cin) weight, i.e. the channels_last memory of the (Cout,Cin,3,3) parameter.
 //
 // Tile 128(m) x 128(n) x 64(k), 256 threads = 2x2 waves of 64x64, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
-// LDS: two K-tiles (A 16 KB + W 16 KB each), 16-byte pieces XOR-swizzled by (row & 7) so the
-// ds_read_b128 fragment reads are bank-conflict free; global->register->LDS staging with the next tile's
-// loads issued before the MFMAs of the current one (one barrier per K-tile).
+// LDS: two K-tiles (A 16 KB + W 16 KB each) filled by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no
+// ds_write traffic -- register staging left the kernel bound by the VGPR->LDS write path at ~500 TFLOP/s); a wave
+// instruction writes 1 KiB = 8 rows x 128 B linearly, so the 16-byte pieces are XOR-swizzled on the SOURCE
+// address (slot = piece ^ ((row >> 1) & 7)) and the same XOR is applied by the ds_read_b128 fragment reads, which
+// makes them bank-conflict free; the DMA of tile k+1 is in flight while tile k feeds the MFMAs (one barrier per
+// K-tile); zero padding (conv borders, M/N tails) is read from a 16-byte zero buffer.
 // The weight tile is the MFMA "A" operand and the pixel tile the "B" operand, so a lane owns one pixel
 // and 4 consecutive output channels per accumulator group -> 8-byte stores into the NHWC output row.
 #include "common.h"
@@ -53,7 +56,9 @@ __device__ __forceinline__ uint4 masked_load16(const bf16* p, int64_t off) {
     return v;
 }
 
-__device__ __forceinline__ int swz(int row, int piece) { return piece ^ (row & 7); }
+__device__ __forceinline__ int swz(int row, int piece) { return piece ^ ((row >> 1) & 7); }
+
+__device__ uint4 g_zero16[4];      // zero-initialised: source of padded 16-byte pieces
 
 template <typename ALoader, bool RELU>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
@@ -73,35 +78,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
     const int wm = wave >> 1, wn = wave & 1;
     const int c = lane & 31, h = lane >> 5;
 
-    // staging role: 4 rows (tid/8 + 32 i), piece tid%8, for both operands
-    const int srow = tid >> 3, spiece = tid & 7;
-    int64_t abase[4]; int ay[4], ax[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) A.prep(m0 + srow + 32 * i, abase[i], ay[i], ax[i]);
-    int64_t woff[4];
+    // DMA role: wave w fills rows [32w, 32w+32) of both operand tiles, 8 rows x 8 slots per instruction
+    const int drow = 32 * wave + (lane >> 3), dslot = lane & 7;
+    int64_t abase[4]; int ay[4], ax[4]; int64_t woff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int n = n0 + srow + 32 * i;
-        woff[i] = n < Nn ? (int64_t)n * K + spiece * 8 : -1;
+        A.prep(m0 + drow + 8 * i, abase[i], ay[i], ax[i]);
+        int n = n0 + drow + 8 * i;
+        woff[i] = n < Nn ? (int64_t)n * K : -1;
     }
     const int nk = K / BK;
-    // two register stages: while tile kt is consumed from LDS, tile kt+1 sits in one register set (landed or
-    // landing) and the loads of tile kt+2 are issued into the other, so ~2 tiles of MFMA work cover the L2/HBM
-    // latency (with one stage the waves sat on s_waitcnt 65 % of the time: profiles/r01_pmc_conv_v1.txt)
-    uint4 ra0[4], rw0[4], ra1[4], rw1[4];
-    auto gload = [&](int kt, uint4 (&ra)[4], uint4 (&rw)[4]) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const bf16* zero = reinterpret_cast<const bf16*>(g_zero16);
+    auto dma_tile = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = masked_load16(A.a, A.offset(abase[i], ay[i], ax[i], kt, spiece));
-            rw[i] = masked_load16(Wt, woff[i] < 0 ? -1 : woff[i] + kt * BK);
-        }
-    };
-    auto lstore = [&](int buf, const uint4 (&ra)[4], const uint4 (&rw)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int row = srow + 32 * i;
-            lds[buf][0][row * 8 + swz(row, spiece)] = ra[i];
-            lds[buf][1][row * 8 + swz(row, spiece)] = rw[i];
+            const int row = drow + 8 * i;
+            const int piece = dslot ^ ((row >> 1) & 7);            // slot s of LDS row holds piece s ^ f(row)
+            int64_t ao = A.offset(abase[i], ay[i], ax[i], kt, piece);
+            const bf16* asrc = ao >= 0 ? A.a + ao : zero;
+            const bf16* wsrc = woff[i] >= 0 ? Wt + woff[i] + kt * BK + piece * 8 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)asrc, (lptr_t)&lds[buf][0][(32 * wave + 8 * i) * 8], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)&lds[buf][1][(32 * wave + 8 * i) * 8], 16, 0, 0);
         }
     };
     f32x16 acc[2][2];
@@ -131,21 +130,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
         }
     };
 
-    gload(0, ra0, rw0);
-    if (nk > 1) gload(1, ra1, rw1);
-    lstore(0, ra0, rw0);
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // top of an (even) iteration: LDS[0] = tile kt, register set 1 = tile kt+1, register set 0 free
-    for (int kt = 0; kt < nk; kt += 2) {
-        if (kt + 2 < nk) gload(kt + 2, ra0, rw0);
-        compute(0);
-        if (kt + 1 < nk) lstore(1, ra1, rw1);
-        __syncthreads();
-        if (kt + 1 >= nk) break;
-        if (kt + 3 < nk) gload(kt + 3, ra1, rw1);
-        compute(1);
-        if (kt + 2 < nk) lstore(0, ra0, rw0);
-        __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);       // lands while this tile feeds the MFMAs
+        compute(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt+1 have landed
+        __syncthreads();                                   // ... and everyone's; all reads of tile kt are done
+        cur ^= 1;
     }
 
     // epilogue: lane = pixel m, registers = output channels
