@@ -85,6 +85,25 @@ def gemm():
         print(f"gemm_nt {M}x{N}x{K}: mine {med:8.1f} us {fl / med / 1e6:7.1f} TF   hipBLASLt {medt:8.1f} us {fl / medt / 1e6:7.1f} TF")
 
 
+def wgrad():
+    for (T, N1, N2) in [(128000, 288, 96), (128000, 384, 96), (128000, 96, 384), (32000, 768, 192), (8000, 1536, 384)]:
+        dy = torch.randn(T, N1, device="cuda").bfloat16()
+        x = torch.randn(T, N2, device="cuda").bfloat16()
+        dw = torch.zeros(N1, N2, device="cuda")
+        db = torch.zeros(N1, device="cuda")
+        med, _ = timeit(lambda: Fn.call("wgrad_linear_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), T, N1, N2, Fn._s()))
+        medt, _ = timeit(lambda: dy.t() @ x)
+        print(f"wgrad_linear T={T} {N1}x{N2}: mine {med:7.1f} us ({(dy.numel() + x.numel()) * 2 / med / 1e3:7.1f} GB/s)   hipBLASLt {medt:7.1f} us")
+    for (N, H, W) in [(2, 200, 320), (2, 100, 160), (2, 50, 80), (200, 14, 14)]:
+        dy = torch.randn(N, H, W, 256, device="cuda").bfloat16()
+        x = torch.randn(N, H, W, 256, device="cuda").bfloat16()
+        dw = torch.zeros(256, 3, 3, 256, device="cuda")
+        db = torch.zeros(256, device="cuda")
+        med, _ = timeit(lambda: Fn.call("wgrad_conv3x3_nhwc_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), N, H, W, 256, 256, Fn._s()))
+        fl = 2.0 * N * H * W * 256 * 256 * 9
+        print(f"wgrad_conv {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
+
+
 def ln():
     for (H, W, C, nH) in STAGES:
         x = torch.randn(2 * H * W, C, device="cuda").bfloat16()
