@@ -140,11 +140,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal switch (development only): run all ranks on cuda:0 over gloo to exercise the N>1 code path on a
+    # one-GPU box.  The driver's multi-GPU runs use one GPU per rank over RCCL ("nccl").
+    rehearsal = os.environ.get("BENCH_REHEARSAL_GLOO") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from swin_transformer_object_detection_amd import data, ddp, detector, presets
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
