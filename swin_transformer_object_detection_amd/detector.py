@@ -180,7 +180,7 @@ def _conv(x, conv, dtype, padding=0, relu=False):
     N, C, H, W = x.shape
     if conv.kernel_size == (1, 1):
         tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
-        y = F.linear(tok, _cast(conv.weight, dtype).view(conv.out_channels, C), _cast(conv.bias, dtype))
+        y = ops.linear(tok, conv.weight, conv.bias, dtype)           # weight/bias gradients on the split-T kernel
         y = y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
     elif dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and padding == 1 and C % 64 == 0:
         return ops.conv3x3(x, _cast(conv.weight, dtype), conv.bias, relu)  # HIP implicit-GEMM kernel (ReLU fused)
@@ -224,10 +224,24 @@ class RPNHead(nn.Module):
     def forward(self, feats):                                   # rpn_head.py:41-47
         dt = self.compute_dtype
         cls, reg = [], []
+        A = self.num_anchors
+        if dt == torch.bfloat16:
+            # rpn_cls (A) and rpn_reg (4A) as ONE GEMM over the tokens, rows padded to a multiple of 8 for the kernels
+            C = self.rpn_cls.in_channels
+            pad = (-5 * A) % 8
+            w = torch.cat([_cast(self.rpn_cls.weight, dt).view(A, C), _cast(self.rpn_reg.weight, dt).view(4 * A, C),
+                           torch.zeros(pad, C, device=self.rpn_cls.weight.device, dtype=dt)], 0)
+            b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias, torch.zeros(pad, device=w.device)], 0).to(dt)
         for x in feats:
             x = _conv(x, self.rpn_conv, dt, padding=1, relu=True)
-            cls.append(_conv(x, self.rpn_cls, dt))
-            reg.append(_conv(x, self.rpn_reg, dt))
+            if dt == torch.bfloat16:
+                N, C, H, W = x.shape
+                y = ops.linear(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w, b, dt).view(N, H, W, -1)
+                cls.append(y[..., :A].permute(0, 3, 1, 2))
+                reg.append(y[..., A:5 * A].permute(0, 3, 1, 2))
+            else:
+                cls.append(_conv(x, self.rpn_cls, dt))
+                reg.append(_conv(x, self.rpn_reg, dt))
         return cls, reg
 
     # ---- training targets + loss (anchor_head.py:175-493) ----
@@ -445,7 +459,7 @@ class FCNMaskHead(nn.Module):
         tok = x.permute(0, 2, 3, 1).reshape(P * H * W, C)
         w = _cast(self.upsample.weight, dt).permute(2, 3, 1, 0).reshape(4 * Co, C)     # rows (ky,kx,co)
         b = _cast(self.upsample.bias, dt).repeat(4)
-        y = F.relu(F.linear(tok, w, b), inplace=True)                                  # (P*H*W, 4*Co)
+        y = F.relu(ops.linear(tok, w, b, dt), inplace=True)                            # (P*H*W, 4*Co)
         y = y.view(P, H, W, 2, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(P, 2 * H, 2 * W, Co)
         return y.permute(0, 3, 1, 2)                                                   # channels-last view
 

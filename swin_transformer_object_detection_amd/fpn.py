@@ -78,7 +78,7 @@ class FPN(nn.Module):
             x = _to_cl(x, dt)
             N, C, H, W = x.shape
             tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
-            y = F.linear(tok, self._w(lc.conv.weight).view(self.out_channels, C), self._w(lc.conv.bias))
+            y = ops.linear(tok, lc.conv.weight, lc.conv.bias, dt)       # (Cout,Cin,1,1) weight == (Cout,Cin) GEMM operand
             laterals.append(y.view(N, H, W, self.out_channels).permute(0, 3, 1, 2))
         for i in range(len(laterals) - 1, 0, -1):               # fpn.py:182-191
             laterals[i - 1] = ops.upsample_add(laterals[i - 1], laterals[i])

@@ -463,7 +463,9 @@ class _LinearBf16(torch.autograd.Function):
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
             ws, bs = mixed.grad_sink(w_master), mixed.grad_sink(b_master) if need_b else None
-            dwf = ws[0] if ws is not None else torch.zeros(N1, N2, device=x.device, dtype=torch.float32)
+            if ws is not None and (ws[0].numel() != N1 * N2 or not ws[0].is_contiguous()):
+                ws = None                                  # a derived weight (e.g. concatenated heads): no direct sink
+            dwf = ws[0].view(N1, N2) if ws is not None else torch.zeros(N1, N2, device=x.device, dtype=torch.float32)
             dbf = None
             if need_b:
                 dbf = bs[0] if bs is not None else torch.zeros(N1, device=x.device, dtype=torch.float32)
@@ -471,7 +473,7 @@ class _LinearBf16(torch.autograd.Function):
             if ws is not None:
                 ws[1]()
             elif need_w:
-                dw = dwf.to(w.dtype)
+                dw = dwf.to(w.dtype).view(w.shape)
             if need_b:
                 if bs is not None:
                     bs[1]()
@@ -488,6 +490,8 @@ def linear(x, weight, bias=None, dtype=None):
     dtype = dtype or x.dtype
     w = mixed.weight(weight, dtype)
     b = mixed.weight(bias, dtype)
+    if w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1:        # 1x1 conv weight (Cout,Cin,1,1)
+        w = w.view(w.shape[0], w.shape[1])
     if (x.dtype == torch.bfloat16 and x.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[0] % 8 == 0
             and w.shape[1] % 8 == 0 and x.numel() // w.shape[1] >= 2048):
         return _LinearBf16.apply(x, w, b, weight, bias)
