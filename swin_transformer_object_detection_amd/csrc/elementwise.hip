@@ -19,33 +19,51 @@ template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void bias_gelu_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                         const T* __restrict__ dy, T* __restrict__ out, float* __restrict__ dbias,
                                                         int64_t nvec, int vec_per_row) {
-    // backward with dbias: a block walks rows with a fixed column slot per thread (256 % vec_per_row == 0 or the
-    // generic LDS-atomic path), accumulates its column sums in LDS and issues one global atomic per channel.
+    // The host sizes the grid so that (gridDim.x * 256) % vec_per_row == 0: a thread then visits ONE column slot
+    // on every row, so the bias (forward/backward) and the bias-gradient partial sums (backward) live in registers;
+    // the block combines them in LDS and issues one global atomic per channel.
     constexpr int VEC = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float colsum[];       // vec_per_row * VEC floats (BWD && dbias)
     const bool want_db = BWD && dbias != nullptr;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int col = (int)(i0 % vec_per_row) * VEC;
+    float bv[VEC], acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { bv[e] = bias ? bias[col + e] : 0.f; acc[e] = 0.f; }
     if (want_db) {
         for (int i = threadIdx.x; i < vec_per_row * VEC; i += 256) colsum[i] = 0.f;
         __syncthreads();
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-        int col = (int)(i % vec_per_row) * VEC;
+    for (int64_t i = i0; i < nvec; i += (int64_t)gridDim.x * 256) {
         Vec16<T> v, o, g;
         v.load(x + i * VEC);
         if (BWD) g.load(dy + i * VEC);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float a = v.get(e) + (bias ? bias[col + e] : 0.f);
+            float a = v.get(e) + bv[e];
             float r = BWD ? g.get(e) * gelu_grad_f(a) : gelu_f(a);
             o.set(e, r);
-            if (want_db) atomicAdd(&colsum[col + e], r);
+            if (BWD) acc[e] += r;
         }
         o.store(out + i * VEC);
     }
     if (want_db) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) atomicAdd(&colsum[col + e], acc[e]);
         __syncthreads();
         for (int i = threadIdx.x; i < vec_per_row * VEC; i += 256) atomicAdd(dbias + i, colsum[i]);
     }
+}
+
+static inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// grid with (blocks * 256) % vec_per_row == 0, about 2048 blocks at most
+static int bias_gelu_blocks(int64_t nvec, int vpr) {
+    int unit = vpr / gcd_i(256, vpr);
+    int64_t want = (nvec + 255) / 256;
+    if (want > 2048) want = 2048;
+    int64_t b = (want + unit - 1) / unit * unit;
+    return (int)(b > 0 ? b : unit);
 }
 
 template <bool BWD>
@@ -58,13 +76,13 @@ static int bias_gelu_launch(const void* x, const float* bias, const void* dy, vo
     if (dtype == SWIN_BF16) {
         if (C % 8) return SWIN_ERR_UNSUPPORTED;
         int64_t nvec = rows * (C / 8);
-        int blocks = dbias ? (ew_blocks(nvec) < 1024 ? ew_blocks(nvec) : 1024) : ew_blocks(nvec);
+        int blocks = bias_gelu_blocks(nvec, C / 8);
         bias_gelu_kernel<bf16, BWD><<<blocks, 256, shm, s>>>((const bf16*)x, bias, (const bf16*)dy, (bf16*)out, dbias, nvec,
                                                             C / 8);
     } else if (dtype == SWIN_F32) {
         if (C % 4) return SWIN_ERR_UNSUPPORTED;
         int64_t nvec = rows * (C / 4);
-        int blocks = dbias ? (ew_blocks(nvec) < 1024 ? ew_blocks(nvec) : 1024) : ew_blocks(nvec);
+        int blocks = bias_gelu_blocks(nvec, C / 4);
         bias_gelu_kernel<float, BWD><<<blocks, 256, shm, s>>>((const float*)x, bias, (const float*)dy, (float*)out, dbias,
                                                               nvec, C / 4);
     } else return SWIN_ERR_UNSUPPORTED;

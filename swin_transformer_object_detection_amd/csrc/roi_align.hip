@@ -140,30 +140,88 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const T* __restrict__ 
     }
 }
 
+// NHWC backward.  One block per RoI, threads = channels (256-byte contiguous atomics per wave).  The bilinear
+// weights are separable, so instead of 4 atomics per SAMPLE the block first sums, per bin row / bin column, the
+// 1-D weights every sample puts on each feature row / column (LDS), and then issues one atomic per touched PIXEL
+// of the bin footprint with weight Wy*Wx -- (grid+1)^2 instead of 4*grid^2 atomics per bin.  The atomic rate is
+// the bound of this kernel (guide G12), so fewer atomic bytes is the lever.
+#define RA_MAXF 8        // footprint rows/cols per bin held in LDS; larger sampling grids take the per-sample path
+#define RA_MAXP 16       // pooled size limit of the fast path (7 and 14 in every swin config)
+
+__device__ __forceinline__ void axis_weights(float start, float bin, int b, int grid, int size, float* Wt, int& p0, int& np,
+                                             bool& overflow) {
+    // accumulate the weights of the `grid` samples of bin b along one axis; border rules of bilinear_interpolate
+    p0 = -1; np = 0;
+    for (int f = 0; f < RA_MAXF; ++f) Wt[f] = 0.f;
+    for (int g = 0; g < grid; ++g) {
+        float t = start + (float)b * bin + ((float)g + .5f) * bin / (float)grid;
+        if (t < -1.0f || t > (float)size) continue;
+        if (t <= 0.f) t = 0.f;
+        int lo = (int)t, hi;
+        if (lo >= size - 1) { hi = lo = size - 1; t = (float)lo; } else hi = lo + 1;
+        float l = t - (float)lo, hgh = 1.f - l;
+        if (p0 < 0) p0 = lo;
+        int a = lo - p0, bb = hi - p0;
+        if (bb >= RA_MAXF) { overflow = true; return; }
+        Wt[a] += hgh; Wt[bb] += l;
+        np = bb + 1 > np ? bb + 1 : np;
+    }
+    if (p0 < 0) p0 = 0;
+}
+
 __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restrict__ gout, const float* __restrict__ rois,
-                                                          float* __restrict__ gin, int C, int H, int W, int64_t total,
+                                                          float* __restrict__ gin, int C, int H, int W, int K,
                                                           int ph, int pw, float scale, int sr, int aligned) {
-    // one thread per (k, i, j, channel): consecutive lanes = consecutive channels = contiguous atomics
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        int c = (int)(idx % C);
-        int64_t t = idx / C;
-        int j = (int)(t % pw); t /= pw;
-        int i = (int)(t % ph);
-        int64_t k = t / ph;
-        RoiGeom g = roi_geom(rois + 5 * k, scale, aligned, ph, pw, sr);
-        float* p = gin + (int64_t)g.batch * H * W * C + c;
-        float go = gout[idx];
-        for (int iy = 0; iy < g.grid_h; ++iy) {
-            float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
-            for (int ix = 0; ix < g.grid_w; ++ix) {
-                float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
-                Bilin b = bilin_setup(H, W, y, x);
-                if (!b.valid) continue;
-                atomicAdd(p + ((int64_t)b.yl * W + b.xl) * C, go * b.w1 / g.count);
-                atomicAdd(p + ((int64_t)b.yl * W + b.xh) * C, go * b.w2 / g.count);
-                atomicAdd(p + ((int64_t)b.yh * W + b.xl) * C, go * b.w3 / g.count);
-                atomicAdd(p + ((int64_t)b.yh * W + b.xh) * C, go * b.w4 / g.count);
-            }
+    __shared__ float Wy[RA_MAXP][RA_MAXF], Wx[RA_MAXP][RA_MAXF];
+    __shared__ int Y0[RA_MAXP], NY[RA_MAXP], X0[RA_MAXP], NX[RA_MAXP];
+    __shared__ int slow;
+    const int k = blockIdx.x, t = threadIdx.x;
+    RoiGeom g = roi_geom(rois + 5 * (int64_t)k, scale, aligned, ph, pw, sr);
+    if (t == 0) slow = (ph > RA_MAXP || pw > RA_MAXP) ? 1 : 0;
+    __syncthreads();
+    if (!slow) {
+        bool ov = false;
+        if (t < ph) axis_weights(g.start_h, g.bin_h, t, g.grid_h, H, Wy[t], Y0[t], NY[t], ov);
+        else if (t >= 32 && t < 32 + pw) axis_weights(g.start_w, g.bin_w, t - 32, g.grid_w, W, Wx[t - 32], X0[t - 32], NX[t - 32], ov);
+        if (ov) slow = 1;
+    }
+    __syncthreads();
+    float* base = gin + (int64_t)g.batch * H * W * C;
+    const float inv = 1.0f / g.count;
+    for (int c = t; c < C; c += 256) {
+        const float* go = gout + (int64_t)k * ph * pw * C + c;
+        if (!slow) {
+            for (int i = 0; i < ph; ++i)
+                for (int j = 0; j < pw; ++j) {
+                    const float gv = go[(i * pw + j) * C] * inv;
+                    for (int fy = 0; fy < NY[i]; ++fy) {
+                        const float wy = Wy[i][fy];
+                        if (wy == 0.f) continue;
+                        float* rowp = base + ((int64_t)(Y0[i] + fy) * W + X0[j]) * C + c;
+                        for (int fx = 0; fx < NX[j]; ++fx) {
+                            const float w = wy * Wx[j][fx];
+                            if (w != 0.f) atomicAdd(rowp + (int64_t)fx * C, gv * w);
+                        }
+                    }
+                }
+        } else {        // per-sample path (very large sampling grids)
+            for (int i = 0; i < ph; ++i)
+                for (int j = 0; j < pw; ++j) {
+                    const float gv = go[(i * pw + j) * C];
+                    for (int iy = 0; iy < g.grid_h; ++iy) {
+                        float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+                        for (int ix = 0; ix < g.grid_w; ++ix) {
+                            float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                            Bilin b = bilin_setup(H, W, y, x);
+                            if (!b.valid) continue;
+                            float* p = base + c;
+                            atomicAdd(p + ((int64_t)b.yl * W + b.xl) * C, gv * b.w1 / g.count);
+                            atomicAdd(p + ((int64_t)b.yl * W + b.xh) * C, gv * b.w2 / g.count);
+                            atomicAdd(p + ((int64_t)b.yh * W + b.xl) * C, gv * b.w3 / g.count);
+                            atomicAdd(p + ((int64_t)b.yh * W + b.xh) * C, gv * b.w4 / g.count);
+                        }
+                    }
+                }
         }
     }
 }
@@ -212,8 +270,8 @@ extern "C" int roi_align_bwd(const float* grad_output, const float* rois, float*
     hipStream_t s = (hipStream_t)stream;
     int64_t total = (int64_t)K * C * ph * pw;
     if (channels_last)
-        roi_align_bwd_nhwc<<<ra_blocks(total), 256, 0, s>>>(grad_output, rois, grad_input, C, H, W, total, ph, pw,
-                                                           spatial_scale, sampling_ratio, aligned);
+        roi_align_bwd_nhwc<<<K, 256, 0, s>>>(grad_output, rois, grad_input, C, H, W, K, ph, pw, spatial_scale,
+                                             sampling_ratio, aligned);
     else
         roi_align_bwd_nchw<<<ra_blocks(total), 256, 0, s>>>(grad_output, rois, grad_input, C, H, W, total, ph, pw,
                                                            spatial_scale, sampling_ratio, aligned);
