@@ -179,6 +179,16 @@ int roi_align_bwd(const float* grad_output, const float* rois, float* grad_input
                   int K, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
                   int channels_last, void* stream);
 
+/* SingleRoIExtractor.forward (single_level_roi_extractor.py:82-97) in one launch over an FPN pyramid in
+ * channels-last memory: RoI k reads level lvl[k] (host-side map_roi_levels, :47-51); lvl[k] < 0 skips the RoI
+ * (zero output row).  feats / grads are HOST arrays of n_levels (<= 4) device pointers. */
+int roi_align_multilevel_fwd(const void* const* feats, const int* Hs, const int* Ws, const float* scales,
+                             int n_levels, const float* rois, const int* lvl, float* output, int C, int K,
+                             int ph, int pw, int sampling_ratio, int aligned, int in_dtype, void* stream);
+int roi_align_multilevel_bwd(float* const* grads, const int* Hs, const int* Ws, const float* scales, int n_levels,
+                             const float* grad_output, const float* rois, const int* lvl, int C, int K, int ph,
+                             int pw, int sampling_ratio, int aligned, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * mmcv.ops.nms device part -- call sites rpn_head.py:233, bbox_nms.py:84 (through batched_nms).
  * boxes_sorted (n,4) f32 ALREADY in descending-score order (stable sort done by the host
@@ -186,10 +196,13 @@ int roi_align_bwd(const float* grad_output, const float* rois, float* grad_input
  * workspace: >= swin_nms_workspace_bytes(n) bytes of device memory.
  * The whole greedy reduction runs on the device (mmcv copies the bitmask to the host).
  * max_num > 0: stop after max_num kept boxes (mmcv nms's `max_num`; == slicing the result).
+ * kept_pos (nullable): fixed-size (kept_cap) int32 list of the kept positions in sorted order, -1 padded --
+ *                      lets a caller consume the result without a device->host sync for the dynamic count.
  * ---------------------------------------------------------------------------------- */
 int64_t swin_nms_workspace_bytes(int64_t n);
 int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int offset, int max_num,
-               uint8_t* keep_flags, int32_t* num_kept, void* workspace, void* stream);
+               uint8_t* keep_flags, int32_t* num_kept, int32_t* kept_pos, int kept_cap, void* workspace,
+               void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
 // the callers slice `dets[:max_per_img]` (rpn_head.py:235, bbox_nms.py:86-88), so later boxes never matter.
 __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks,
                                                          uint8_t* __restrict__ keep, int32_t* __restrict__ num_kept,
-                                                         int max_num) {
+                                                         int max_num, int32_t* __restrict__ kept_pos, int kept_cap) {
     extern __shared__ __attribute__((aligned(16))) uint64_t remv[];   // col_blocks words
     __shared__ uint64_t diag[64];
     __shared__ uint64_t kept_bits;
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
     __shared__ int kept_cnt, total;
     const int t = threadIdx.x;
     for (int j = t; j < col_blocks; j += 256) remv[j] = 0;
+    if (kept_pos) for (int i = t; i < kept_cap; i += 256) kept_pos[i] = -1;     // fixed-size, -1 padded output
     if (t == 0) total = 0;
     __syncthreads();
     int b = 0;
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
         const uint64_t kb = kept_bits;
         const int cnt = kept_cnt;
         if (t < lim) keep[b * 64 + t] = (uint8_t)((kb >> t) & 1);
+        if (kept_pos && t < cnt && total - cnt + t < kept_cap) kept_pos[total - cnt + t] = kept_rows[t];
         if (max_num > 0 && total >= max_num) { ++b; break; }
         for (int j = b + 1 + t; j < col_blocks; j += 256) {
             uint64_t acc = remv[j];
@@ -104,11 +106,13 @@ extern "C" int64_t swin_nms_workspace_bytes(int64_t n) {
 }
 
 extern "C" int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int offset, int max_num,
-                          uint8_t* keep_flags, int32_t* num_kept, void* workspace, void* stream) {
+                          uint8_t* keep_flags, int32_t* num_kept, int32_t* kept_pos, int kept_cap, void* workspace,
+                          void* stream) {
     if (n < 0 || !num_kept) return SWIN_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
         hipError_t e = hipMemsetAsync(num_kept, 0, sizeof(int32_t), s);
+        if (e == hipSuccess && kept_pos && kept_cap > 0) e = hipMemsetAsync(kept_pos, 0xFF, sizeof(int32_t) * kept_cap, s);
         return e == hipSuccess ? SWIN_OK : SWIN_ERR_LAUNCH;
     }
     if (!boxes_sorted || !keep_flags || !workspace) return SWIN_ERR_BAD_ARG;
@@ -118,6 +122,6 @@ extern "C" int nms_sorted(const float* boxes_sorted, int64_t n, float iou_thresh
     nms_mask_kernel<<<grid, 64, 0, s>>>((const float4*)boxes_sorted, (int)n, iou_threshold, (float)offset,
                                         (uint64_t*)workspace, col_blocks);
     nms_reduce_kernel<<<1, 256, (size_t)col_blocks * 8, s>>>((const uint64_t*)workspace, (int)n, col_blocks, keep_flags,
-                                                            num_kept, max_num);
+                                                            num_kept, max_num, kept_pos, kept_cap);
     return swin_launch_status();
 }

@@ -226,6 +226,114 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restric
     }
 }
 
+// ----------------------------------------------------------------------------- multi-level (FPN) NHWC
+// SingleRoIExtractor.forward (single_level_roi_extractor.py:82-97) in ONE launch: every RoI reads the pyramid level
+// `lvl[k]` the host mapped it to (map_roi_levels, :47-51), so there is no per-level nonzero / gather / scatter and
+// no host synchronisation.  RoIs with lvl < 0 are skipped (output rows stay zero): slots of a fixed-size sample.
+struct MLFeats { const void* p[4]; int H[4], W[4]; float scale[4]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_ml_fwd_nhwc(MLFeats F, const float* __restrict__ rois, const int* __restrict__ lvl,
+                                                             float* __restrict__ out, int C, int64_t total, int ph, int pw,
+                                                             int sr, int aligned) {
+    const int cg = C / 4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int c4 = (int)(idx % cg) * 4;
+        int64_t t = idx / cg;
+        int j = (int)(t % pw); t /= pw;
+        int i = (int)(t % ph);
+        int64_t k = t / ph;
+        const int l = lvl[k];
+        float4 o = {0.f, 0.f, 0.f, 0.f};
+        if (l >= 0) {
+            const int H = F.H[l], W = F.W[l];
+            RoiGeom g = roi_geom(rois + 5 * k, F.scale[l], aligned, ph, pw, sr);
+            const T* p = (const T*)F.p[l] + (int64_t)g.batch * H * W * C + c4;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int iy = 0; iy < g.grid_h; ++iy) {
+                float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+                for (int ix = 0; ix < g.grid_w; ++ix) {
+                    float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                    Bilin b = bilin_setup(H, W, y, x);
+                    if (!b.valid) continue;
+                    const T* p1 = p + ((int64_t)b.yl * W + b.xl) * C;
+                    const T* p2 = p + ((int64_t)b.yl * W + b.xh) * C;
+                    const T* p3 = p + ((int64_t)b.yh * W + b.xl) * C;
+                    const T* p4 = p + ((int64_t)b.yh * W + b.xh) * C;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[e] += b.w1 * Elt<T>::ld(p1 + e) + b.w2 * Elt<T>::ld(p2 + e) + b.w3 * Elt<T>::ld(p3 + e) +
+                                  b.w4 * Elt<T>::ld(p4 + e);
+                }
+            }
+            o = float4{acc[0] / g.count, acc[1] / g.count, acc[2] / g.count, acc[3] / g.count};
+        }
+        *(float4*)(out + idx * 4) = o;
+    }
+}
+
+struct MLGrads { float* p[4]; int H[4], W[4]; float scale[4]; };
+
+__global__ __launch_bounds__(256) void roi_align_ml_bwd_nhwc(MLGrads G, const float* __restrict__ gout, const float* __restrict__ rois,
+                                                             const int* __restrict__ lvl, int C, int K, int ph, int pw, int sr,
+                                                             int aligned) {
+    __shared__ float Wy[RA_MAXP][RA_MAXF], Wx[RA_MAXP][RA_MAXF];
+    __shared__ int Y0[RA_MAXP], NY[RA_MAXP], X0[RA_MAXP], NX[RA_MAXP];
+    __shared__ int slow;
+    const int k = blockIdx.x, t = threadIdx.x;
+    const int l = lvl[k];
+    if (l < 0) return;
+    const int H = G.H[l], W = G.W[l];
+    RoiGeom g = roi_geom(rois + 5 * (int64_t)k, G.scale[l], aligned, ph, pw, sr);
+    if (t == 0) slow = (ph > RA_MAXP || pw > RA_MAXP) ? 1 : 0;
+    __syncthreads();
+    if (!slow) {
+        bool ov = false;
+        if (t < ph) axis_weights(g.start_h, g.bin_h, t, g.grid_h, H, Wy[t], Y0[t], NY[t], ov);
+        else if (t >= 32 && t < 32 + pw) axis_weights(g.start_w, g.bin_w, t - 32, g.grid_w, W, Wx[t - 32], X0[t - 32], NX[t - 32], ov);
+        if (ov) slow = 1;
+    }
+    __syncthreads();
+    float* base = G.p[l] + (int64_t)g.batch * H * W * C;
+    const float inv = 1.0f / g.count;
+    for (int c = t; c < C; c += 256) {
+        const float* go = gout + (int64_t)k * ph * pw * C + c;
+        if (!slow) {
+            for (int i = 0; i < ph; ++i)
+                for (int j = 0; j < pw; ++j) {
+                    const float gv = go[(i * pw + j) * C] * inv;
+                    for (int fy = 0; fy < NY[i]; ++fy) {
+                        const float wy = Wy[i][fy];
+                        if (wy == 0.f) continue;
+                        float* rowp = base + ((int64_t)(Y0[i] + fy) * W + X0[j]) * C + c;
+                        for (int fx = 0; fx < NX[j]; ++fx) {
+                            const float w = wy * Wx[j][fx];
+                            if (w != 0.f) atomicAdd(rowp + (int64_t)fx * C, gv * w);
+                        }
+                    }
+                }
+        } else {
+            for (int i = 0; i < ph; ++i)
+                for (int j = 0; j < pw; ++j) {
+                    const float gv = go[(i * pw + j) * C];
+                    for (int iy = 0; iy < g.grid_h; ++iy) {
+                        float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+                        for (int ix = 0; ix < g.grid_w; ++ix) {
+                            float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                            Bilin b = bilin_setup(H, W, y, x);
+                            if (!b.valid) continue;
+                            float* p = base + c;
+                            atomicAdd(p + ((int64_t)b.yl * W + b.xl) * C, gv * b.w1 / g.count);
+                            atomicAdd(p + ((int64_t)b.yl * W + b.xh) * C, gv * b.w2 / g.count);
+                            atomicAdd(p + ((int64_t)b.yh * W + b.xl) * C, gv * b.w3 / g.count);
+                            atomicAdd(p + ((int64_t)b.yh * W + b.xh) * C, gv * b.w4 / g.count);
+                        }
+                    }
+                }
+        }
+    }
+}
+
 static inline int ra_blocks(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 65535 ? (b > 0 ? b : 1) : 65535);
@@ -275,5 +383,48 @@ extern "C" int roi_align_bwd(const float* grad_output, const float* rois, float*
     else
         roi_align_bwd_nchw<<<ra_blocks(total), 256, 0, s>>>(grad_output, rois, grad_input, C, H, W, total, ph, pw,
                                                            spatial_scale, sampling_ratio, aligned);
+    return swin_launch_status();
+}
+
+// Multi-level RoIAlign over an FPN pyramid in channels-last memory (see roi_align_ml_fwd_nhwc above).
+//   feats[l]: (N, H[l], W[l], C) in_dtype, l < n_levels <= 4;  lvl (K) int32 level per RoI, < 0 = skip (zero row);
+//   output (K, ph, pw, C) f32.
+extern "C" int roi_align_multilevel_fwd(const void* const* feats, const int* Hs, const int* Ws, const float* scales,
+                                        int n_levels, const float* rois, const int* lvl, float* output, int C, int K,
+                                        int ph, int pw, int sampling_ratio, int aligned, int in_dtype, void* stream) {
+    if (K == 0) return SWIN_OK;
+    if (!feats || !Hs || !Ws || !scales || !rois || !lvl || !output || n_levels <= 0 || n_levels > 4 || C <= 0 || K < 0)
+        return SWIN_ERR_BAD_ARG;
+    if (C % 4) return SWIN_ERR_UNSUPPORTED;
+    MLFeats F;
+    for (int l = 0; l < 4; ++l) {
+        int m = l < n_levels ? l : n_levels - 1;
+        F.p[l] = feats[m]; F.H[l] = Hs[m]; F.W[l] = Ws[m]; F.scale[l] = scales[m];
+        if (!F.p[l]) return SWIN_ERR_BAD_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int64_t total = (int64_t)K * ph * pw * (C / 4);
+    if (in_dtype == SWIN_F32)
+        roi_align_ml_fwd_nhwc<float><<<ra_blocks(total), 256, 0, s>>>(F, rois, lvl, output, C, total, ph, pw, sampling_ratio, aligned);
+    else if (in_dtype == SWIN_BF16)
+        roi_align_ml_fwd_nhwc<bf16><<<ra_blocks(total), 256, 0, s>>>(F, rois, lvl, output, C, total, ph, pw, sampling_ratio, aligned);
+    else return SWIN_ERR_UNSUPPORTED;
+    return swin_launch_status();
+}
+
+// grads[l]: (N, H[l], W[l], C) f32, zeroed by the caller; fp32 atomics.
+extern "C" int roi_align_multilevel_bwd(float* const* grads, const int* Hs, const int* Ws, const float* scales, int n_levels,
+                                        const float* grad_output, const float* rois, const int* lvl, int C, int K, int ph,
+                                        int pw, int sampling_ratio, int aligned, void* stream) {
+    if (K == 0) return SWIN_OK;
+    if (!grads || !Hs || !Ws || !scales || !grad_output || !rois || !lvl || n_levels <= 0 || n_levels > 4 || C <= 0 || K < 0)
+        return SWIN_ERR_BAD_ARG;
+    MLGrads G;
+    for (int l = 0; l < 4; ++l) {
+        int m = l < n_levels ? l : n_levels - 1;
+        G.p[l] = grads[m]; G.H[l] = Hs[m]; G.W[l] = Ws[m]; G.scale[l] = scales[m];
+        if (!G.p[l]) return SWIN_ERR_BAD_ARG;
+    }
+    roi_align_ml_bwd_nhwc<<<K, 256, 0, (hipStream_t)stream>>>(G, grad_output, rois, lvl, C, K, ph, pw, sampling_ratio, aligned);
     return swin_launch_status();
 }

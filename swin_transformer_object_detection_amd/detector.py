@@ -168,6 +168,28 @@ def random_sample(assigned, num, pos_fraction):
     return pos_inds, neg_inds
 
 
+def sample_static(assigned, num, pos_fraction):
+    """RandomSampler (random_sampler.py:31-78) with a FIXED-size result and no host synchronisation.
+
+    Same distribution as the reference: a uniformly random subset of min(n_pos, num*pos_fraction) positives,
+    then uniformly random negatives up to ``num`` in total.  Implemented with random keys and two top-k
+    selections instead of nonzero + randperm (whose output sizes would have to travel to the host).
+    Returns (idx (k,), is_pos (k,), valid (k,)) with k = min(num, n); positives come first."""
+    n = assigned.numel()
+    key = torch.rand(n, device=assigned.device)
+    is_p = assigned > 0
+    num_pos = min(int(num * pos_fraction), n)
+    if num_pos > 0:
+        posk = torch.where(is_p, key, key.new_full((), 2.0))
+        kth = torch.topk(posk, num_pos, largest=False, sorted=True).values[-1]
+        pos_sel = is_p & (posk <= kth)
+    else:
+        pos_sel = torch.zeros_like(is_p)
+    comb = torch.where(pos_sel, key, torch.where(assigned == 0, key + 1.0, key.new_full((), 3.0)))
+    vals, idx = torch.topk(comb, min(num, n), largest=False, sorted=True)
+    return idx, vals < 1.0, vals < 3.0
+
+
 def _cast(t, dtype):
     """compute-dtype view of a tensor; parameters resolve to their bf16 shadow (mixed.py)"""
     return mixed.weight(t, dtype)
@@ -246,39 +268,39 @@ class RPNHead(nn.Module):
 
     # ---- training targets + loss (anchor_head.py:175-493) ----
     def loss(self, cls_scores, bbox_preds, gt_bboxes, img_shapes):
+        """Sampled-anchor form of AnchorHead.loss: the reference builds (B, 255780) label / weight / target arrays and
+        multiplies the per-anchor losses by 0/1 weights; only the <= 256 sampled anchors per image have non-zero
+        weight, so the same sums are taken over those anchors directly.  No host synchronisation."""
         cfg = self.train_cfg
         a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
         sizes = [tuple(c.shape[-2:]) for c in cls_scores]
         anchors = torch.cat(self.anchor_generator.grid_anchors(sizes, cls_scores[0].device), 0)
         B = cls_scores[0].size(0)
-        A = anchors.size(0)
-        labels = anchors.new_full((B, A), 1, dtype=torch.long)            # background = num_classes = 1
-        label_w = anchors.new_zeros((B, A))
-        bbox_t = anchors.new_zeros((B, A, 4))
-        bbox_w = anchors.new_zeros((B, A, 4))
-        total = 0
+        cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1)
+        reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
+        loss_cls = loss_bbox = total = 0.
         for i in range(B):
             assigned, _, _ = max_iou_assign(anchors, gt_bboxes[i], a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'],
                                             a_cfg['min_pos_iou'], a_cfg.get('match_low_quality', True))
-            pos, neg = random_sample(assigned, s_cfg['num'], s_cfg['pos_fraction'])
-            if pos.numel() > 0:
-                bbox_t[i, pos] = bbox2delta(anchors[pos], gt_bboxes[i][assigned[pos] - 1], self.means, self.stds)
-                bbox_w[i, pos] = 1.0
-                labels[i, pos] = 0
-                label_w[i, pos] = 1.0
-            label_w[i, neg] = 1.0
-            total += pos.numel() + neg.numel()
-        avg = float(max(total, 1))
-        cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1).float()
-        reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1).float()
-        target = (labels == 0).float()
-        loss_cls = (F.binary_cross_entropy_with_logits(cls, target, reduction='none') * label_w).sum() / avg
-        loss_bbox = ((reg - bbox_t).abs() * bbox_w).sum() / avg
-        return dict(loss_rpn_cls=loss_cls * self.loss_cls_weight, loss_rpn_bbox=loss_bbox * self.loss_bbox_weight)
+            idx, is_pos, valid = sample_static(assigned, s_cfg['num'], s_cfg['pos_fraction'])
+            a = anchors[idx]
+            if gt_bboxes[i].size(0) > 0:
+                g = gt_bboxes[i][(assigned[idx] - 1).clamp(min=0)]
+                tgt = bbox2delta(a, g, self.means, self.stds)
+                tgt = torch.where(is_pos[:, None], tgt, torch.zeros_like(tgt))
+            else:
+                tgt = torch.zeros_like(a)
+            c_i, r_i = cls[i][idx].float(), reg[i][idx].float()
+            lc = F.binary_cross_entropy_with_logits(c_i, is_pos.float(), reduction='none')     # fg -> 1, bg -> 0
+            loss_cls = loss_cls + (lc * valid).sum()
+            loss_bbox = loss_bbox + ((r_i - tgt).abs() * is_pos[:, None]).sum()
+            total = total + valid.sum()
+        avg = total.clamp(min=1).float()                                                   # num_total_samples
+        return dict(loss_rpn_cls=loss_cls / avg * self.loss_cls_weight, loss_rpn_bbox=loss_bbox / avg * self.loss_bbox_weight)
 
     # ---- proposals (rpn_head.py:82-236): detached, per level top-k by a full stable sort ----
     @torch.no_grad()
-    def get_bboxes(self, cls_scores, bbox_preds, img_shapes, cfg):
+    def get_bboxes(self, cls_scores, bbox_preds, img_shapes, cfg, static=False):
         sizes = [tuple(c.shape[-2:]) for c in cls_scores]
         mlvl_anchors = self.anchor_generator.grid_anchors(sizes, cls_scores[0].device)
         B = cls_scores[0].size(0)
@@ -307,6 +329,10 @@ class RPNHead(nn.Module):
                 props, sc, idl = props[v], scores[i][v], ids[i][v]
             else:
                 sc, idl = scores[i], ids[i]
+            if static and cfg.get('min_bbox_size', 0) <= 0 and props.size(0) < cfg['nms'].get('split_thr', 10000):
+                # fixed-size (max_per_img, 5) result + validity mask: the kept count never leaves the device
+                out.append(ops.batched_nms_static(props, sc, idl, cfg['nms']['iou_threshold'], cfg['max_per_img']))
+                continue
             # max_num == the reference's `dets[:cfg.max_per_img]` (rpn_head.py:235); lets the device reduction stop early
             nms_cfg = dict(cfg['nms'], max_num=cfg['max_per_img'])
             dets, _ = ops.batched_nms(props, sc, idl, nms_cfg)                  # HIP nms
@@ -340,9 +366,21 @@ class SingleRoIExtractor(nn.Module):
         lv = torch.floor(torch.log2(scale / self.finest_scale + 1e-6))
         return lv.clamp(min=0, max=num_levels - 1).long()
 
-    def forward(self, feats, rois, roi_scale_factor=None):
+    def forward(self, feats, rois, roi_scale_factor=None, valid=None):
         out_size = self.roi_layers[0].output_size
         num_levels = len(feats)
+        f0 = feats[0]
+        if (num_levels > 1 and num_levels <= 4 and f0.is_cuda and f0.shape[1] % 4 == 0 and rois.size(0) > 0
+                and f0.dtype in (torch.float32, torch.bfloat16)):
+            # one launch over the pyramid, level chosen per RoI on the device: no per-level nonzero / gather /
+            # scatter and no host sync; every level receives a gradient tensor, so the reference's dummy-gradient
+            # trick (:98-107) is not needed.  `valid` marks the used slots of a fixed-size sample.
+            lvls = self.map_roi_levels(rois, num_levels)
+            if valid is not None:
+                lvls = torch.where(valid, lvls, torch.full_like(lvls, -1))
+            rl = self.roi_layers[0]
+            return ops.roi_align_multilevel(list(feats), rois, lvls, out_size, self.featmap_strides[:num_levels],
+                                            rl.sampling_ratio, rl.aligned)
         cl = feats[0].is_contiguous(memory_format=torch.channels_last) and not feats[0].is_contiguous()
         roi_feats = torch.empty((rois.size(0), self.out_channels, *out_size), device=rois.device, dtype=torch.float32,
                                 memory_format=torch.channels_last if cl else torch.contiguous_format).zero_()
@@ -409,14 +447,19 @@ class Shared2FCBBoxHead(nn.Module):
         reg = F.linear(x, _cast(self.fc_reg.weight, dt), _cast(self.fc_reg.bias, dt))
         return cls, reg
 
-    def loss(self, cls_score, bbox_pred, labels, bbox_targets, num_pos_mask):
+    def loss(self, cls_score, bbox_pred, labels, bbox_targets, pos_mask, valid=None):
+        """bbox_head.py loss: CE over the sampled RoIs (avg_factor = their count), class-specific L1 over the
+        positives divided by the number of samples.  ``valid`` masks the unused slots of a fixed-size sample."""
         cls_score, bbox_pred = cls_score.float(), bbox_pred.float()
         n = cls_score.size(0)
-        loss_cls = F.cross_entropy(cls_score, labels, reduction='sum') / max(float(n), 1.)
-        acc = (cls_score.argmax(1) == labels).float().mean() * 100
-        pos = num_pos_mask
-        pred = bbox_pred.view(n, -1, 4)[pos, labels[pos]]
-        loss_bbox = (pred - bbox_targets[pos]).abs().sum() / max(float(n), 1.)
+        if valid is None:
+            valid = torch.ones(n, dtype=torch.bool, device=cls_score.device)
+        nv = valid.sum().clamp(min=1).float()
+        ce = F.cross_entropy(cls_score, labels, reduction='none')
+        loss_cls = (ce * valid).sum() / nv
+        acc = (((cls_score.argmax(1) == labels) & valid).sum() / nv) * 100
+        pred = bbox_pred.view(n, -1, 4)[torch.arange(n, device=labels.device), labels.clamp(max=self.num_classes - 1)]
+        loss_bbox = ((pred - bbox_targets).abs() * pos_mask[:, None]).sum() / nv
         return dict(loss_cls=loss_cls * self.loss_cls_weight, acc=acc, loss_bbox=loss_bbox * self.loss_bbox_weight)
 
 
@@ -463,11 +506,17 @@ class FCNMaskHead(nn.Module):
         y = y.view(P, H, W, 2, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(P, 2 * H, 2 * W, Co)
         return y.permute(0, 3, 1, 2)                                                   # channels-last view
 
-    def loss(self, mask_pred, mask_targets, labels):
-        if mask_pred.size(0) == 0:
+    def loss(self, mask_pred, mask_targets, labels, valid=None):
+        """mask_cross_entropy (cross_entropy_loss.py): mean BCE over (positives x 28 x 28) of the class channel."""
+        n = mask_pred.size(0)
+        if n == 0:
             return dict(loss_mask=mask_pred.sum() * 0)
-        pred = mask_pred.float()[torch.arange(mask_pred.size(0), device=mask_pred.device), labels]
-        return dict(loss_mask=F.binary_cross_entropy_with_logits(pred, mask_targets, reduction='mean') * self.loss_mask_weight)
+        pred = mask_pred.float()[torch.arange(n, device=mask_pred.device), labels]
+        per_roi = F.binary_cross_entropy_with_logits(pred, mask_targets, reduction='none').mean(dim=(1, 2))
+        if valid is None:
+            return dict(loss_mask=per_roi.mean() * self.loss_mask_weight)
+        loss = (per_roi * valid).sum() / valid.sum().clamp(min=1)
+        return dict(loss_mask=loss * self.loss_mask_weight)
 
 
 @HEADS.register_module()
@@ -487,55 +536,69 @@ class StandardRoIHead(nn.Module):
             self.mask_head.init_weights()
 
     def forward_train(self, x, proposal_list, gt_bboxes, gt_labels, gt_masks):
-        """standard_roi_head.py:70-131.  gt_masks: list of (G_i, H, W) uint8/bool tensors on the device."""
+        """standard_roi_head.py:70-131 with fixed-size samples.  ``proposal_list[i]`` is either ``dets (n,5)`` (the
+        reference's form) or ``(dets (max,5), valid (max,))`` from the static RPN path.  Every tensor below has a
+        shape known on the host (512 RoIs and 128 mask slots per image); unused slots are masked out of the losses
+        and skipped by RoIAlign, so the step needs no device->host synchronisation.
+        gt_masks: list of (G_i, H, W) uint8/bool tensors on the device."""
         cfg = self.train_cfg
         a, s = cfg['assigner'], cfg['sampler']
         nimg = len(proposal_list)
-        rois_l, labels_l, tgt_l, pos_l = [], [], [], []
-        pos_boxes, pos_gt_inds, pos_labels = [], [], []
+        nc = self.bbox_head.num_classes
+        num, npos_max = s['num'], int(s['num'] * s['pos_fraction'])
+        roi_l, lab_l, tgt_l, pos_l, val_l = [], [], [], [], []
+        m_roi, m_gt, m_lab, m_val = [], [], [], []
         for i in range(nimg):
-            props = proposal_list[i][:, :4]
+            p = proposal_list[i]
+            dets, pvalid = (p if isinstance(p, tuple) else (p, torch.ones(p.size(0), dtype=torch.bool, device=p.device)))
+            props = dets[:, :4]
+            g = gt_bboxes[i].size(0)
             if s.get('add_gt_as_proposals', True):
                 props = torch.cat([gt_bboxes[i], props], 0)
+                pvalid = torch.cat([torch.ones(g, dtype=torch.bool, device=props.device), pvalid], 0)
             assigned, _, lab = max_iou_assign(props, gt_bboxes[i], a['pos_iou_thr'], a['neg_iou_thr'], a['min_pos_iou'],
                                               a.get('match_low_quality', True), gt_labels[i])
-            if s.get('add_gt_as_proposals', True):          # AssignResult.add_gt_: gts are assigned to themselves
-                g = gt_bboxes[i].size(0)
-                assigned[:g] = torch.arange(1, g + 1, device=assigned.device)
-                lab[:g] = gt_labels[i]
-            pos, neg = random_sample(assigned, s['num'], s['pos_fraction'])
-            pb, nb = props[pos], props[neg]
-            rois_l.append(torch.cat([pb, nb], 0))
-            lab_i = props.new_full((pos.numel() + neg.numel(),), self.bbox_head.num_classes, dtype=torch.long)
-            lab_i[:pos.numel()] = lab[pos]
-            t_i = props.new_zeros((pos.numel() + neg.numel(), 4))
-            if pos.numel() > 0:
-                t_i[:pos.numel()] = bbox2delta(pb, gt_bboxes[i][assigned[pos] - 1], self.bbox_head.means, self.bbox_head.stds)
-            m_i = torch.zeros(pos.numel() + neg.numel(), dtype=torch.bool, device=props.device)
-            m_i[:pos.numel()] = True
-            labels_l.append(lab_i); tgt_l.append(t_i); pos_l.append(m_i)
-            pos_boxes.append(pb); pos_gt_inds.append(assigned[pos] - 1); pos_labels.append(lab[pos])
+            if s.get('add_gt_as_proposals', True) and g > 0:          # AssignResult.add_gt_: gts match themselves
+                self_ind = torch.arange(1, g + 1, device=assigned.device)
+                assigned = torch.cat([self_ind, assigned[g:]], 0)
+                lab = torch.cat([gt_labels[i], lab[g:]], 0)
+            assigned = torch.where(pvalid, assigned, torch.full_like(assigned, -1))     # padding slots are never sampled
+            idx, is_pos, valid = sample_static(assigned, num, s['pos_fraction'])
+            boxes = torch.where(valid[:, None], props[idx], props.new_tensor([0., 0., 1., 1.]).expand(idx.numel(), 4))
+            gt_ind = (assigned[idx] - 1).clamp(min=0)
+            if g > 0:
+                t_i = bbox2delta(boxes, gt_bboxes[i][gt_ind], self.bbox_head.means, self.bbox_head.stds)
+                t_i = torch.where(is_pos[:, None], t_i, torch.zeros_like(t_i))
+                l_i = torch.where(is_pos, lab[idx], torch.full_like(idx, nc))
+            else:
+                t_i = torch.zeros_like(boxes)
+                l_i = torch.full_like(idx, nc)
+            roi_l.append(boxes); lab_l.append(l_i); tgt_l.append(t_i); pos_l.append(is_pos); val_l.append(valid)
+            k = min(npos_max, idx.numel())                            # positives come first in the sample
+            m_roi.append(boxes[:k]); m_gt.append(gt_ind[:k]); m_lab.append(l_i[:k].clamp(max=nc - 1)); m_val.append(is_pos[:k])
         losses = {}
-        rois = bbox2roi(rois_l)
+        rois = bbox2roi(roi_l)
+        valid = torch.cat(val_l)
         feats = x[:self.bbox_roi_extractor.num_inputs]
-        bbox_feats = self.bbox_roi_extractor(feats, rois)                         # HIP RoIAlign
+        bbox_feats = self.bbox_roi_extractor(feats, rois, valid=valid)                      # HIP RoIAlign, all levels at once
         cls_score, bbox_pred = self.bbox_head(bbox_feats)
-        losses.update(self.bbox_head.loss(cls_score, bbox_pred, torch.cat(labels_l), torch.cat(tgt_l), torch.cat(pos_l)))
+        losses.update(self.bbox_head.loss(cls_score, bbox_pred, torch.cat(lab_l), torch.cat(tgt_l), torch.cat(pos_l), valid))
         if self.mask_head is not None:
-            pos_rois = bbox2roi(pos_boxes)
-            mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois)
+            pos_rois = bbox2roi(m_roi)
+            mvalid = torch.cat(m_val)
+            mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois, valid=mvalid)
             mask_pred = self.mask_head(mask_feats)
             size = cfg.get('mask_size', 28)
             tg = []
             for i in range(nimg):                                                 # mask_target.py:66-122, on device
-                if pos_boxes[i].size(0) == 0:
-                    tg.append(pos_boxes[i].new_zeros((0, size, size)))
+                if m_roi[i].size(0) == 0 or gt_masks[i].size(0) == 0:
+                    tg.append(m_roi[i].new_zeros((m_roi[i].size(0), size, size)))
                     continue
                 m = gt_masks[i].to(torch.bfloat16)[:, None].contiguous()          # 0/1 exact in bf16
-                r = torch.cat([pos_gt_inds[i].to(pos_boxes[i].dtype)[:, None], pos_boxes[i]], 1)
+                r = torch.cat([m_gt[i].to(m_roi[i].dtype)[:, None], m_roi[i]], 1)
                 t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)        # structures.py:353-354
                 tg.append((t[:, 0] >= 0.5).float())
-            losses.update(self.mask_head.loss(mask_pred, torch.cat(tg), torch.cat(pos_labels)))
+            losses.update(self.mask_head.loss(mask_pred, torch.cat(tg), torch.cat(m_lab), mvalid))
         return losses
 
 
@@ -576,7 +639,7 @@ class MaskRCNN(nn.Module):
         cls_scores, bbox_preds = self.rpn_head(x)
         losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_shapes))
         proposal_cfg = _cfg_get(self.train_cfg, 'rpn_proposal', _cfg_get(self.test_cfg, 'rpn'))
-        proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_shapes, proposal_cfg)
+        proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_shapes, proposal_cfg, static=True)
         losses.update(self.roi_head.forward_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks))
         return losses
 

@@ -34,8 +34,8 @@ def nms(boxes, scores, iou_threshold, offset=0, score_threshold=0, max_num=-1):
         ws = torch.empty(lib().swin_nms_workspace_bytes(n), dtype=torch.uint8, device=boxes.device)
         flags = torch.empty(n, dtype=torch.uint8, device=boxes.device)
         cnt = torch.empty(1, dtype=torch.int32, device=boxes.device)
-        call("nms_sorted", _p(bs), n, float(iou_threshold), int(offset), int(max(max_num, 0)), _p(flags), _p(cnt), _p(ws),
-             _s())
+        call("nms_sorted", _p(bs), n, float(iou_threshold), int(offset), int(max(max_num, 0)), _p(flags), _p(cnt), None, 0,
+             _p(ws), _s())
         inds = order[flags.bool()]
     if max_num > 0:
         inds = inds[:max_num]
@@ -81,3 +81,35 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
         if max_num > 0:
             keep, boxes, scores = keep[:max_num], boxes[:max_num], scores[:max_num]
     return torch.cat([boxes, scores[:, None]], -1), keep
+
+
+def nms_static(boxes, scores, iou_threshold, max_num, offset=0):
+    """Fixed-shape variant for callers that slice to ``max_num`` anyway (rpn_head.py:235): returns
+    (inds (max_num,) int64 into the input, valid (max_num,) bool); kept boxes first, in descending-score order.
+    No device->host synchronisation (the dynamic count never leaves the device)."""
+    if not boxes.is_cuda:
+        raise SwinHipError("nms: HIP path needs GPU tensors (no CPU fallback)")
+    boxes = boxes.float()
+    scores = scores.float()
+    n = boxes.size(0)
+    pos = torch.empty(max_num, dtype=torch.int32, device=boxes.device)
+    if n == 0:
+        return torch.zeros(max_num, dtype=torch.long, device=boxes.device), torch.zeros(max_num, dtype=torch.bool, device=boxes.device)
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    bs = boxes.index_select(0, order).contiguous()
+    ws = torch.empty(lib().swin_nms_workspace_bytes(n), dtype=torch.uint8, device=boxes.device)
+    flags = torch.empty(n, dtype=torch.uint8, device=boxes.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=boxes.device)
+    call("nms_sorted", _p(bs), n, float(iou_threshold), int(offset), int(max_num), _p(flags), _p(cnt), _p(pos), int(max_num),
+         _p(ws), _s())
+    valid = pos >= 0
+    return order[pos.clamp(min=0).long()], valid
+
+
+def batched_nms_static(boxes, scores, idxs, iou_threshold, max_num):
+    """batched_nms (single-pass branch, n < split_thr) with a fixed-size result: (dets (max_num,5), valid (max_num,))."""
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    inds, valid = nms_static(boxes + offsets[:, None], scores, iou_threshold, max_num)
+    dets = torch.cat([boxes[inds], scores[inds, None]], -1)
+    return torch.where(valid[:, None], dets, torch.zeros_like(dets)), valid

@@ -88,3 +88,57 @@ class RoIAlign(nn.Module):
     def __repr__(self):
         return (f'{self.__class__.__name__}(output_size={self.output_size}, spatial_scale={self.spatial_scale}, '
                 f'sampling_ratio={self.sampling_ratio}, pool_mode={self.pool_mode}, aligned={self.aligned})')
+
+
+class _RoIAlignMultiLevelFn(torch.autograd.Function):
+    """All pyramid levels in one launch (fwd) / one launch (bwd); see csrc/roi_align.hip."""
+
+    @staticmethod
+    def forward(ctx, rois, lvls, output_size, strides, sampling_ratio, aligned, *feats):
+        import ctypes
+        n = len(feats)
+        assert 1 <= n <= 4
+        f0 = feats[0]
+        if not f0.is_cuda:
+            raise SwinHipError("roi_align_multilevel: GPU tensors only")
+        feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+        C = f0.shape[1]
+        dt = SWIN_F32 if f0.dtype == torch.float32 else SWIN_BF16
+        rois = rois.contiguous().float()
+        lvls = lvls.to(torch.int32).contiguous()
+        K = rois.shape[0]
+        ph, pw = output_size
+        out = torch.empty((K, C, ph, pw), device=f0.device, dtype=torch.float32, memory_format=torch.channels_last)
+        ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
+        Hs = (ctypes.c_int * n)(*[f.shape[2] for f in feats])
+        Ws = (ctypes.c_int * n)(*[f.shape[3] for f in feats])
+        sc = (ctypes.c_float * n)(*[1.0 / s for s in strides])
+        if K > 0:
+            call("roi_align_multilevel_fwd", ptrs, Hs, Ws, sc, n, _p(rois), _p(lvls), _p(out), C, K, ph, pw,
+                 int(sampling_ratio), int(bool(aligned)), dt, _s())
+        ctx.save_for_backward(rois, lvls)
+        ctx.cfg = (n, C, K, ph, pw, tuple(strides), int(sampling_ratio), int(bool(aligned)),
+                   [tuple(f.shape) for f in feats], f0.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        import ctypes
+        rois, lvls = ctx.saved_tensors
+        n, C, K, ph, pw, strides, sr, aligned, shapes, in_dtype = ctx.cfg
+        grads = [torch.empty(s, device=gout.device, dtype=torch.float32, memory_format=torch.channels_last).zero_()
+                 for s in shapes]
+        if K > 0:
+            gout = gout.float().contiguous(memory_format=torch.channels_last)
+            ptrs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+            Hs = (ctypes.c_int * n)(*[s[2] for s in shapes])
+            Ws = (ctypes.c_int * n)(*[s[3] for s in shapes])
+            sc = (ctypes.c_float * n)(*[1.0 / s for s in strides])
+            call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, n, _p(gout), _p(rois), _p(lvls), C, K, ph, pw, sr, aligned, _s())
+        return (None, None, None, None, None, None) + tuple(g.to(in_dtype) for g in grads)
+
+
+def roi_align_multilevel(feats, rois, lvls, output_size, strides, sampling_ratio=0, aligned=True):
+    """feats: list of (N,C,H_l,W_l) channels-last maps; rois (K,5); lvls (K,) level per RoI (< 0: skip, zero row).
+    -> (K, C, ph, pw) float32 (channels-last).  Same arithmetic as RoIAlign level by level."""
+    return _RoIAlignMultiLevelFn.apply(rois, lvls, _pair(output_size), tuple(strides), sampling_ratio, aligned, *feats)

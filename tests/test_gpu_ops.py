@@ -419,3 +419,63 @@ def test_linear_wgrad_bf16(ops, T, N1, N2):
     close(w1.grad, w0.grad, bf16_tol(w0.grad, 2), msg="dW")      # fp32 accumulation, one bf16 rounding at the end
     close(x1.grad, x0.grad, bf16_tol(x0.grad, 3), msg="dx")
     close(b1.grad, b0.grad, bf16_tol(b0.grad, 2), msg="db")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("out_size", [7, 14])
+def test_roi_align_multilevel(ops, dtype, out_size):
+    """One launch over the pyramid == per-level mmcv roi_align on the rois of that level (single_level_roi_extractor.py
+    :84-107); lvl = -1 rows are skipped (zero output, no gradient)."""
+    rng = np.random.RandomState(31)
+    N, C = 2, 8
+    strides = [4, 8, 16, 32]
+    shapes = [(48, 64), (24, 32), (12, 16), (6, 8)]
+    feats_np = [rng.randn(N, C, h, w).astype(np.float32) for h, w in shapes]
+    if dtype == torch.bfloat16:
+        feats_np = [torch.from_numpy(f).bfloat16().float().numpy() for f in feats_np]
+    K = 90
+    rois = _rand_rois(rng, K, N, 256, 192)
+    lvls = rng.randint(-1, 4, K).astype(np.int32)
+    lvls[:4] = [0, 1, 2, 3]
+    feats = [torch.from_numpy(f).cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for f in feats_np]
+    out = ops.roi_align_multilevel(feats, torch.from_numpy(rois).cuda(), torch.from_numpy(lvls).cuda(), out_size, strides, 0, True)
+    assert out.dtype == torch.float32 and out.shape == (K, C, out_size, out_size)
+    ref = np.zeros((K, C, out_size, out_size), np.float32)
+    for l in range(4):
+        sel = np.nonzero(lvls == l)[0]
+        ref[sel] = D.roi_align_c(feats_np[l], rois[sel], out_size, 1.0 / strides[l], 0, True)
+    close(out, torch.from_numpy(ref), ATOL32)
+    gy = rng.randn(*ref.shape).astype(np.float32)
+    (out * torch.from_numpy(gy).cuda()).sum().backward()
+    for l in range(4):
+        sel = np.nonzero(lvls == l)[0]
+        gref = D.roi_align_bwd_c(gy[sel], rois[sel], feats_np[l].shape, 1.0 / strides[l], 0, True)
+        assert feats[l].grad is not None and feats[l].grad.dtype == dtype
+        if dtype == torch.float32:
+            close(feats[l].grad, torch.from_numpy(gref).float(), 2e-4, 1e-4)
+        else:   # fp32 accumulation, one rounding to bf16 at the end: <= 1/2 ulp(bf16) = 2^-9 relative
+            close(feats[l].grad.float(), torch.from_numpy(gref).float(), 2e-4, 2.0 ** -8)
+
+
+def test_nms_static_matches_dynamic(ops):
+    """Fixed-size form: first max_num kept indices, -1 / invalid padded; identical to the dynamic result's prefix."""
+    rng = np.random.RandomState(33)
+    for n, m in [(3000, 1000), (500, 1000), (70, 64), (1, 5)]:
+        xy = rng.rand(n, 2).astype(np.float32) * 400
+        boxes = np.concatenate([xy, xy + rng.rand(n, 2).astype(np.float32) * 80 + 1], 1)
+        scores = rng.rand(n).astype(np.float32)
+        dref, kref = D.nms_c(boxes, scores, 0.7)
+        inds, valid = ops.nms_static(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.7, m)
+        assert inds.shape == (m,) and valid.shape == (m,)
+        k = min(m, len(kref))
+        assert int(valid.sum()) == k and bool(valid[:k].all())
+        np.testing.assert_array_equal(inds[:k].cpu().numpy(), kref[:k])
+        # batched (class-aware offsets, nms.py:258-262 of mmcv)
+        idxs = rng.randint(0, 3, n)
+        bref, bkeep = D.batched_nms(boxes, scores, idxs, dict(type='nms', iou_threshold=0.7))
+        dets, v = ops.batched_nms_static(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(),
+                                         torch.from_numpy(idxs).cuda(), 0.7, m)
+        k = min(m, len(bkeep))
+        assert dets.shape == (m, 5) and int(v.sum()) == k
+        np.testing.assert_array_equal(dets[:k].cpu().numpy(), bref[:k])

@@ -173,3 +173,23 @@ def test_shadow_params_and_gradient_gather():
         np.testing.assert_allclose(sh.shadows[0].detach().float().numpy(), lin1.weight.detach().bfloat16().float().numpy())
     finally:
         sh.release()
+
+
+def test_sample_static_counts_and_order():
+    """Fixed-size sampler: same counts as RandomSampler (random_sampler.py:31-78); positives first, then negatives,
+    then invalid padding; never picks ignored (-1) entries."""
+    from swin_transformer_object_detection_amd.detector import sample_static
+    torch.manual_seed(0)
+    for n_pos, n_neg, n_ign, num, frac in [(10, 1000, 50, 256, 0.5), (300, 1000, 0, 256, 0.5), (5, 20, 3, 512, 0.25),
+                                           (0, 40, 0, 64, 0.25), (200, 30, 0, 256, 0.5)]:
+        a = torch.cat([torch.randint(1, 5, (n_pos,)), torch.zeros(n_neg, dtype=torch.long), -torch.ones(n_ign, dtype=torch.long)])
+        a = a[torch.randperm(a.numel())]
+        idx, is_pos, valid = sample_static(a, num, frac)
+        k = min(num, a.numel())
+        assert idx.shape == (k,)
+        exp_pos = min(n_pos, int(num * frac))
+        exp_neg = min(n_neg, num - exp_pos)
+        assert int(is_pos.sum()) == exp_pos and int(valid.sum()) == exp_pos + exp_neg
+        assert bool((a[idx[is_pos]] > 0).all()) and bool((a[idx[valid & ~is_pos]] == 0).all())
+        assert bool(is_pos[:exp_pos].all()) and bool(valid[:exp_pos + exp_neg].all())
+        assert idx[valid].unique().numel() == exp_pos + exp_neg
