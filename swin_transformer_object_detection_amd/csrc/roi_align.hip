@@ -140,71 +140,143 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const T* __restrict__ 
     }
 }
 
-// NHWC backward.  One block per RoI, threads = channels (256-byte contiguous atomics per wave).  The bilinear
-// weights are separable, so instead of 4 atomics per SAMPLE the block first sums, per bin row / bin column, the
-// 1-D weights every sample puts on each feature row / column (LDS), and then issues one atomic per touched PIXEL
-// of the bin footprint with weight Wy*Wx -- (grid+1)^2 instead of 4*grid^2 atomics per bin.  The atomic rate is
-// the bound of this kernel (guide G12), so fewer atomic bytes is the lever.
-#define RA_MAXF 8        // footprint rows/cols per bin held in LDS; larger sampling grids take the per-sample path
+// NHWC backward.  grid (K, S): the blocks of one RoI share its footprint rows (y % S), threads = channels
+// (256-byte contiguous atomics per wave).  The bilinear weights are separable: per bin row / bin column the block
+// first sums the 1-D weights every sample puts on each feature row / column (LDS tables), then walks the PIXELS of
+// the RoI footprint, gathers for each pixel the <= 2x2 bins whose footprints contain it and issues ONE atomic per
+// (pixel, channel).  The atomic rate bounds this kernel (guide G12): 4*grid^2 atomics per bin in the per-sample
+// form, (grid+1)^2 per bin when scattering per bin, ~grid^2 here (adjacent bins share their border pixels).
 #define RA_MAXP 16       // pooled size limit of the fast path (7 and 14 in every swin config)
+#define RA_MAXT 352      // RoI footprint rows/cols covered by the tables (1333 / 4 = 334)
+#define RA_MAXW (RA_MAXT + 3 * RA_MAXP)   // ragged per-bin weight table of one axis
 
-__device__ __forceinline__ void axis_weights(float start, float bin, int b, int grid, int size, float* Wt, int& p0, int& np,
-                                             bool& overflow) {
-    // accumulate the weights of the `grid` samples of bin b along one axis; border rules of bilinear_interpolate
-    p0 = -1; np = 0;
-    for (int f = 0; f < RA_MAXF; ++f) Wt[f] = 0.f;
-    for (int g = 0; g < grid; ++g) {
-        float t = start + (float)b * bin + ((float)g + .5f) * bin / (float)grid;
-        if (t < -1.0f || t > (float)size) continue;
-        if (t <= 0.f) t = 0.f;
-        int lo = (int)t, hi;
-        if (lo >= size - 1) { hi = lo = size - 1; t = (float)lo; } else hi = lo + 1;
-        float l = t - (float)lo, hgh = 1.f - l;
-        if (p0 < 0) p0 = lo;
-        int a = lo - p0, bb = hi - p0;
-        if (bb >= RA_MAXF) { overflow = true; return; }
-        Wt[a] += hgh; Wt[bb] += l;
-        np = bb + 1 > np ? bb + 1 : np;
-    }
-    if (p0 < 0) p0 = 0;
+// one sample of bilinear_interpolate along one axis: false = contributes nothing; else pixels lo/hi, weights hgh/l
+__device__ __forceinline__ bool axis_sample(float t, int size, int& lo, int& hi, float& l, float& hgh) {
+    if (t < -1.0f || t > (float)size) return false;
+    if (t <= 0.f) t = 0.f;
+    lo = (int)t;
+    if (lo >= size - 1) { hi = lo = size - 1; t = (float)lo; } else hi = lo + 1;
+    l = t - (float)lo; hgh = 1.f - l;
+    return true;
 }
 
-__global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restrict__ gout, const float* __restrict__ rois,
-                                                          float* __restrict__ gin, int C, int H, int W, int K,
-                                                          int ph, int pw, float scale, int sr, int aligned) {
-    __shared__ float Wy[RA_MAXP][RA_MAXF], Wx[RA_MAXP][RA_MAXF];
-    __shared__ int Y0[RA_MAXP], NY[RA_MAXP], X0[RA_MAXP], NX[RA_MAXP];
-    __shared__ int slow;
-    const int k = blockIdx.x, t = threadIdx.x;
-    RoiGeom g = roi_geom(rois + 5 * (int64_t)k, scale, aligned, ph, pw, sr);
-    if (t == 0) slow = (ph > RA_MAXP || pw > RA_MAXP) ? 1 : 0;
-    __syncthreads();
-    if (!slow) {
-        bool ov = false;
-        if (t < ph) axis_weights(g.start_h, g.bin_h, t, g.grid_h, H, Wy[t], Y0[t], NY[t], ov);
-        else if (t >= 32 && t < 32 + pw) axis_weights(g.start_w, g.bin_w, t - 32, g.grid_w, W, Wx[t - 32], X0[t - 32], NX[t - 32], ov);
-        if (ov) slow = 1;
+struct RoiBwdLds {
+    float Wy[RA_MAXW], Wx[RA_MAXW];                       // ragged: bin i owns [off[i], off[i] + N[i])
+    int Y0[RA_MAXP], NY[RA_MAXP], YO[RA_MAXP], X0[RA_MAXP], NX[RA_MAXP], XO[RA_MAXP];
+    unsigned char ylo[RA_MAXT], yhi[RA_MAXT], xlo[RA_MAXT], xhi[RA_MAXT];
+    int ymin, ymax, xmin, xmax, slow;
+    float R[RA_MAXP][256];      // per-thread (channel) row intermediates of the separable form
+};
+
+// pixel extent [p0, p0 + np) touched by the samples of bin b along one axis
+__device__ __forceinline__ void axis_extent(float start, float bin, int b, int grid, int size, int& p0, int& np) {
+    int first = 1 << 30, last = -1;
+    for (int g = 0; g < grid; ++g) {
+        int lo, hi; float l, h;
+        if (!axis_sample(start + (float)b * bin + ((float)g + .5f) * bin / (float)grid, size, lo, hi, l, h)) continue;
+        first = lo < first ? lo : first; last = hi > last ? hi : last;
+    }
+    if (last < 0) { p0 = 0; np = 0; } else { p0 = first; np = last - first + 1; }
+}
+
+__device__ __forceinline__ void axis_fill(float start, float bin, int b, int grid, int size, float* Wt, int p0, int np) {
+    for (int f = 0; f < np; ++f) Wt[f] = 0.f;
+    for (int g = 0; g < grid; ++g) {
+        int lo, hi; float l, h;
+        if (!axis_sample(start + (float)b * bin + ((float)g + .5f) * bin / (float)grid, size, lo, hi, l, h)) continue;
+        Wt[lo - p0] += h; Wt[hi - p0] += l;
+    }
+}
+
+// bins (first, last+1) whose footprint [P0[i], P0[i]+NP[i]) contains pixel p
+__device__ __forceinline__ void bin_range(const int* P0, const int* NP, int nb, int p, unsigned char& lo, unsigned char& hi) {
+    int l = nb, h = 0;
+    for (int i = 0; i < nb; ++i)
+        if (p >= P0[i] && p < P0[i] + NP[i]) { l = i < l ? i : l; h = i + 1; }
+    lo = (unsigned char)(l < h ? l : 0); hi = (unsigned char)h;
+}
+
+__device__ __forceinline__ void roi_bwd_body(RoiBwdLds& L, float* __restrict__ gin, const float* __restrict__ gout,
+                                             const float* __restrict__ roi, int64_t k, int C, int H, int W, int ph, int pw,
+                                             float scale, int sr, int aligned) {
+    const int t = threadIdx.x;
+    RoiGeom g = roi_geom(roi, scale, aligned, ph, pw, sr);
+    const bool fast = ph <= RA_MAXP && pw <= RA_MAXP;
+    if (fast) {
+        if (t < ph) axis_extent(g.start_h, g.bin_h, t, g.grid_h, H, L.Y0[t], L.NY[t]);
+        else if (t >= 32 && t < 32 + pw) axis_extent(g.start_w, g.bin_w, t - 32, g.grid_w, W, L.X0[t - 32], L.NX[t - 32]);
     }
     __syncthreads();
+    if (t == 0) {
+        int slow = fast ? 0 : 1;
+        if (fast) {
+            int y0 = 1 << 30, y1 = 0, x0 = 1 << 30, x1 = 0, oy = 0, ox = 0;
+            for (int i = 0; i < ph; ++i) {
+                L.YO[i] = oy; oy += L.NY[i];
+                if (L.NY[i] > 0) { y0 = min(y0, L.Y0[i]); y1 = max(y1, L.Y0[i] + L.NY[i]); }
+            }
+            for (int j = 0; j < pw; ++j) {
+                L.XO[j] = ox; ox += L.NX[j];
+                if (L.NX[j] > 0) { x0 = min(x0, L.X0[j]); x1 = max(x1, L.X0[j] + L.NX[j]); }
+            }
+            if (y1 <= y0 || x1 <= x0) { y0 = y1 = x0 = x1 = 0; }
+            L.ymin = y0; L.ymax = y1; L.xmin = x0; L.xmax = x1;
+            if (y1 - y0 > RA_MAXT || x1 - x0 > RA_MAXT || oy > RA_MAXW || ox > RA_MAXW) slow = 1;
+        }
+        L.slow = slow;
+    }
+    __syncthreads();
+    if (!L.slow) {
+        if (t < ph) axis_fill(g.start_h, g.bin_h, t, g.grid_h, H, L.Wy + L.YO[t], L.Y0[t], L.NY[t]);
+        else if (t >= 32 && t < 32 + pw) axis_fill(g.start_w, g.bin_w, t - 32, g.grid_w, W, L.Wx + L.XO[t - 32], L.X0[t - 32], L.NX[t - 32]);
+    }
     float* base = gin + (int64_t)g.batch * H * W * C;
-    const float inv = 1.0f / g.count;
-    for (int c = t; c < C; c += 256) {
-        const float* go = gout + (int64_t)k * ph * pw * C + c;
-        if (!slow) {
-            for (int i = 0; i < ph; ++i)
-                for (int j = 0; j < pw; ++j) {
-                    const float gv = go[(i * pw + j) * C] * inv;
-                    for (int fy = 0; fy < NY[i]; ++fy) {
-                        const float wy = Wy[i][fy];
-                        if (wy == 0.f) continue;
-                        float* rowp = base + ((int64_t)(Y0[i] + fy) * W + X0[j]) * C + c;
-                        for (int fx = 0; fx < NX[j]; ++fx) {
-                            const float w = wy * Wx[j][fx];
-                            if (w != 0.f) atomicAdd(rowp + (int64_t)fx * C, gv * w);
+    const float* gob = gout + k * ph * pw * C;
+    if (!L.slow) {
+        const int ny = L.ymax - L.ymin, nx = L.xmax - L.xmin;
+        for (int q = t; q < ny; q += 256) bin_range(L.Y0, L.NY, ph, L.ymin + q, L.ylo[q], L.yhi[q]);
+        for (int q = t; q < nx; q += 256) bin_range(L.X0, L.NX, pw, L.xmin + q, L.xlo[q], L.xhi[q]);
+        __syncthreads();
+        const float inv = 1.0f / g.count;
+        for (int c = t; c < C; c += 256) {
+            for (int ry = blockIdx.y; ry < ny; ry += gridDim.y) {
+                const int y = L.ymin + ry, ilo = L.ylo[ry], ihi = L.yhi[ry];
+                // separable step 1: R[j] = sum_i Wy[i][y] * gout[i][j][c] for this feature row (pw independent loads
+                // per bin row, issued back to back); kept in this thread's LDS column
+                if (ihi - ilo <= 2) {
+                    const int i0 = ilo, i1 = (ilo + 1 < ihi) ? ilo + 1 : ilo;
+                    const int f0 = y - L.Y0[i0], f1 = y - L.Y0[i1];
+                    const float w0 = (ihi > ilo && f0 >= 0 && f0 < L.NY[i0]) ? L.Wy[L.YO[i0] + f0] : 0.f;
+                    const float w1 = (i1 != i0 && f1 >= 0 && f1 < L.NY[i1]) ? L.Wy[L.YO[i1] + f1] : 0.f;
+                    const float* g0 = gob + (int64_t)i0 * pw * C + c;
+                    const float* g1 = gob + (int64_t)i1 * pw * C + c;
+                    for (int j = 0; j < pw; ++j) L.R[j][t] = w0 * g0[j * C] + w1 * g1[j * C];
+                } else {
+                    for (int j = 0; j < pw; ++j) {
+                        float r = 0.f;
+                        for (int i = ilo; i < ihi; ++i) {
+                            const int fy = y - L.Y0[i];
+                            if (fy >= 0 && fy < L.NY[i]) r += L.Wy[L.YO[i] + fy] * gob[((int64_t)i * pw + j) * C + c];
                         }
+                        L.R[j][t] = r;
                     }
                 }
-        } else {        // per-sample path (very large sampling grids)
+                // step 2: one atomic per pixel of the row
+                float* rowp = base + ((int64_t)y * W + L.xmin) * C + c;
+                for (int rx = 0; rx < nx; ++rx) {
+                    const int x = L.xmin + rx, jlo = L.xlo[rx], jhi = L.xhi[rx];
+                    float acc = 0.f;
+                    for (int j = jlo; j < jhi; ++j) {
+                        const int fx = x - L.X0[j];
+                        if (fx >= 0 && fx < L.NX[j]) acc += L.Wx[L.XO[j] + fx] * L.R[j][t];
+                    }
+                    if (acc != 0.f) atomicAdd(rowp + (int64_t)rx * C, acc * inv);
+                }
+            }
+        }
+    } else if (blockIdx.y == 0) {        // per-sample path (very large sampling grids / footprints)
+        for (int c = t; c < C; c += 256) {
+            const float* go = gob + c;
             for (int i = 0; i < ph; ++i)
                 for (int j = 0; j < pw; ++j) {
                     const float gv = go[(i * pw + j) * C];
@@ -224,6 +296,14 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restric
                 }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restrict__ gout, const float* __restrict__ rois,
+                                                          float* __restrict__ gin, int C, int H, int W, int K,
+                                                          int ph, int pw, float scale, int sr, int aligned) {
+    __shared__ RoiBwdLds L;
+    const int64_t k = blockIdx.x;
+    roi_bwd_body(L, gin, gout, rois + 5 * k, k, C, H, W, ph, pw, scale, sr, aligned);
 }
 
 // ----------------------------------------------------------------------------- multi-level (FPN) NHWC
@@ -277,61 +357,17 @@ struct MLGrads { float* p[4]; int H[4], W[4]; float scale[4]; };
 __global__ __launch_bounds__(256) void roi_align_ml_bwd_nhwc(MLGrads G, const float* __restrict__ gout, const float* __restrict__ rois,
                                                              const int* __restrict__ lvl, int C, int K, int ph, int pw, int sr,
                                                              int aligned) {
-    __shared__ float Wy[RA_MAXP][RA_MAXF], Wx[RA_MAXP][RA_MAXF];
-    __shared__ int Y0[RA_MAXP], NY[RA_MAXP], X0[RA_MAXP], NX[RA_MAXP];
-    __shared__ int slow;
-    const int k = blockIdx.x, t = threadIdx.x;
+    __shared__ RoiBwdLds L;
+    const int64_t k = blockIdx.x;
     const int l = lvl[k];
     if (l < 0) return;
-    const int H = G.H[l], W = G.W[l];
-    RoiGeom g = roi_geom(rois + 5 * (int64_t)k, G.scale[l], aligned, ph, pw, sr);
-    if (t == 0) slow = (ph > RA_MAXP || pw > RA_MAXP) ? 1 : 0;
-    __syncthreads();
-    if (!slow) {
-        bool ov = false;
-        if (t < ph) axis_weights(g.start_h, g.bin_h, t, g.grid_h, H, Wy[t], Y0[t], NY[t], ov);
-        else if (t >= 32 && t < 32 + pw) axis_weights(g.start_w, g.bin_w, t - 32, g.grid_w, W, Wx[t - 32], X0[t - 32], NX[t - 32], ov);
-        if (ov) slow = 1;
-    }
-    __syncthreads();
-    float* base = G.p[l] + (int64_t)g.batch * H * W * C;
-    const float inv = 1.0f / g.count;
-    for (int c = t; c < C; c += 256) {
-        const float* go = gout + (int64_t)k * ph * pw * C + c;
-        if (!slow) {
-            for (int i = 0; i < ph; ++i)
-                for (int j = 0; j < pw; ++j) {
-                    const float gv = go[(i * pw + j) * C] * inv;
-                    for (int fy = 0; fy < NY[i]; ++fy) {
-                        const float wy = Wy[i][fy];
-                        if (wy == 0.f) continue;
-                        float* rowp = base + ((int64_t)(Y0[i] + fy) * W + X0[j]) * C + c;
-                        for (int fx = 0; fx < NX[j]; ++fx) {
-                            const float w = wy * Wx[j][fx];
-                            if (w != 0.f) atomicAdd(rowp + (int64_t)fx * C, gv * w);
-                        }
-                    }
-                }
-        } else {
-            for (int i = 0; i < ph; ++i)
-                for (int j = 0; j < pw; ++j) {
-                    const float gv = go[(i * pw + j) * C];
-                    for (int iy = 0; iy < g.grid_h; ++iy) {
-                        float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
-                        for (int ix = 0; ix < g.grid_w; ++ix) {
-                            float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
-                            Bilin b = bilin_setup(H, W, y, x);
-                            if (!b.valid) continue;
-                            float* p = base + c;
-                            atomicAdd(p + ((int64_t)b.yl * W + b.xl) * C, gv * b.w1 / g.count);
-                            atomicAdd(p + ((int64_t)b.yl * W + b.xh) * C, gv * b.w2 / g.count);
-                            atomicAdd(p + ((int64_t)b.yh * W + b.xl) * C, gv * b.w3 / g.count);
-                            atomicAdd(p + ((int64_t)b.yh * W + b.xh) * C, gv * b.w4 / g.count);
-                        }
-                    }
-                }
-        }
-    }
+    roi_bwd_body(L, G.p[l], gout, rois + 5 * k, k, C, G.H[l], G.W[l], ph, pw, G.scale[l], sr, aligned);
+}
+
+// row splits per RoI: enough blocks to fill the chip when K is small
+static inline int ra_row_splits(int K) {
+    int s = 4096 / (K > 0 ? K : 1);
+    return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 
 static inline int ra_blocks(int64_t n) {
@@ -378,7 +414,7 @@ extern "C" int roi_align_bwd(const float* grad_output, const float* rois, float*
     hipStream_t s = (hipStream_t)stream;
     int64_t total = (int64_t)K * C * ph * pw;
     if (channels_last)
-        roi_align_bwd_nhwc<<<K, 256, 0, s>>>(grad_output, rois, grad_input, C, H, W, K, ph, pw, spatial_scale,
+        roi_align_bwd_nhwc<<<dim3(K, ra_row_splits(K)), 256, 0, s>>>(grad_output, rois, grad_input, C, H, W, K, ph, pw, spatial_scale,
                                              sampling_ratio, aligned);
     else
         roi_align_bwd_nchw<<<ra_blocks(total), 256, 0, s>>>(grad_output, rois, grad_input, C, H, W, total, ph, pw,
@@ -425,6 +461,6 @@ extern "C" int roi_align_multilevel_bwd(float* const* grads, const int* Hs, cons
         G.p[l] = grads[m]; G.H[l] = Hs[m]; G.W[l] = Ws[m]; G.scale[l] = scales[m];
         if (!G.p[l]) return SWIN_ERR_BAD_ARG;
     }
-    roi_align_ml_bwd_nhwc<<<K, 256, 0, (hipStream_t)stream>>>(G, grad_output, rois, lvl, C, K, ph, pw, sampling_ratio, aligned);
+    roi_align_ml_bwd_nhwc<<<dim3(K, ra_row_splits(K)), 256, 0, (hipStream_t)stream>>>(G, grad_output, rois, lvl, C, K, ph, pw, sampling_ratio, aligned);
     return swin_launch_status();
 }

@@ -292,6 +292,8 @@ def test_roi_align_fwd_bwd(ops, cl, out_size, scale):
     rois = _rand_rois(rng, 60, N, W / scale, H / scale)
     rois[0, 1:] = [5, 5, 5, 5]                 # zero-size roi
     rois[1, 1:] = [1e4, 1e4, 1e4 + 8, 1e4 + 8]  # fully outside
+    rois[2, 1:] = [-20, 10 / scale, W / scale + 30, 10.4 / scale]   # thin, wider than the map: large sampling grid on one axis
+    rois[3, 1:] = [0, 0, W / scale, H / scale]                      # the whole map
     ref = D.roi_align_c(inp, rois, out_size, scale, 0, True)
     mf = torch.channels_last if cl else torch.contiguous_format
     x = torch.from_numpy(inp).cuda().contiguous(memory_format=mf).requires_grad_(True)
@@ -437,6 +439,8 @@ def test_roi_align_multilevel(ops, dtype, out_size):
     rois = _rand_rois(rng, K, N, 256, 192)
     lvls = rng.randint(-1, 4, K).astype(np.int32)
     lvls[:4] = [0, 1, 2, 3]
+    rois[4, 1:] = [0, 40, 255, 46]; lvls[4] = 0          # thin, full-width: 64-px footprint, sampling grid 10 x 1
+    rois[5, 1:] = [0, 0, 255, 191]; lvls[5] = 0          # whole image on the finest level
     feats = [torch.from_numpy(f).cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
              for f in feats_np]
     out = ops.roi_align_multilevel(feats, torch.from_numpy(rois).cuda(), torch.from_numpy(lvls).cuda(), out_size, strides, 0, True)

@@ -26,7 +26,7 @@ def step(sync=False):
     t = time.perf_counter(); losses = model.rpn_head.loss(cls, reg, batch["gt_bboxes"], shapes)
     if sync: torch.cuda.synchronize()
     tick("rpn_loss", t)
-    t = time.perf_counter(); props = model.rpn_head.get_bboxes(cls, reg, shapes, model.train_cfg['rpn_proposal'])
+    t = time.perf_counter(); props = model.rpn_head.get_bboxes(cls, reg, shapes, model.train_cfg['rpn_proposal'], static=True)
     if sync: torch.cuda.synchronize()
     tick("proposals", t)
     t = time.perf_counter(); losses.update(model.roi_head.forward_train(x, props, batch["gt_bboxes"], batch["gt_labels"], batch["gt_masks"]))

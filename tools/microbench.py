@@ -149,6 +149,41 @@ def roi():
         print(f"roi_align 1024 rois lvl{lvl}: fwd {med:7.1f} us  bwd {medb:7.1f} us")
 
 
+def gelu():
+    for (H, W, C, nH) in STAGES:
+        rows, C4 = 2 * H * W, 4 * C
+        h = torch.randn(rows, C4, device="cuda").bfloat16()
+        bb = torch.zeros(C4, device="cuda")
+        medf, _ = timeit(lambda: ops.bias_gelu(h, bb))
+        g = torch.randn_like(h); dx = torch.empty_like(h); db = torch.zeros(C4, device="cuda")
+        medb, _ = timeit(lambda: Fn.call("swin_bias_gelu_bwd", Fn._p(g), Fn._p(h), Fn._p(bb), Fn._p(dx), Fn._p(db), rows, C4, 1, Fn._s()))
+        print(f"bias_gelu rows={rows} C={C4}: fwd {medf:7.1f} us ({4.0 * h.numel() / medf / 1e3:7.1f} GB/s)  "
+              f"bwd {medb:7.1f} us ({6.0 * h.numel() / medb / 1e3:7.1f} GB/s)")
+
+
+def roiml():
+    import ctypes
+    torch.manual_seed(0)
+    feats = [torch.randn(2, 256, 200 // s, 320 // s, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+             for s in (1, 2, 4, 8)]
+    grads = [torch.zeros(f.shape, device="cuda").contiguous(memory_format=torch.channels_last) for f in feats]
+    for K, out in ((1024, 7), (256, 14)):
+        rois = torch.rand(K, 5, device="cuda")
+        rois[:, 0] = (torch.arange(K, device="cuda") >= K // 2).float()
+        wh = torch.exp(torch.rand(K, 2, device="cuda") * 4.0 + 2.5)          # 12 .. 660 px
+        rois[:, 1:3] = rois[:, 1:3] * torch.tensor([1280., 800.], device="cuda") * 0.8
+        rois[:, 3:] = torch.minimum(rois[:, 1:3] + wh, torch.tensor([1279., 799.], device="cuda"))
+        scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+        lv = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(0, 3).int()
+        med, _ = timeit(lambda: ops.roi_align_multilevel(feats, rois, lv, out, [4, 8, 16, 32], 0, True))
+        g = torch.randn(K, 256, out, out, device="cuda").contiguous(memory_format=torch.channels_last)
+        ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in grads])
+        Hs = (ctypes.c_int * 4)(*[t.shape[2] for t in grads]); Ws = (ctypes.c_int * 4)(*[t.shape[3] for t in grads])
+        sc = (ctypes.c_float * 4)(0.25, 0.125, 0.0625, 0.03125)
+        medb, _ = timeit(lambda: Fn.call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, 4, Fn._p(g), Fn._p(rois), Fn._p(lv), 256, K, out, out, 0, 1, Fn._s()), n=10)
+        print(f"roi_align_multilevel K={K} out={out}: fwd {med:7.1f} us  bwd {medb:7.1f} us  levels {torch.bincount(lv, minlength=4).tolist()}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "conv", "ln", "nms", "roi"]
     for w in which:

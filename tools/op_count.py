@@ -26,7 +26,7 @@ shapes = [m['img_shape'] for m in batch["img_metas"]]
 x = run("trunk_fwd", lambda: model.extract_feat(batch["img"]))
 cls, reg = run("rpn_convs", lambda: model.rpn_head(x))
 losses = run("rpn_loss", lambda: model.rpn_head.loss(cls, reg, batch["gt_bboxes"], shapes))
-props = run("proposals", lambda: model.rpn_head.get_bboxes(cls, reg, shapes, model.train_cfg['rpn_proposal']))
+props = run("proposals", lambda: model.rpn_head.get_bboxes(cls, reg, shapes, model.train_cfg['rpn_proposal'], static=True))
 l2 = run("roi_head", lambda: model.roi_head.forward_train(x, props, batch["gt_bboxes"], batch["gt_labels"], batch["gt_masks"]))
 losses.update(l2)
 loss, _ = model.parse_losses(losses)
