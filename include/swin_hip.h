@@ -204,6 +204,24 @@ int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int of
                uint8_t* keep_flags, int32_t* num_kept, int32_t* kept_pos, int kept_cap, void* workspace,
                void* stream);
 
+/* ---- training targets of the detector heads (csrc/det_targets.hip) --------------------------------------------
+ * det_max_iou_assign replaces MaxIoUAssigner.assign (mmdet/core/bbox/assigners/max_iou_assigner.py:128-212 with
+ * BboxOverlaps2D, iou2d_calculator.py) as called from anchor_head.py:215 and standard_roi_head.py:85:
+ *   bboxes (n,4) f32 xyxy, gt_bboxes (g,4) f32, gt_labels (g) i64 or NULL ->
+ *   assigned_gt_inds (n) i64 (-1 ignore / 0 background / k+1), max_overlaps (n) f32, assigned_labels (n) i64 or NULL.
+ *   num_leading_gt: the first rows of bboxes are the gts themselves (add_gt_as_proposals, base_sampler.py:77-84) and
+ *   match themselves; valid (n) u8 or NULL: rows with 0 get -1.  workspace: det_assign_workspace_bytes(n, g).
+ * det_random_sample replaces RandomSampler.sample (random_sampler.py:31-78, base_sampler.py:54-96) with a fixed-size
+ *   result: out_inds (num) i64, out_flags (num) u8 (bit 0 slot used, bit 1 positive), positives first. */
+int64_t det_assign_workspace_bytes(int64_t n, int num_gts);
+int det_max_iou_assign(const float* bboxes, int64_t n, const float* gt_bboxes, int num_gts, const int64_t* gt_labels,
+                       float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
+                       int num_leading_gt, const uint8_t* valid, int64_t* assigned_gt_inds, float* max_overlaps,
+                       int64_t* assigned_labels, void* workspace, void* stream);
+int64_t det_random_sample_workspace_bytes(void);
+int det_random_sample(const int64_t* assigned_gt_inds, int64_t n, int num, int num_pos_max, uint64_t seed,
+                      int64_t* out_inds, uint8_t* out_flags, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

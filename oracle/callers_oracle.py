@@ -150,3 +150,50 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, n
     if max_num > 0:
         dets, keep = dets[:max_num], keep[:max_num]
     return dets, labels[keep]
+
+
+# ---- training targets (checker for csrc/det_targets.hip) ---------------------------------------------------------
+def bbox_overlaps(b1, b2, eps=1e-6):
+    """IoU matrix (len(b1), len(b2)) in float32, operation order of
+    mmdet/core/bbox/iou_calculators/iou2d_calculator.py (bbox_overlaps, mode='iou', is_aligned=False)."""
+    b1 = np.asarray(b1, np.float32).reshape(-1, 4)
+    b2 = np.asarray(b2, np.float32).reshape(-1, 4)
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = np.maximum(b1[:, None, :2], b2[None, :, :2])
+    rb = np.minimum(b1[:, None, 2:], b2[None, :, 2:])
+    wh = np.maximum(rb - lt, np.float32(0))
+    inter = wh[..., 0] * wh[..., 1]
+    union = np.maximum(a1[:, None] + a2[None, :] - inter, np.float32(eps))
+    return (inter / union).astype(np.float32)
+
+
+def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_low_quality=True, gt_labels=None):
+    """MaxIoUAssigner.assign_wrt_overlaps (mmdet/core/bbox/assigners/max_iou_assigner.py:128-212) with
+    ignore_iof_thr=-1, gt_max_assign_all=True.  -> (assigned_gt_inds int64, max_overlaps f32, labels int64 | None)."""
+    bboxes = np.asarray(bboxes, np.float32).reshape(-1, 4)
+    gt_bboxes = np.asarray(gt_bboxes, np.float32).reshape(-1, 4)
+    n, g = len(bboxes), len(gt_bboxes)
+    assigned = np.full(n, -1, np.int64)
+    if g == 0 or n == 0:
+        if g == 0:
+            assigned[:] = 0
+        labels = None if gt_labels is None else np.full(n, -1, np.int64)
+        return assigned, np.zeros(n, np.float32), labels
+    ov = bbox_overlaps(gt_bboxes, bboxes)                 # (g, n)
+    max_ov = ov.max(0)
+    argmax = ov.argmax(0)
+    gt_max = ov.max(1)
+    assigned[(max_ov >= 0) & (max_ov < neg_iou_thr)] = 0
+    pos = max_ov >= pos_iou_thr
+    assigned[pos] = argmax[pos] + 1
+    if match_low_quality:
+        for i in range(g):
+            if gt_max[i] >= min_pos_iou:
+                assigned[ov[i] == gt_max[i]] = i + 1
+    labels = None
+    if gt_labels is not None:
+        labels = np.full(n, -1, np.int64)
+        p = assigned > 0
+        labels[p] = np.asarray(gt_labels, np.int64)[assigned[p] - 1]
+    return assigned, max_ov, labels

@@ -1,0 +1,293 @@
+// Training-target kernels of the detector heads for gfx950: MaxIoUAssigner and RandomSampler on the device, with
+// fixed-size outputs and no host synchronisation.
+// Reference: mmdet/core/bbox/assigners/max_iou_assigner.py:128-212 (assign_wrt_overlaps, ignore_iof_thr = -1,
+// gt_max_assign_all = True), mmdet/core/bbox/iou_calculators/iou2d_calculator.py (bbox_overlaps, mode 'iou',
+// eps 1e-6), mmdet/core/bbox/samplers/random_sampler.py:31-78 (neg_pos_ub = -1), base_sampler.py:54-96.
+// The reference builds the (num_gts, num_boxes) IoU matrix with ~15 elementwise launches and samples with
+// nonzero + randperm (two device->host syncs per image); here the IoU is recomputed in registers (HBM-free) and the
+// sample is the k smallest of per-box hash keys, found with a 4096-bin histogram -> candidate list -> one-block sort.
+#include "common.h"
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float iou_gt_box(const float4 g, const float4 b) {
+    // same operation order as bbox_overlaps: areas, clamp(rb - lt, 0), overlap / max(a1 + a2 - overlap, eps)
+    const float a1 = (g.z - g.x) * (g.w - g.y);
+    const float a2 = (b.z - b.x) * (b.w - b.y);
+    const float w = fmaxf(fminf(g.z, b.z) - fmaxf(g.x, b.x), 0.f);
+    const float h = fmaxf(fminf(g.w, b.w) - fmaxf(g.y, b.y), 0.f);
+    const float inter = w * h;
+    const float uni = fmaxf(a1 + a2 - inter, 1e-6f);
+    return inter / uni;
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { unsigned y = (unsigned)__shfl_xor((int)x, o); x = y > x ? y : x; }
+    return x;
+}
+
+// ---- pass 1: per box max / argmax over the gts, per gt max over the boxes (IoU >= 0: uint order == float order)
+__global__ __launch_bounds__(256) void assign_max_kernel(const float4* __restrict__ boxes, int n, const float4* __restrict__ gts,
+                                                         int G, int n_self, float* __restrict__ max_ov,
+                                                         int* __restrict__ argmax, unsigned* __restrict__ gt_max) {
+    __shared__ float4 sg[256];
+    __shared__ unsigned smax[256];
+    const int t = threadIdx.x, lane = t & 63;
+    const int idx = blockIdx.x * 256 + t;
+    const bool valid = idx < n;
+    const float4 box = valid ? boxes[idx] : float4{0.f, 0.f, 0.f, 0.f};
+    float best = -1.f;
+    int arg = 0;
+    for (int g0 = 0; g0 < G; g0 += 256) {
+        const int cnt = min(256, G - g0);
+        if (t < cnt) { sg[t] = gts[g0 + t]; smax[t] = 0u; }
+        __syncthreads();
+        for (int q = 0; q < cnt; ++q) {
+            const float iou = valid ? iou_gt_box(sg[q], box) : 0.f;
+            if (iou > best) { best = iou; arg = g0 + q; }                // strict: first maximum, as argmax does
+            // leading gt rows are appended AFTER the assignment in the reference: they do not feed the per-gt maximum
+            const unsigned m = wave_max_u32(idx >= n_self ? __float_as_uint(iou) : 0u);
+            if (lane == 0 && m) atomicMax(&smax[q], m);
+        }
+        __syncthreads();
+        if (t < cnt && smax[t]) atomicMax(&gt_max[g0 + t], smax[t]);
+        __syncthreads();
+    }
+    if (valid) { max_ov[idx] = best; argmax[idx] = arg; }
+}
+
+// ---- pass 2: thresholds, low-quality matches (later gts override earlier ones), leading-gt self match, labels
+__global__ __launch_bounds__(256) void assign_final_kernel(const float4* __restrict__ boxes, int n, const float4* __restrict__ gts,
+                                                           int G, const int64_t* __restrict__ gt_labels, float pos_thr,
+                                                           float neg_thr, float min_pos, int low_quality, int n_self,
+                                                           const uint8_t* __restrict__ valid_mask, float* __restrict__ max_ov,
+                                                           const int* __restrict__ argmax, const unsigned* __restrict__ gt_max,
+                                                           int64_t* __restrict__ assigned, int64_t* __restrict__ labels) {
+    __shared__ float4 sg[256];
+    __shared__ float sm[256];
+    const int t = threadIdx.x;
+    const int idx = blockIdx.x * 256 + t;
+    const bool valid = idx < n;
+    const float4 box = valid ? boxes[idx] : float4{0.f, 0.f, 0.f, 0.f};
+    int a = -1;
+    float mo = 0.f;
+    if (G == 0) {
+        a = 0;                                        // no ground truth: everything is background
+    } else {
+        mo = valid ? max_ov[idx] : 0.f;
+        if (mo >= 0.f && mo < neg_thr) a = 0;
+        if (mo >= pos_thr) a = (valid ? argmax[idx] : 0) + 1;
+        if (low_quality) {
+            for (int g0 = 0; g0 < G; g0 += 256) {
+                const int cnt = min(256, G - g0);
+                __syncthreads();
+                if (t < cnt) { sg[t] = gts[g0 + t]; sm[t] = __uint_as_float(gt_max[g0 + t]); }
+                __syncthreads();
+                for (int q = 0; q < cnt; ++q) {
+                    const float gm = sm[q];
+                    if (gm >= min_pos && iou_gt_box(sg[q], box) == gm) a = g0 + q + 1;
+                }
+            }
+        }
+    }
+    if (!valid) return;
+    if (idx < n_self) a = idx + 1;                    // AssignResult.add_gt_: a leading gt box matches itself
+    if (valid_mask && !valid_mask[idx]) a = -1;       // padding slot of a fixed-size proposal list: never sampled
+    if (G == 0) max_ov[idx] = 0.f;
+    else if (idx < n_self) max_ov[idx] = 1.f;
+    assigned[idx] = a;
+    if (labels) labels[idx] = (a > 0 && gt_labels) ? gt_labels[a - 1] : -1;
+}
+
+// ------------------------------------------------------------------------------------------ RandomSampler
+#define DS_BINS 4096
+#define DS_CAP 4096                 // candidates per class: take + (boxes in the threshold bin) ~ num + n / 4096
+
+struct SampleWs {                   // device workspace header (zeroed by the entry point)
+    unsigned hist_pos[DS_BINS], hist_neg[DS_BINS];
+    unsigned cnt_pos, cnt_neg, pad0, pad1;
+    unsigned long long cand_pos[DS_CAP], cand_neg[DS_CAP];
+};
+
+__device__ __forceinline__ unsigned sample_key(unsigned idx, unsigned s0, unsigned s1) {
+    unsigned h = idx * 0x9E3779B1u ^ s0;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h += s1;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void sample_hist_kernel(const int64_t* __restrict__ assigned, int n, unsigned s0, unsigned s1,
+                                                          SampleWs* __restrict__ ws) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int64_t a = assigned[idx];
+    if (a < 0) return;
+    const unsigned bin = sample_key((unsigned)idx, s0, s1) >> 20;
+    atomicAdd(a > 0 ? &ws->hist_pos[bin] : &ws->hist_neg[bin], 1u);
+}
+
+// exclusive prefix over groups of 16 bins (scratch[0..256]) and the class total.  256 threads.
+__device__ __forceinline__ void hist_prefix(const unsigned* __restrict__ hist, int& total, int* scratch) {
+    const int t = threadIdx.x;
+    unsigned s = 0;
+    for (int q = 0; q < DS_BINS / 256; ++q) s += hist[t * (DS_BINS / 256) + q];
+    scratch[t] = (int)s;
+    __syncthreads();
+    if (t == 0) { int acc = 0; for (int q = 0; q < 256; ++q) { int v = scratch[q]; scratch[q] = acc; acc += v; } scratch[256] = acc; }
+    __syncthreads();
+    total = scratch[256];
+}
+
+__device__ __forceinline__ int find_threshold_bin(const unsigned* __restrict__ hist, int take, const int* scratch, int* out) {
+    // scratch[q] = exclusive prefix over groups of 16 bins; every thread owns one group
+    const int t = threadIdx.x;
+    if (t == 0) *out = -1;
+    __syncthreads();
+    if (take > 0) {
+        int acc = scratch[t];
+        const int next = (t == 255) ? scratch[256] : scratch[t + 1];
+        if (acc < take && next >= take) {
+            for (int q = 0; q < DS_BINS / 256; ++q) {
+                acc += (int)hist[t * (DS_BINS / 256) + q];
+                if (acc >= take) { *out = t * (DS_BINS / 256) + q; break; }
+            }
+        }
+    }
+    __syncthreads();
+    return *out;
+}
+
+__global__ __launch_bounds__(256) void sample_collect_kernel(const int64_t* __restrict__ assigned, int n, unsigned s0, unsigned s1,
+                                                             int num, int num_pos_max, SampleWs* __restrict__ ws) {
+    __shared__ int scratch[257];
+    __shared__ int tb;
+    int tot_pos, tot_neg;
+    hist_prefix(ws->hist_pos, tot_pos, scratch);
+    const int take_pos = min(tot_pos, num_pos_max);
+    const int tb_pos = find_threshold_bin(ws->hist_pos, take_pos, scratch, &tb);
+    __syncthreads();
+    hist_prefix(ws->hist_neg, tot_neg, scratch);
+    const int take_neg = min(tot_neg, num - take_pos);
+    const int tb_neg = find_threshold_bin(ws->hist_neg, take_neg, scratch, &tb);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int64_t a = assigned[idx];
+    if (a < 0) return;
+    const unsigned key = sample_key((unsigned)idx, s0, s1);
+    const int bin = (int)(key >> 20);
+    const unsigned long long item = ((unsigned long long)key << 32) | (unsigned)idx;
+    if (a > 0) {
+        if (bin <= tb_pos) { unsigned slot = atomicAdd(&ws->cnt_pos, 1u); if (slot < DS_CAP) ws->cand_pos[slot] = item; }
+    } else {
+        if (bin <= tb_neg) { unsigned slot = atomicAdd(&ws->cnt_neg, 1u); if (slot < DS_CAP) ws->cand_neg[slot] = item; }
+    }
+}
+
+// one workgroup: sort the candidates of each class by (key, index) in LDS and emit the first `take` of each
+__device__ void sort_emit(unsigned long long* buf, const unsigned long long* __restrict__ cand, int cnt, int take, int out_off,
+                          int64_t* __restrict__ out_inds, uint8_t* __restrict__ out_flags, uint8_t flag) {
+    const int t = threadIdx.x;
+    int m = 1;
+    while (m < cnt) m <<= 1;
+    for (int i = t; i < m; i += 1024) buf[i] = i < cnt ? cand[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < m; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = buf[i], y = buf[p];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { buf[i] = y; buf[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = t; i < take; i += 1024) {
+        out_inds[out_off + i] = (int64_t)(unsigned)(buf[i] & 0xFFFFFFFFull);
+        out_flags[out_off + i] = flag;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void sample_select_kernel(SampleWs* __restrict__ ws, int num, int num_pos_max,
+                                                             int64_t* __restrict__ out_inds, uint8_t* __restrict__ out_flags) {
+    __shared__ unsigned long long buf[DS_CAP];
+    __shared__ int tots[2];
+    const int t = threadIdx.x;
+    if (t < 2) tots[t] = 0;
+    __syncthreads();
+    {   // class totals from the histograms
+        unsigned sp = 0, sn = 0;
+        for (int i = t; i < DS_BINS; i += 1024) { sp += ws->hist_pos[i]; sn += ws->hist_neg[i]; }
+        atomicAdd(&tots[0], (int)sp); atomicAdd(&tots[1], (int)sn);
+    }
+    __syncthreads();
+    const int take_pos = min(tots[0], num_pos_max);
+    const int take_neg = min(tots[1], num - take_pos);
+    const int cp = min((int)ws->cnt_pos, DS_CAP), cn = min((int)ws->cnt_neg, DS_CAP);
+    // a full candidate list (cnt > cap) can only lose boxes of the threshold bin; the take is clamped to what is there
+    const int tp = min(take_pos, cp), tn = min(take_neg, cn);
+    sort_emit(buf, ws->cand_pos, cp, tp, 0, out_inds, out_flags, 3);
+    sort_emit(buf, ws->cand_neg, cn, tn, tp, out_inds, out_flags, 1);
+    for (int i = tp + tn + t; i < num; i += 1024) { out_inds[i] = 0; out_flags[i] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int64_t det_assign_workspace_bytes(int64_t n, int num_gts) {
+    if (n < 0) n = 0;
+    if (num_gts < 0) num_gts = 0;
+    return (((int64_t)num_gts * 4 + 255) / 256) * 256 + n * 4 + 256;       // gt_max (u32 per gt) | argmax (i32 per box)
+}
+
+// MaxIoUAssigner.assign: bboxes (n,4) f32 xyxy, gt_bboxes (g,4) f32, gt_labels (g) i64 or NULL.
+// Outputs: assigned_gt_inds (n) i64 (-1 ignore, 0 background, k+1 = gt k), max_overlaps (n) f32,
+// assigned_labels (n) i64 or NULL (-1 where not positive).  num_leading_gt: the first rows of bboxes ARE the gts
+// (add_gt_as_proposals) and match themselves; valid (n) u8 or NULL: 0 forces -1 (padding of fixed-size lists).
+extern "C" int det_max_iou_assign(const float* bboxes, int64_t n, const float* gt_bboxes, int num_gts, const int64_t* gt_labels,
+                                  float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
+                                  int num_leading_gt, const uint8_t* valid, int64_t* assigned_gt_inds, float* max_overlaps,
+                                  int64_t* assigned_labels, void* workspace, void* stream) {
+    if (n == 0) return SWIN_OK;
+    if (!bboxes || n < 0 || num_gts < 0 || !assigned_gt_inds || !max_overlaps || !workspace || (num_gts > 0 && !gt_bboxes))
+        return SWIN_ERR_BAD_ARG;
+    if (n > (int64_t)1 << 30 || num_leading_gt > num_gts) return SWIN_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* gt_max = (unsigned*)workspace;
+    int* argmax = (int*)((char*)workspace + (((int64_t)num_gts * 4 + 255) / 256) * 256);
+    const int blocks = (int)((n + 255) / 256);
+    if (num_gts > 0) {
+        if (hipMemsetAsync(gt_max, 0, (size_t)num_gts * 4, s) != hipSuccess) return SWIN_ERR_LAUNCH;
+        assign_max_kernel<<<blocks, 256, 0, s>>>((const float4*)bboxes, (int)n, (const float4*)gt_bboxes, num_gts, num_leading_gt,
+                                                 max_overlaps, argmax, gt_max);
+    }
+    assign_final_kernel<<<blocks, 256, 0, s>>>((const float4*)bboxes, (int)n, (const float4*)gt_bboxes, num_gts, gt_labels,
+                                               pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality, num_leading_gt, valid,
+                                               max_overlaps, argmax, gt_max, assigned_gt_inds, assigned_labels);
+    return swin_launch_status();
+}
+
+extern "C" int64_t det_random_sample_workspace_bytes(void) { return (int64_t)sizeof(SampleWs); }
+
+// RandomSampler.sample with a fixed-size result: out_inds (num) i64, out_flags (num) u8 (bit 0 = slot used,
+// bit 1 = positive); positives first.  A uniformly random subset of min(#pos, num_pos_max) positives and of
+// min(#neg, num - #taken_pos) negatives, drawn from the counter-based hash of (seed, box index): deterministic
+// for a given seed.  n <= 2^22, num <= 2048 (candidate capacity).
+extern "C" int det_random_sample(const int64_t* assigned_gt_inds, int64_t n, int num, int num_pos_max, uint64_t seed,
+                                 int64_t* out_inds, uint8_t* out_flags, void* workspace, void* stream) {
+    if (num <= 0) return SWIN_OK;
+    if (n < 0 || !out_inds || !out_flags || !workspace || (n > 0 && !assigned_gt_inds) || num_pos_max < 0) return SWIN_ERR_BAD_ARG;
+    if (n > (1 << 22) || num > DS_CAP / 2) return SWIN_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    SampleWs* ws = (SampleWs*)workspace;
+    if (hipMemsetAsync(ws, 0, offsetof(SampleWs, cand_pos), s) != hipSuccess) return SWIN_ERR_LAUNCH;
+    const unsigned s0 = (unsigned)(seed & 0xFFFFFFFFull), s1 = (unsigned)(seed >> 32);
+    if (n > 0) {
+        const int blocks = (int)((n + 255) / 256);
+        sample_hist_kernel<<<blocks, 256, 0, s>>>(assigned_gt_inds, (int)n, s0, s1, ws);
+        sample_collect_kernel<<<blocks, 256, 0, s>>>(assigned_gt_inds, (int)n, s0, s1, num, num_pos_max, ws);
+    }
+    sample_select_kernel<<<1, 1024, 0, s>>>(ws, num, num_pos_max, out_inds, out_flags);
+    return swin_launch_status();
+}

@@ -126,6 +126,13 @@ class AnchorGenerator:
             self._cache[key] = out
         return self._cache[key]
 
+    def grid_anchors_cat(self, featmap_sizes, device):
+        """All levels concatenated (anchor_head.py:451 `torch.cat(anchor_list[i])`), cached like the per-level lists."""
+        key = ('cat', tuple(featmap_sizes), str(device))
+        if key not in self._cache:
+            self._cache[key] = torch.cat(self.grid_anchors(featmap_sizes, device), 0).contiguous()
+        return self._cache[key]
+
 
 def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality=True, gt_labels=None):
     """MaxIoUAssigner.assign_wrt_overlaps (max_iou_assigner.py:130-212), ignore_iof_thr=-1."""
@@ -188,6 +195,31 @@ def sample_static(assigned, num, pos_fraction):
     comb = torch.where(pos_sel, key, torch.where(assigned == 0, key + 1.0, key.new_full((), 3.0)))
     vals, idx = torch.topk(comb, min(num, n), largest=False, sorted=True)
     return idx, vals < 1.0, vals < 3.0
+
+
+def assign_and_sample(bboxes, gt_bboxes, a_cfg, s_cfg, gt_labels=None, num_leading_gt=0, valid=None):
+    """assigner.assign + sampler.sample of one image (anchor_head.py:213-219, standard_roi_head.py:83-93) with a
+    fixed-size result: (idx, is_pos, valid, assigned_gt_inds, assigned_labels).  On the GPU both run as HIP kernels
+    (ops.max_iou_assign / ops.random_sample); the torch forms above are the host restatement used on CPU."""
+    if bboxes.is_cuda:
+        assigned, _, lab = ops.max_iou_assign(bboxes, gt_bboxes, a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'], a_cfg['min_pos_iou'],
+                                              a_cfg.get('match_low_quality', True), gt_labels, num_leading_gt, valid)
+        idx, is_pos, ok = ops.random_sample(assigned, s_cfg['num'], s_cfg['pos_fraction'])
+        return idx, is_pos, ok, assigned, lab
+    g = num_leading_gt
+    assigned, _, lab = max_iou_assign(bboxes[g:], gt_bboxes, a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'], a_cfg['min_pos_iou'],
+                                      a_cfg.get('match_low_quality', True), gt_labels)
+    if g > 0:
+        assigned = torch.cat([torch.arange(1, g + 1, device=assigned.device), assigned], 0)
+        if lab is not None:
+            lab = torch.cat([gt_labels, lab], 0)
+    if valid is not None:
+        assigned = torch.where(valid, assigned, torch.full_like(assigned, -1))
+    idx, is_pos, ok = sample_static(assigned, s_cfg['num'], s_cfg['pos_fraction'])
+    k = s_cfg['num'] - idx.numel()
+    if k > 0:                                   # fewer boxes than samples: pad to the fixed size
+        idx = torch.cat([idx, idx.new_zeros(k)]); is_pos = torch.cat([is_pos, is_pos.new_zeros(k)]); ok = torch.cat([ok, ok.new_zeros(k)])
+    return idx, is_pos, ok, assigned, lab
 
 
 def _cast(t, dtype):
@@ -274,15 +306,13 @@ class RPNHead(nn.Module):
         cfg = self.train_cfg
         a_cfg, s_cfg = cfg['assigner'], cfg['sampler']
         sizes = [tuple(c.shape[-2:]) for c in cls_scores]
-        anchors = torch.cat(self.anchor_generator.grid_anchors(sizes, cls_scores[0].device), 0)
+        anchors = self.anchor_generator.grid_anchors_cat(sizes, cls_scores[0].device)
         B = cls_scores[0].size(0)
         cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1)
         reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
         loss_cls = loss_bbox = total = 0.
         for i in range(B):
-            assigned, _, _ = max_iou_assign(anchors, gt_bboxes[i], a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'],
-                                            a_cfg['min_pos_iou'], a_cfg.get('match_low_quality', True))
-            idx, is_pos, valid = sample_static(assigned, s_cfg['num'], s_cfg['pos_fraction'])
+            idx, is_pos, valid, assigned, _ = assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg)
             a = anchors[idx]
             if gt_bboxes[i].size(0) > 0:
                 g = gt_bboxes[i][(assigned[idx] - 1).clamp(min=0)]
@@ -556,14 +586,8 @@ class StandardRoIHead(nn.Module):
             if s.get('add_gt_as_proposals', True):
                 props = torch.cat([gt_bboxes[i], props], 0)
                 pvalid = torch.cat([torch.ones(g, dtype=torch.bool, device=props.device), pvalid], 0)
-            assigned, _, lab = max_iou_assign(props, gt_bboxes[i], a['pos_iou_thr'], a['neg_iou_thr'], a['min_pos_iou'],
-                                              a.get('match_low_quality', True), gt_labels[i])
-            if s.get('add_gt_as_proposals', True) and g > 0:          # AssignResult.add_gt_: gts match themselves
-                self_ind = torch.arange(1, g + 1, device=assigned.device)
-                assigned = torch.cat([self_ind, assigned[g:]], 0)
-                lab = torch.cat([gt_labels[i], lab[g:]], 0)
-            assigned = torch.where(pvalid, assigned, torch.full_like(assigned, -1))     # padding slots are never sampled
-            idx, is_pos, valid = sample_static(assigned, num, s['pos_fraction'])
+            lead = g if s.get('add_gt_as_proposals', True) else 0
+            idx, is_pos, valid, assigned, lab = assign_and_sample(props, gt_bboxes[i], a, s, gt_labels[i], lead, pvalid)
             boxes = torch.where(valid[:, None], props[idx], props.new_tensor([0., 0., 1., 1.]).expand(idx.numel(), 4))
             gt_ind = (assigned[idx] - 1).clamp(min=0)
             if g > 0:

@@ -1,0 +1,60 @@
+"""Device-side training targets: MaxIoUAssigner and RandomSampler behind the C ABI (csrc/det_targets.hip).
+
+Reference call sites: anchor_head.py:213-219 (assign + sample per image for the RPN), standard_roi_head.py:83-93
+(the same for the RoI head).  Results have fixed shapes, so nothing here synchronises with the host."""
+import torch
+
+from .. import _lib
+from .._lib import SwinHipError, call
+from .functional import _p, _s
+
+
+def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_low_quality=True, gt_labels=None,
+                   num_leading_gt=0, valid=None):
+    """MaxIoUAssigner.assign (max_iou_assigner.py:85-212, ignore_iof_thr=-1, gt_max_assign_all=True).
+
+    bboxes (n,4), gt_bboxes (g,4) float32 xyxy on the GPU -> (assigned_gt_inds (n) int64, max_overlaps (n) float32,
+    assigned_labels (n) int64 or None).  ``num_leading_gt``: the first rows of bboxes are the gts (add_gt_as_proposals)
+    and are matched to themselves, as AssignResult.add_gt_ does.  ``valid`` (n) bool: False rows get -1."""
+    if not bboxes.is_cuda:
+        raise SwinHipError("max_iou_assign: GPU tensors only")
+    if isinstance(neg_iou_thr, (tuple, list)):
+        raise SwinHipError("max_iou_assign: a (lo, hi) neg_iou_thr range is not supported")
+    bboxes = bboxes.detach().float().contiguous()
+    gt_bboxes = gt_bboxes.detach().float().contiguous()
+    n, g = bboxes.size(0), gt_bboxes.size(0)
+    assigned = torch.empty(n, dtype=torch.long, device=bboxes.device)
+    max_ov = torch.empty(n, dtype=torch.float32, device=bboxes.device)
+    labels = torch.empty(n, dtype=torch.long, device=bboxes.device) if gt_labels is not None else None
+    if n == 0:
+        return assigned, max_ov, labels
+    ws = torch.empty(_lib.lib().det_assign_workspace_bytes(n, g), dtype=torch.uint8, device=bboxes.device)
+    gl = gt_labels.long().contiguous() if gt_labels is not None else None
+    vm = valid.to(torch.uint8).contiguous() if valid is not None else None
+    call("det_max_iou_assign", _p(bboxes), n, _p(gt_bboxes) if g else None, g, _p(gl) if gl is not None and g else None,
+         float(pos_iou_thr), float(neg_iou_thr), float(min_pos_iou), int(bool(match_low_quality)), int(num_leading_gt),
+         _p(vm) if vm is not None else None, _p(assigned), _p(max_ov), _p(labels) if labels is not None else None, _p(ws), _s())
+    return assigned, max_ov, labels
+
+
+def _next_seed():
+    """64-bit seed drawn on the HOST from torch's CPU generator (follows torch.manual_seed; no device op, no sync)."""
+    return int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64))
+
+
+def random_sample(assigned_gt_inds, num, pos_fraction, seed=None):
+    """RandomSampler.sample (random_sampler.py:31-78, neg_pos_ub=-1) with a fixed-size result.
+
+    -> (inds (num,) int64, is_pos (num,) bool, valid (num,) bool): a uniformly random subset of
+    min(#pos, int(num * pos_fraction)) positives first, then uniformly random negatives up to ``num`` in total;
+    unused slots have valid == False."""
+    a = assigned_gt_inds
+    if not a.is_cuda:
+        raise SwinHipError("random_sample: GPU tensors only")
+    a = a.long().contiguous()
+    inds = torch.empty(num, dtype=torch.long, device=a.device)
+    flags = torch.empty(num, dtype=torch.uint8, device=a.device)
+    ws = torch.empty(_lib.lib().det_random_sample_workspace_bytes(), dtype=torch.uint8, device=a.device)
+    call("det_random_sample", _p(a) if a.numel() else None, a.numel(), int(num), int(num * pos_fraction),
+         _next_seed() if seed is None else int(seed), _p(inds), _p(flags), _p(ws), _s())
+    return inds, flags >= 2, flags >= 1

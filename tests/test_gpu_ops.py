@@ -483,3 +483,85 @@ def test_nms_static_matches_dynamic(ops):
         k = min(m, len(bkeep))
         assert dets.shape == (m, 5) and int(v.sum()) == k
         np.testing.assert_array_equal(dets[:k].cpu().numpy(), bref[:k])
+
+
+# ------------------------------------------------------------------------------------------
+# training targets: assigner / sampler kernels
+# ------------------------------------------------------------------------------------------
+def _boxes(rng, n, size=640.0, wh=160.0):
+    xy = rng.rand(n, 2).astype(np.float32) * size
+    return np.concatenate([xy, xy + rng.rand(n, 2).astype(np.float32) * wh + 2], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,g,pos,neg,minpos,lowq", [(20000, 8, 0.7, 0.3, 0.3, True), (1000, 5, 0.5, 0.5, 0.5, False),
+                                                      (3000, 300, 0.6, 0.4, 0.0, True), (77, 1, 0.5, 0.5, 0.5, True),
+                                                      (500, 0, 0.7, 0.3, 0.3, True)])
+def test_max_iou_assign_bit_exact(ops, n, g, pos, neg, minpos, lowq):
+    """Device MaxIoUAssigner == the numpy restatement of max_iou_assigner.py:128-212, index for index."""
+    rng = np.random.RandomState(n + g)
+    boxes, gts = _boxes(rng, n), _boxes(rng, g)
+    if g:
+        boxes[5] = gts[0]                       # an exact match (IoU 1) and a duplicate of it (tie on the gt maximum)
+        boxes[9] = gts[0]
+    labels = rng.randint(0, 80, g)
+    a_ref, m_ref, l_ref = CO.max_iou_assign(boxes, gts, pos, neg, minpos, lowq, labels)
+    a, m, l = ops.max_iou_assign(dev(torch.from_numpy(boxes)), dev(torch.from_numpy(gts)), pos, neg, minpos, lowq,
+                                 dev(torch.from_numpy(labels)))
+    np.testing.assert_array_equal(a.cpu().numpy(), a_ref)
+    np.testing.assert_array_equal(l.cpu().numpy(), l_ref)
+    np.testing.assert_array_equal(m.cpu().numpy(), m_ref)          # same fp32 operation order: bit-exact IoU
+
+
+def test_max_iou_assign_leading_gts_and_valid_mask(ops):
+    """add_gt_as_proposals (base_sampler.py:77-84): the gt rows are appended to the ASSIGNED result, i.e. they match
+    themselves and do not take part in the per-gt maxima; padding slots (valid == 0) are never assigned."""
+    rng = np.random.RandomState(5)
+    g, n = 6, 400
+    gts, props = _boxes(rng, g), _boxes(rng, n)
+    labels = rng.randint(0, 80, g)
+    valid = rng.rand(n) > 0.2
+    a_ref, m_ref, l_ref = CO.max_iou_assign(props, gts, 0.5, 0.5, 0.5, True, labels)
+    a_ref = np.where(valid, a_ref, -1)
+    l_ref = np.where(a_ref > 0, l_ref, -1)
+    a_ref = np.concatenate([np.arange(1, g + 1), a_ref]); l_ref = np.concatenate([labels, l_ref])
+    allb = np.concatenate([gts, props]); v = np.concatenate([np.ones(g, bool), valid])
+    a, m, l = ops.max_iou_assign(dev(torch.from_numpy(allb)), dev(torch.from_numpy(gts)), 0.5, 0.5, 0.5, True,
+                                 dev(torch.from_numpy(labels)), num_leading_gt=g, valid=dev(torch.from_numpy(v)))
+    np.testing.assert_array_equal(a.cpu().numpy(), a_ref)
+    np.testing.assert_array_equal(l.cpu().numpy(), l_ref)
+    np.testing.assert_array_equal(m.cpu().numpy()[g:], m_ref)
+    assert bool((m[:g] == 1).all())
+
+
+def test_random_sample_counts_and_uniformity(ops):
+    """Device RandomSampler: the counts of random_sampler.py:31-78, positives first, no duplicates, never an ignored
+    box; deterministic per seed; every candidate equally likely (frequency test over 300 seeds)."""
+    torch.manual_seed(0)
+    for n_pos, n_neg, n_ign, num, frac in [(10, 100000, 50, 256, 0.5), (300, 1000, 0, 256, 0.5), (5, 20, 3, 512, 0.25),
+                                           (0, 40, 0, 64, 0.25), (200, 30, 0, 256, 0.5), (0, 0, 9, 16, 0.5)]:
+        a = torch.cat([torch.randint(1, 5, (n_pos,)), torch.zeros(n_neg, dtype=torch.long), -torch.ones(n_ign, dtype=torch.long)])
+        a = a[torch.randperm(a.numel())].cuda()
+        idx, is_pos, valid = ops.random_sample(a, num, frac, seed=1234)
+        assert idx.shape == (num,) and is_pos.shape == (num,) and valid.shape == (num,)
+        exp_pos = min(n_pos, int(num * frac)); exp_neg = min(n_neg, num - exp_pos)
+        assert int(is_pos.sum()) == exp_pos and int(valid.sum()) == exp_pos + exp_neg
+        assert bool((a[idx[is_pos]] > 0).all()) and bool((a[idx[valid & ~is_pos]] == 0).all())
+        assert bool(is_pos[:exp_pos].all()) and bool(valid[:exp_pos + exp_neg].all()) and not bool(valid[exp_pos + exp_neg:].any())
+        assert idx[valid].unique().numel() == exp_pos + exp_neg
+        idx2, _, _ = ops.random_sample(a, num, frac, seed=1234)
+        assert torch.equal(idx, idx2)
+        if exp_neg < n_neg:
+            idx3, _, _ = ops.random_sample(a, num, frac, seed=99)
+            assert not torch.equal(idx, idx3)
+    n, num, trials = 2000, 256, 300
+    a = torch.zeros(n, dtype=torch.long, device="cuda"); a[:100] = 1
+    hits = torch.zeros(n, device="cuda")
+    for s in range(trials):
+        idx, is_pos, valid = ops.random_sample(a, num, 0.25, seed=1000 + s)
+        hits[idx[valid]] += 1
+    hp, hn = hits[:100].cpu().numpy(), hits[100:].cpu().numpy()
+    # positives: 64 of 100 per draw -> p = 0.64; negatives: 192 of 1900 -> p = 0.101; binomial 5-sigma bands
+    for h, p in ((hp, 0.64), (hn, 192 / 1900)):
+        sd = (trials * p * (1 - p)) ** 0.5
+        assert abs(h.mean() - trials * p) < 1e-6 * trials + 1e-3 or abs(h.mean() - trials * p) < sd
+        assert h.max() < trials * p + 5.5 * sd and h.min() > trials * p - 5.5 * sd
