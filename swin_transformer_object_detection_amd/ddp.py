@@ -117,6 +117,8 @@ class BucketedGradReducer:
 
     def finish(self):
         """Call after backward: handles buckets with parameters that got no gradient, waits for the collectives."""
+        from . import mixed
+        mixed.flush_pending()
         for b in self.buckets:
             if b['pending'] > 0:
                 self._launch(b)
@@ -130,6 +132,8 @@ class BucketedGradReducer:
 
     def zero_grad(self):
         """Before forward: ONE memset per bucket (kernels accumulate into the views) and drop the leaves' grads."""
+        from . import mixed
+        mixed.reset_step()
         for b in self.buckets:
             b['flat'].zero_()
             for leaf in b['leaves']:

@@ -237,7 +237,7 @@ def _conv(x, conv, dtype, padding=0, relu=False):
         y = ops.linear(tok, conv.weight, conv.bias, dtype)           # weight/bias gradients on the split-T kernel
         y = y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
     elif dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and padding == 1 and C % 64 == 0:
-        return ops.conv3x3(x, _cast(conv.weight, dtype), conv.bias, relu)  # HIP implicit-GEMM kernel (ReLU fused)
+        return ops.conv3x3(x, conv.weight, conv.bias, relu)  # HIP implicit-GEMM kernel (ReLU fused)
     else:
         x = x.contiguous(memory_format=torch.channels_last)
         w = _cast(conv.weight, dtype).contiguous(memory_format=torch.channels_last)

@@ -83,7 +83,7 @@ class FPN(nn.Module):
         for i in range(len(laterals) - 1, 0, -1):               # fpn.py:182-191
             laterals[i - 1] = ops.upsample_add(laterals[i - 1], laterals[i])
         if dt == torch.bfloat16 and self.out_channels % 64 == 0:
-            outs = [ops.conv3x3(laterals[i], self._w(fc.conv.weight), fc.conv.bias) for i, fc in enumerate(self.fpn_convs)]
+            outs = [ops.conv3x3(laterals[i], fc.conv.weight, fc.conv.bias) for i, fc in enumerate(self.fpn_convs)]
         else:                                                   # fp32 parity path: library conv
             outs = [F.conv2d(laterals[i].contiguous(memory_format=torch.channels_last),
                              self._w(fc.conv.weight).contiguous(memory_format=torch.channels_last),

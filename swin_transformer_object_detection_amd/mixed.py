@@ -9,6 +9,7 @@ the autograd leaves (their bf16 gradients are gathered into the flat fp32 gradie
 import torch
 
 _SHADOW = {}          # id(master parameter) -> bf16 leaf tensor (a view of the flat shadow buffer)
+_CONST = {}           # id(master parameter) -> bf16 constant copy (no gradient; biases of shadowed layers)
 _SINK = {}            # id(master parameter) -> (fp32 gradient view in a flat bucket, notify())  -- set by ddp.py
 
 
@@ -31,6 +32,72 @@ def clear_sinks(ids=None):
             _SINK.pop(i, None)
 
 
+# ---- per-step caches and use counts ------------------------------------------------------------------------------
+_DERIVED = {}         # (id(master), tag) -> tensor derived from the shadow (re-laid-out conv weights ...); cleared by refresh()
+_STEPBUF = {}         # (id(master), tag) -> persistent scratch buffer
+_STEPLIVE = set()     # buffers already zeroed in the current accumulation
+_USES = {}            # id(master) -> forward uses whose backward has not run yet
+_PENDING = {}         # id(master) -> finalizer to run at reducer.finish() if the count never reached zero
+
+
+def derived(master, tag, fn):
+    """fn() cached until the next ShadowParams.refresh() when ``master`` has a shadow (its value is then constant
+    over the step); recomputed on every call otherwise."""
+    if master is None or id(master) not in _SHADOW:
+        return fn()
+    k = (id(master), tag)
+    v = _DERIVED.get(k)
+    if v is None:
+        v = _DERIVED[k] = fn()
+    return v
+
+
+def step_buffer(master, tag, shape, device):
+    """A persistent fp32 scratch accumulator for ``master``; zeroed on its first request of an accumulation round."""
+    k = (id(master), tag)
+    b = _STEPBUF.get(k)
+    if b is None or tuple(b.shape) != tuple(shape) or b.device != device:
+        b = _STEPBUF[k] = torch.empty(shape, device=device, dtype=torch.float32)
+    if k not in _STEPLIVE:
+        b.zero_()
+        _STEPLIVE.add(k)
+    return b
+
+
+def step_buffer_done(master, tag):
+    _STEPLIVE.discard((id(master), tag))
+
+
+def use_begin(master):
+    _USES[id(master)] = _USES.get(id(master), 0) + 1
+
+
+def use_end(master):
+    """-> forward uses of ``master`` still waiting for their backward (0: this was the last one)."""
+    n = max(_USES.get(id(master), 1) - 1, 0)
+    _USES[id(master)] = n
+    return n
+
+
+def set_pending(master, fn):
+    if fn is None:
+        _PENDING.pop(id(master), None)
+    else:
+        _PENDING[id(master)] = fn
+
+
+def flush_pending():
+    """Run the finalizers of parameters whose last backward never came (a use outside the loss's graph)."""
+    for k in list(_PENDING):
+        _PENDING.pop(k)()
+
+
+def reset_step():
+    _USES.clear()
+    _PENDING.clear()
+    _STEPLIVE.clear()
+
+
 def weight(p, dtype):
     """The tensor a GEMM/conv should consume for parameter ``p`` in compute dtype ``dtype``."""
     if p is None or p.dtype == dtype:
@@ -41,38 +108,61 @@ def weight(p, dtype):
     return p.to(dtype)
 
 
+def const(p, dtype):
+    """A compute-dtype copy of ``p`` that is NOT part of the autograd graph (None if there is none): the caller
+    must deliver the gradient of ``p`` itself."""
+    if p is None:
+        return None
+    c = _CONST.get(id(p))
+    return c if c is not None and c.dtype == dtype else None
+
+
 class ShadowParams:
     def __init__(self, module, dtype=torch.bfloat16, min_numel=1024):
-        """Shadows are created for the ``weight`` of Linear / Conv2d / ConvTranspose2d layers with >= min_numel
-        elements (the GEMM / conv operands).  Everything else (LayerNorm affine, biases, relative-position bias
-        tables, position embeddings) is consumed in fp32 by the kernels and keeps its direct gradient."""
+        """Shadows are created for the ``weight`` (>= min_numel elements) and ``bias`` of Linear / Conv2d /
+        ConvTranspose2d layers (the GEMM / conv operands).  Everything else (LayerNorm affine, relative-position
+        bias tables, position embeddings) is consumed in fp32 by the kernels and keeps its direct gradient."""
         import torch.nn as nn
         self.dtype = dtype
-        seen, self.masters = set(), []
+        seen, self.masters, self.const_masters = set(), [], []
         for m in module.modules():
             if isinstance(m, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)):
                 p = m.weight
                 if p.requires_grad and p.dtype == torch.float32 and p.numel() >= min_numel and id(p) not in seen:
                     seen.add(id(p))
                     self.masters.append(p)
-        n = sum(p.numel() for p in self.masters)
+                    # the bias of a shadowed layer gets a bf16 CONSTANT copy for the GEMM epilogue (addmm): not an
+                    # autograd leaf -- ops.linear hands the bias gradient to the fp32 master itself; the fused
+                    # kernels that want the bias in fp32 (bias_gelu, attention pad rows, conv3x3) read the master
+                    b = m.bias
+                    if b is not None and b.dtype == torch.float32 and id(b) not in seen:
+                        seen.add(id(b))
+                        self.const_masters.append(b)
+        pad = lambda k: (k + 7) // 8 * 8                       # 16-byte aligned slots
+        n = sum(pad(p.numel()) for p in self.masters + self.const_masters)
         dev = self.masters[0].device if self.masters else torch.device("cpu")
         self.flat = torch.empty(n, device=dev, dtype=dtype)
-        self.shadows = []
+        self.shadows, self.consts = [], []
         off = 0
         for p in self.masters:
             v = self.flat[off:off + p.numel()].view_as(p)
             v.requires_grad_(True)
             self.shadows.append(v)
             _SHADOW[id(p)] = v
-            off += p.numel()
+            off += pad(p.numel())
+        for p in self.const_masters:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            self.consts.append(v)
+            _CONST[id(p)] = v
+            off += pad(p.numel())
         self.refresh()
 
     @torch.no_grad()
     def refresh(self):
         """shadow <- master (after every optimizer step): one multi-tensor copy."""
         if self.masters:
-            torch._foreach_copy_(self.shadows, self.masters)
+            torch._foreach_copy_(self.shadows + self.consts, self.masters + self.const_masters)
+        _DERIVED.clear()
 
     def leaf_of(self, p):
         return _SHADOW.get(id(p), p)
@@ -80,3 +170,6 @@ class ShadowParams:
     def release(self):
         for p in self.masters:
             _SHADOW.pop(id(p), None)
+        for p in self.const_masters:
+            _CONST.pop(id(p), None)
+        _DERIVED.clear()

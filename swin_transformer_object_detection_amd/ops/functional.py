@@ -378,55 +378,88 @@ def _im2col3x3(x_cl):
 
 
 class _Conv3x3(torch.autograd.Function):
+    """Inputs: x, weight (compute-dtype leaf: the bf16 shadow or a cast of the master), bias (fp32 master), relu,
+    weight_master.  The re-laid-out weights are cached per step (mixed.derived); with a reducer active the weight
+    gradient of ALL uses of a shared conv (the RPN conv runs on five levels) is summed in one (Cout,3,3,Cin) fp32
+    accumulator and folded into the parameter's all-reduce bucket after the last use's backward."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, bias_master=None):
+    def forward(ctx, x, weight, bias, relu, weight_master):
+        from .. import mixed
         if x.dtype != torch.bfloat16 or not x.is_cuda:
             raise SwinHipError("conv3x3: bf16 GPU activations only (fp32 parity runs use the library conv)")
         x = x.contiguous(memory_format=torch.channels_last)
-        w = weight.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()               # (Cout,3,3,Cin); no-op cast for a shadow
-        b = None if bias is None else _f32(bias.float()).contiguous()
+        w = mixed.derived(weight_master, 'khwc',
+                          lambda: weight.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())   # (Cout,3,3,Cin)
+        b = None if bias is None else _f32(bias.detach().float()).contiguous()
         y = _conv3x3_raw(x, w, b, relu)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.relu, ctx.has_bias = relu, bias is not None
-        ctx.bias_master = bias_master
+        ctx.masters = (weight_master, bias)
+        ctx.counted = False
+        if mixed.grad_sink(weight_master) is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            mixed.use_begin(weight_master)
+            ctx.counted = True
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        from .. import mixed
         x, weight, y = ctx.saved_tensors
+        w_master, b_master = ctx.masters
         dy = dy.contiguous(memory_format=torch.channels_last)
         if ctx.relu:
-            dy = dy * (y > 0)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0)
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # dx = conv(dy, rot180(w) with in/out swapped): (Cin, 3, 3, Cout)
-            wt = weight.to(torch.bfloat16).flip(2, 3).permute(1, 2, 3, 0).contiguous()
+            wt = mixed.derived(w_master, 'dgrad',
+                               lambda: weight.detach().to(torch.bfloat16).flip(2, 3).permute(1, 2, 3, 0).contiguous())
             dx = _conv3x3_raw(dy, wt, None, False)
+        need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or need_b:
-            from .. import mixed
-            dwf = torch.zeros(Cout, 3, 3, Cin, device=x.device, dtype=torch.float32)
-            bs = mixed.grad_sink(ctx.bias_master) if need_b else None
+        if need_w or need_b:
+            ws = mixed.grad_sink(w_master) if ctx.counted else None
+            bs = mixed.grad_sink(b_master) if (need_b and ctx.counted) else None
+            if ws is not None and tuple(ws[0].shape) != (Cout, Cin, 3, 3):
+                ws = None
+            if ws is not None:
+                dwf = mixed.step_buffer(w_master, 'dw_khwc', (Cout, 3, 3, Cin), x.device)
+            else:
+                dwf = torch.zeros(Cout, 3, 3, Cin, device=x.device, dtype=torch.float32)
             dbf = None
             if need_b:
                 dbf = bs[0] if bs is not None else torch.zeros(Cout, device=x.device, dtype=torch.float32)
             call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), _p(dbf), N, H, W, Cin, Cout, _s())   # implicit im2col
-            if ctx.needs_input_grad[1]:
-                dw = dwf.permute(0, 3, 1, 2).to(weight.dtype)
-            if need_b:
-                if bs is not None:
-                    bs[1]()
+            if ws is not None:
+                def finalize(ws=ws, bs=bs, dwf=dwf, w_master=w_master):
+                    ws[0].add_(dwf.permute(0, 3, 1, 2))
+                    mixed.step_buffer_done(w_master, 'dw_khwc')
+                    mixed.set_pending(w_master, None)
+                    ws[1]()
+                    if bs is not None:
+                        bs[1]()
+                if mixed.use_end(w_master) == 0:
+                    finalize()
                 else:
-                    db = dbf
+                    mixed.set_pending(w_master, finalize)
+            elif need_w:
+                dw = dwf.permute(0, 3, 1, 2).to(weight.dtype)
+            if need_b and bs is None:
+                db = dbf
+        elif ctx.counted:
+            mixed.use_end(w_master)
         return dx, dw, db, None, None
 
 
-def conv3x3(x, weight, bias=None, relu=False):
-    """3x3, padding 1, stride 1 conv of a logically-NCHW bf16 tensor (channels-last memory).  ``bias`` is the fp32
-    master parameter (its gradient may be accumulated straight into the reducer's bucket)."""
-    return _Conv3x3.apply(x, weight, bias, relu, bias)
+def conv3x3(x, weight, bias=None, relu=False, dtype=torch.bfloat16):
+    """3x3, padding 1, stride 1 conv of a logically-NCHW bf16 tensor (channels-last memory).  ``weight`` / ``bias``
+    are the fp32 master parameters (the compute-dtype weight is resolved through mixed.weight; gradients may be
+    accumulated straight into the reducer's buckets)."""
+    from .. import mixed
+    return _Conv3x3.apply(x, mixed.weight(weight, dtype), bias, relu, weight)
 
 
 # --------------------------------------------------------------------------------------
@@ -435,13 +468,21 @@ def conv3x3(x, weight, bias=None, relu=False):
 class _LinearBf16(torch.autograd.Function):
     """y = x w^T + b.  Forward / data gradient: library GEMM.  Weight AND bias gradient: the split-T kernel
     (wgrad_gemm.hip), accumulating in fp32 -- straight into the parameters' all-reduce buckets when a reducer
-    has registered gradient sinks (mixed.grad_sink), else into fresh buffers returned through autograd."""
+    has registered gradient sinks (mixed.grad_sink), else into fresh buffers returned through autograd.
+    ``b`` may be a constant bf16 copy of ``b_master`` (mixed.const): the bias gradient then goes to ``b_master``."""
 
     @staticmethod
     def forward(ctx, x, w, b, w_master, b_master):
+        from .. import mixed
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.masters = (w_master, b_master)
+        ctx.bias_to_master = b is not None and not ctx.needs_input_grad[2] and b_master is not None and b_master.requires_grad
+        ctx.counted = False
+        ws = mixed.grad_sink(w_master)
+        if ws is not None and ws[0].numel() == w.numel() and ws[0].is_contiguous() and ctx.needs_input_grad[1]:
+            mixed.use_begin(w_master)
+            ctx.counted = True
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -456,30 +497,39 @@ class _LinearBf16(torch.autograd.Function):
         x2 = x.reshape(-1, N2)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        dx = dw = db = None
+        dx = dw = db = dbm = None
         if ctx.needs_input_grad[0]:
             dx = (dy2 @ w).view(x.shape)
         need_w = ctx.needs_input_grad[1]
-        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        need_b = ctx.has_bias and (ctx.needs_input_grad[2] or ctx.bias_to_master)
         if need_w or need_b:
-            ws, bs = mixed.grad_sink(w_master), mixed.grad_sink(b_master) if need_b else None
-            if ws is not None and (ws[0].numel() != N1 * N2 or not ws[0].is_contiguous()):
-                ws = None                                  # a derived weight (e.g. concatenated heads): no direct sink
+            ws = mixed.grad_sink(w_master) if ctx.counted else None
+            bs = mixed.grad_sink(b_master) if (need_b and ctx.counted) else None
             dwf = ws[0].view(N1, N2) if ws is not None else torch.zeros(N1, N2, device=x.device, dtype=torch.float32)
             dbf = None
             if need_b:
                 dbf = bs[0] if bs is not None else torch.zeros(N1, device=x.device, dtype=torch.float32)
             call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2, _s())
             if ws is not None:
-                ws[1]()
+                def finalize(ws=ws, bs=bs, w_master=w_master):
+                    mixed.set_pending(w_master, None)
+                    ws[1]()
+                    if bs is not None:
+                        bs[1]()
+                if mixed.use_end(w_master) == 0:        # the last backward of a layer used several times
+                    finalize()
+                else:
+                    mixed.set_pending(w_master, finalize)
             elif need_w:
                 dw = dwf.to(w.dtype).view(w.shape)
-            if need_b:
-                if bs is not None:
-                    bs[1]()
+            if need_b and bs is None:
+                if ctx.bias_to_master:
+                    dbm = dbf
                 else:
                     db = dbf.to(dy.dtype)
-        return dx, dw, db, None, None
+        elif ctx.counted:
+            mixed.use_end(w_master)
+        return dx, dw, db, None, dbm
 
 
 def linear(x, weight, bias=None, dtype=None):
@@ -489,10 +539,12 @@ def linear(x, weight, bias=None, dtype=None):
     from .. import mixed
     dtype = dtype or x.dtype
     w = mixed.weight(weight, dtype)
-    b = mixed.weight(bias, dtype)
     if w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1:        # 1x1 conv weight (Cout,Cin,1,1)
         w = w.view(w.shape[0], w.shape[1])
     if (x.dtype == torch.bfloat16 and x.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[0] % 8 == 0
-            and w.shape[1] % 8 == 0 and x.numel() // w.shape[1] >= 2048):
+            and w.shape[1] % 8 == 0 and x.numel() // w.shape[1] >= 1024):
+        b = mixed.const(bias, dtype)                                # bf16 constant; gradient delivered to the master
+        if b is None:
+            b = mixed.weight(bias, dtype)
         return _LinearBf16.apply(x, w, b, weight, bias)
-    return torch.nn.functional.linear(x, w, b)
+    return torch.nn.functional.linear(x, w, mixed.weight(bias, dtype))

@@ -126,16 +126,20 @@ class _RoIAlignMultiLevelFn(torch.autograd.Function):
         import ctypes
         rois, lvls = ctx.saved_tensors
         n, C, K, ph, pw, strides, sr, aligned, shapes, in_dtype = ctx.cfg
-        grads = [torch.empty(s, device=gout.device, dtype=torch.float32, memory_format=torch.channels_last).zero_()
-                 for s in shapes]
+        # one flat fp32 accumulator for the whole pyramid: one memset, one cast back to the feature dtype
+        sizes = [s[0] * s[1] * s[2] * s[3] for s in shapes]
+        flat = torch.zeros(sum(sizes), device=gout.device, dtype=torch.float32)
+        offs = [sum(sizes[:i]) for i in range(n)]
         if K > 0:
             gout = gout.float().contiguous(memory_format=torch.channels_last)
-            ptrs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+            ptrs = (ctypes.c_void_p * n)(*[flat.data_ptr() + 4 * o for o in offs])
             Hs = (ctypes.c_int * n)(*[s[2] for s in shapes])
             Ws = (ctypes.c_int * n)(*[s[3] for s in shapes])
             sc = (ctypes.c_float * n)(*[1.0 / s for s in strides])
             call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, n, _p(gout), _p(rois), _p(lvls), C, K, ph, pw, sr, aligned, _s())
-        return (None, None, None, None, None, None) + tuple(g.to(in_dtype) for g in grads)
+        flat = flat.to(in_dtype)
+        grads = tuple(flat[o:o + m].view(s[0], s[2], s[3], s[1]).permute(0, 3, 1, 2) for o, m, s in zip(offs, sizes, shapes))
+        return (None, None, None, None, None, None) + grads
 
 
 def roi_align_multilevel(feats, rois, lvls, output_size, strides, sampling_ratio=0, aligned=True):
