@@ -222,6 +222,16 @@ int64_t det_random_sample_workspace_bytes(void);
 int det_random_sample(const int64_t* assigned_gt_inds, int64_t n, int num, int num_pos_max, uint64_t seed,
                       int64_t* out_inds, uint8_t* out_flags, void* workspace, void* stream);
 
+/* det_bbox_targets: targets of a fixed-size sample -- the gathers of anchor_head.py:221-247 / bbox_head.py:140-186 plus
+ *   DeltaXYWHBBoxCoder.encode (delta_xywh_bbox_coder.py:82-130).  means / stds are HOST pointers to 4 floats.
+ * det_delta2bbox: DeltaXYWHBBoxCoder.decode (delta_xywh_bbox_coder.py:189-237) for (n,4) rois / deltas. */
+int det_bbox_targets(const float* bboxes, const int64_t* inds, const uint8_t* flags, const int64_t* assigned_gt_inds,
+                     const float* gt_bboxes, int num_gts, const int64_t* assigned_labels, int64_t bg_label,
+                     const float* means, const float* stds, int k, float* out_bboxes, float* out_deltas,
+                     int64_t* out_gt_inds, int64_t* out_labels, void* stream);
+int det_delta2bbox(const float* rois, const float* deltas, int64_t n, const float* means, const float* stds,
+                   float max_h, float max_w, float wh_ratio_clip, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,6 +234,64 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(SampleWs* __restric
     for (int i = tp + tn + t; i < num; i += 1024) { out_inds[i] = 0; out_flags[i] = 0; }
 }
 
+// ------------------------------------------------------------------------------------------ DeltaXYWHBBoxCoder
+struct F4 { float v[4]; };
+
+// encode (delta_xywh_bbox_coder.py:82-130) for a fixed-size sample + the gathers around it
+// (anchor_head.py:221-247 / bbox_head.py:140-186 `_get_target_single`): one thread per sample slot.
+__global__ __launch_bounds__(256) void bbox_targets_kernel(const float4* __restrict__ boxes, const int64_t* __restrict__ inds,
+                                                           const uint8_t* __restrict__ flags, const int64_t* __restrict__ assigned,
+                                                           const float4* __restrict__ gts, int G,
+                                                           const int64_t* __restrict__ assigned_labels, int64_t bg_label, F4 means,
+                                                           F4 stds, int k, float4* __restrict__ out_boxes,
+                                                           float4* __restrict__ out_deltas, int64_t* __restrict__ out_gt,
+                                                           int64_t* __restrict__ out_labels) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= k) return;
+    const uint8_t f = flags[i];
+    const bool valid = f & 1, pos = (f & 2) && G > 0;
+    const int64_t idx = valid ? inds[i] : 0;
+    const float4 b = valid ? boxes[idx] : float4{0.f, 0.f, 1.f, 1.f};
+    const int64_t a = valid ? assigned[idx] : 0;
+    const int64_t gi = a > 0 ? a - 1 : 0;
+    float4 d = {0.f, 0.f, 0.f, 0.f};
+    if (pos) {
+        const float4 g = gts[gi];
+        const float px = (b.x + b.z) * 0.5f, py = (b.y + b.w) * 0.5f, pw = b.z - b.x, ph = b.w - b.y;
+        const float gx = (g.x + g.z) * 0.5f, gy = (g.y + g.w) * 0.5f, gw = g.z - g.x, gh = g.w - g.y;
+        d.x = ((gx - px) / pw - means.v[0]) / stds.v[0];
+        d.y = ((gy - py) / ph - means.v[1]) / stds.v[1];
+        d.z = (logf(gw / pw) - means.v[2]) / stds.v[2];
+        d.w = (logf(gh / ph) - means.v[3]) / stds.v[3];
+    }
+    out_boxes[i] = b;
+    out_deltas[i] = d;
+    if (out_gt) out_gt[i] = gi;
+    if (out_labels) out_labels[i] = (pos && assigned_labels) ? assigned_labels[idx] : bg_label;
+}
+
+// decode (delta_xywh_bbox_coder.py:189-237), (n,4) rois / deltas
+__global__ __launch_bounds__(256) void delta2bbox_kernel(const float4* __restrict__ rois, const float4* __restrict__ deltas, int64_t n,
+                                                         F4 means, F4 stds, float max_h, float max_w, float max_ratio,
+                                                         float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 r = rois[i], dl = deltas[i];
+    const float dx = dl.x * stds.v[0] + means.v[0], dy = dl.y * stds.v[1] + means.v[1];
+    float dw = dl.z * stds.v[2] + means.v[2], dh = dl.w * stds.v[3] + means.v[3];
+    dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+    dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+    const float px = (r.x + r.z) * 0.5f, py = (r.y + r.w) * 0.5f, pw = r.z - r.x, ph = r.w - r.y;
+    const float gw = pw * expf(dw), gh = ph * expf(dh);
+    const float gx = px + pw * dx, gy = py + ph * dy;
+    float4 o = {gx - gw * 0.5f, gy - gh * 0.5f, gx + gw * 0.5f, gy + gh * 0.5f};
+    if (max_w > 0.f) {
+        o.x = fminf(fmaxf(o.x, 0.f), max_w); o.z = fminf(fmaxf(o.z, 0.f), max_w);
+        o.y = fminf(fmaxf(o.y, 0.f), max_h); o.w = fminf(fmaxf(o.w, 0.f), max_h);
+    }
+    out[i] = o;
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int64_t det_assign_workspace_bytes(int64_t n, int num_gts) {
     if (n < 0) n = 0;
@@ -289,5 +347,37 @@ extern "C" int det_random_sample(const int64_t* assigned_gt_inds, int64_t n, int
         sample_collect_kernel<<<blocks, 256, 0, s>>>(assigned_gt_inds, (int)n, s0, s1, num, num_pos_max, ws);
     }
     sample_select_kernel<<<1, 1024, 0, s>>>(ws, num, num_pos_max, out_inds, out_flags);
+    return swin_launch_status();
+}
+
+// Targets of a fixed-size sample (det_random_sample's inds / flags): sampled boxes (unused slots: 0,0,1,1), encoded
+// regression targets (zero unless positive), matched gt index (0 when none) and, when assigned_labels is given, the
+// class label (bg_label unless positive).  means / stds: 4 host floats each.
+extern "C" int det_bbox_targets(const float* bboxes, const int64_t* inds, const uint8_t* flags, const int64_t* assigned_gt_inds,
+                                const float* gt_bboxes, int num_gts, const int64_t* assigned_labels, int64_t bg_label,
+                                const float* means, const float* stds, int k, float* out_bboxes, float* out_deltas,
+                                int64_t* out_gt_inds, int64_t* out_labels, void* stream) {
+    if (k == 0) return SWIN_OK;
+    if (!bboxes || !inds || !flags || !assigned_gt_inds || !means || !stds || k < 0 || !out_bboxes || !out_deltas ||
+        (num_gts > 0 && !gt_bboxes))
+        return SWIN_ERR_BAD_ARG;
+    F4 m, sd;
+    for (int q = 0; q < 4; ++q) { m.v[q] = means[q]; sd.v[q] = stds[q]; }
+    bbox_targets_kernel<<<(k + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+        (const float4*)bboxes, inds, flags, assigned_gt_inds, (const float4*)gt_bboxes, num_gts, assigned_labels, bg_label, m, sd, k,
+        (float4*)out_bboxes, (float4*)out_deltas, out_gt_inds, out_labels);
+    return swin_launch_status();
+}
+
+// DeltaXYWHBBoxCoder.decode: rois, deltas (n,4) f32 -> out (n,4); clipped to [0,max_w] x [0,max_h] when max_w > 0.
+extern "C" int det_delta2bbox(const float* rois, const float* deltas, int64_t n, const float* means, const float* stds,
+                              float max_h, float max_w, float wh_ratio_clip, float* out, void* stream) {
+    if (n == 0) return SWIN_OK;
+    if (!rois || !deltas || !means || !stds || !out || n < 0 || wh_ratio_clip <= 0.f) return SWIN_ERR_BAD_ARG;
+    F4 m, sd;
+    for (int q = 0; q < 4; ++q) { m.v[q] = means[q]; sd.v[q] = stds[q]; }
+    const float mr = fabsf(logf(wh_ratio_clip));
+    delta2bbox_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>((const float4*)rois, (const float4*)deltas, n, m, sd,
+                                                                                   max_h, max_w, mr, (float4*)out);
     return swin_launch_status();
 }

@@ -197,15 +197,19 @@ def sample_static(assigned, num, pos_fraction):
     return idx, vals < 1.0, vals < 3.0
 
 
-def assign_and_sample(bboxes, gt_bboxes, a_cfg, s_cfg, gt_labels=None, num_leading_gt=0, valid=None):
-    """assigner.assign + sampler.sample of one image (anchor_head.py:213-219, standard_roi_head.py:83-93) with a
-    fixed-size result: (idx, is_pos, valid, assigned_gt_inds, assigned_labels).  On the GPU both run as HIP kernels
-    (ops.max_iou_assign / ops.random_sample); the torch forms above are the host restatement used on CPU."""
+def assign_and_sample(bboxes, gt_bboxes, a_cfg, s_cfg, means, stds, gt_labels=None, num_leading_gt=0, valid=None, bg_label=0):
+    """assigner.assign + sampler.sample + target encoding of one image (anchor_head.py:213-247,
+    standard_roi_head.py:83-93 + bbox_head.py:140-186) with a fixed-size result:
+    (boxes (num,4), deltas (num,4), labels (num,), gt_inds (num,), is_pos (num,), valid (num,)).
+    On the GPU this is four HIP entry points (ops.max_iou_assign / random_sample_raw / bbox_targets); the torch
+    forms above are the host restatement used on CPU."""
+    num = s_cfg['num']
     if bboxes.is_cuda:
         assigned, _, lab = ops.max_iou_assign(bboxes, gt_bboxes, a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'], a_cfg['min_pos_iou'],
                                               a_cfg.get('match_low_quality', True), gt_labels, num_leading_gt, valid)
-        idx, is_pos, ok = ops.random_sample(assigned, s_cfg['num'], s_cfg['pos_fraction'])
-        return idx, is_pos, ok, assigned, lab
+        inds, flags = ops.random_sample_raw(assigned, num, s_cfg['pos_fraction'])
+        boxes, deltas, gt_inds, labels = ops.bbox_targets(bboxes, inds, flags, assigned, gt_bboxes, means, stds, lab, bg_label)
+        return boxes, deltas, labels, gt_inds, flags >= 2, flags >= 1, inds
     g = num_leading_gt
     assigned, _, lab = max_iou_assign(bboxes[g:], gt_bboxes, a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'], a_cfg['min_pos_iou'],
                                       a_cfg.get('match_low_quality', True), gt_labels)
@@ -215,11 +219,22 @@ def assign_and_sample(bboxes, gt_bboxes, a_cfg, s_cfg, gt_labels=None, num_leadi
             lab = torch.cat([gt_labels, lab], 0)
     if valid is not None:
         assigned = torch.where(valid, assigned, torch.full_like(assigned, -1))
-    idx, is_pos, ok = sample_static(assigned, s_cfg['num'], s_cfg['pos_fraction'])
-    k = s_cfg['num'] - idx.numel()
+    idx, is_pos, ok = sample_static(assigned, num, s_cfg['pos_fraction'])
+    k = num - idx.numel()
     if k > 0:                                   # fewer boxes than samples: pad to the fixed size
         idx = torch.cat([idx, idx.new_zeros(k)]); is_pos = torch.cat([is_pos, is_pos.new_zeros(k)]); ok = torch.cat([ok, ok.new_zeros(k)])
-    return idx, is_pos, ok, assigned, lab
+    boxes = torch.where(ok[:, None], bboxes[idx], bboxes.new_tensor([0., 0., 1., 1.]).expand(num, 4))
+    gt_inds = (assigned[idx] - 1).clamp(min=0)
+    if gt_bboxes.size(0) > 0:
+        deltas = bbox2delta(boxes, gt_bboxes[gt_inds], means, stds)
+        deltas = torch.where(is_pos[:, None], deltas, torch.zeros_like(deltas))
+    else:
+        deltas = torch.zeros_like(boxes)
+        is_pos = torch.zeros_like(is_pos)
+    labels = None
+    if lab is not None:
+        labels = torch.where(is_pos, lab[idx], torch.full_like(idx, bg_label))
+    return boxes, deltas, labels, gt_inds, is_pos, ok, idx
 
 
 def _cast(t, dtype):
@@ -312,14 +327,7 @@ class RPNHead(nn.Module):
         reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
         loss_cls = loss_bbox = total = 0.
         for i in range(B):
-            idx, is_pos, valid, assigned, _ = assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg)
-            a = anchors[idx]
-            if gt_bboxes[i].size(0) > 0:
-                g = gt_bboxes[i][(assigned[idx] - 1).clamp(min=0)]
-                tgt = bbox2delta(a, g, self.means, self.stds)
-                tgt = torch.where(is_pos[:, None], tgt, torch.zeros_like(tgt))
-            else:
-                tgt = torch.zeros_like(a)
+            _, tgt, _, _, is_pos, valid, idx = assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg, self.means, self.stds)
             c_i, r_i = cls[i][idx].float(), reg[i][idx].float()
             lc = F.binary_cross_entropy_with_logits(c_i, is_pos.float(), reduction='none')     # fg -> 1, bg -> 0
             loss_cls = loss_cls + (lc * valid).sum()
@@ -352,7 +360,8 @@ class RPNHead(nn.Module):
         anchors, ids = torch.cat(an_l, 1), torch.cat(id_l, 1)
         out = []
         for i in range(B):
-            props = delta2bbox(anchors[i], deltas[i], self.means, self.stds, max_shape=img_shapes[i])
+            dec = ops.delta2bbox if anchors.is_cuda else delta2bbox
+            props = dec(anchors[i], deltas[i], self.means, self.stds, max_shape=img_shapes[i])
             if cfg.get('min_bbox_size', 0) > 0:
                 w, h = props[:, 2] - props[:, 0], props[:, 3] - props[:, 1]
                 v = (w >= cfg['min_bbox_size']) & (h >= cfg['min_bbox_size'])
@@ -587,18 +596,10 @@ class StandardRoIHead(nn.Module):
                 props = torch.cat([gt_bboxes[i], props], 0)
                 pvalid = torch.cat([torch.ones(g, dtype=torch.bool, device=props.device), pvalid], 0)
             lead = g if s.get('add_gt_as_proposals', True) else 0
-            idx, is_pos, valid, assigned, lab = assign_and_sample(props, gt_bboxes[i], a, s, gt_labels[i], lead, pvalid)
-            boxes = torch.where(valid[:, None], props[idx], props.new_tensor([0., 0., 1., 1.]).expand(idx.numel(), 4))
-            gt_ind = (assigned[idx] - 1).clamp(min=0)
-            if g > 0:
-                t_i = bbox2delta(boxes, gt_bboxes[i][gt_ind], self.bbox_head.means, self.bbox_head.stds)
-                t_i = torch.where(is_pos[:, None], t_i, torch.zeros_like(t_i))
-                l_i = torch.where(is_pos, lab[idx], torch.full_like(idx, nc))
-            else:
-                t_i = torch.zeros_like(boxes)
-                l_i = torch.full_like(idx, nc)
+            boxes, t_i, l_i, gt_ind, is_pos, valid, _ = assign_and_sample(
+                props, gt_bboxes[i], a, s, self.bbox_head.means, self.bbox_head.stds, gt_labels[i], lead, pvalid, bg_label=nc)
             roi_l.append(boxes); lab_l.append(l_i); tgt_l.append(t_i); pos_l.append(is_pos); val_l.append(valid)
-            k = min(npos_max, idx.numel())                            # positives come first in the sample
+            k = min(npos_max, num)                                    # positives come first in the sample
             m_roi.append(boxes[:k]); m_gt.append(gt_ind[:k]); m_lab.append(l_i[:k].clamp(max=nc - 1)); m_val.append(is_pos[:k])
         losses = {}
         rois = bbox2roi(roi_l)

@@ -2,6 +2,8 @@
 
 Reference call sites: anchor_head.py:213-219 (assign + sample per image for the RPN), standard_roi_head.py:83-93
 (the same for the RoI head).  Results have fixed shapes, so nothing here synchronises with the host."""
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -58,3 +60,49 @@ def random_sample(assigned_gt_inds, num, pos_fraction, seed=None):
     call("det_random_sample", _p(a) if a.numel() else None, a.numel(), int(num), int(num * pos_fraction),
          _next_seed() if seed is None else int(seed), _p(inds), _p(flags), _p(ws), _s())
     return inds, flags >= 2, flags >= 1
+
+
+def _f4(v):
+    return (ctypes.c_float * 4)(*[float(x) for x in v])
+
+
+def random_sample_raw(assigned_gt_inds, num, pos_fraction, seed=None):
+    """random_sample returning the kernel's (inds, flags) pair (bit 0 used, bit 1 positive) for bbox_targets."""
+    a = assigned_gt_inds.long().contiguous()
+    inds = torch.empty(num, dtype=torch.long, device=a.device)
+    flags = torch.empty(num, dtype=torch.uint8, device=a.device)
+    ws = torch.empty(_lib.lib().det_random_sample_workspace_bytes(), dtype=torch.uint8, device=a.device)
+    call("det_random_sample", _p(a) if a.numel() else None, a.numel(), int(num), int(num * pos_fraction),
+         _next_seed() if seed is None else int(seed), _p(inds), _p(flags), _p(ws), _s())
+    return inds, flags
+
+
+def bbox_targets(bboxes, inds, flags, assigned_gt_inds, gt_bboxes, means, stds, assigned_labels=None, bg_label=0):
+    """Targets of a fixed-size sample in one launch: the gathers of anchor_head.py:221-247 / bbox_head.py:140-186 and
+    DeltaXYWHBBoxCoder.encode (delta_xywh_bbox_coder.py:82-130).
+
+    -> (boxes (k,4) [unused slots (0,0,1,1)], deltas (k,4) [zero unless positive], gt_inds (k) int64,
+        labels (k) int64 or None [bg_label unless positive])."""
+    k = inds.numel()
+    dev = bboxes.device
+    boxes = torch.empty(k, 4, dtype=torch.float32, device=dev)
+    deltas = torch.empty(k, 4, dtype=torch.float32, device=dev)
+    gt_inds = torch.empty(k, dtype=torch.long, device=dev)
+    labels = torch.empty(k, dtype=torch.long, device=dev) if assigned_labels is not None else None
+    g = gt_bboxes.size(0)
+    bb, gb = bboxes.detach().float().contiguous(), gt_bboxes.detach().float().contiguous()
+    call("det_bbox_targets", _p(bb), _p(inds), _p(flags), _p(assigned_gt_inds), _p(gb) if g else None, g,
+         _p(assigned_labels) if assigned_labels is not None else None, int(bg_label), _f4(means), _f4(stds), k, _p(boxes), _p(deltas),
+         _p(gt_inds), _p(labels) if labels is not None else None, _s())
+    return boxes, deltas, gt_inds, labels
+
+
+def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None, wh_ratio_clip=16 / 1000):
+    """DeltaXYWHBBoxCoder.decode (delta_xywh_bbox_coder.py:189-237) for (n,4) float32 rois / deltas on the GPU."""
+    if not rois.is_cuda:
+        raise SwinHipError("delta2bbox: GPU tensors only")
+    r, d = rois.detach().float().contiguous(), deltas.detach().float().contiguous()
+    out = torch.empty_like(r)
+    mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    call("det_delta2bbox", _p(r), _p(d), r.size(0), _f4(means), _f4(stds), mh, mw, float(wh_ratio_clip), _p(out), _s())
+    return out

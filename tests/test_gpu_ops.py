@@ -565,3 +565,43 @@ def test_random_sample_counts_and_uniformity(ops):
         sd = (trials * p * (1 - p)) ** 0.5
         assert abs(h.mean() - trials * p) < 1e-6 * trials + 1e-3 or abs(h.mean() - trials * p) < sd
         assert h.max() < trials * p + 5.5 * sd and h.min() > trials * p - 5.5 * sd
+
+
+def test_delta2bbox_and_bbox_targets(ops):
+    """DeltaXYWHBBoxCoder on the device vs the oracle's numpy decode (callers_oracle.delta2bbox) and an fp64 encode;
+    fp32, atol 1e-4 px for decode (exp of a clamped delta times a box side <= ~1e3) / 1e-5 for the encoded deltas."""
+    rng = np.random.RandomState(41)
+    n = 5000
+    rois = _boxes(rng, n, 1000.0, 300.0)
+    deltas = (rng.randn(n, 4) * np.array([0.5, 0.5, 2.0, 2.0])).astype(np.float32)     # |dw| beyond the ratio clip too
+    for means, stds, shape in [((0., 0., 0., 0.), (1., 1., 1., 1.), (800, 1216)), ((0., 0., 0., 0.), (.1, .1, .2, .2), None)]:
+        ref = CO.delta2bbox(rois, deltas, means, stds, shape)
+        out = ops.delta2bbox(dev(torch.from_numpy(rois)), dev(torch.from_numpy(deltas)), means, stds, shape)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-6, atol=2e-4)
+    # targets of a sample: positives encode against their gt, the rest is zero / background
+    g = 7
+    gts = _boxes(rng, g, 900.0, 250.0)
+    assigned = rng.randint(-1, g + 1, n).astype(np.int64)
+    labels_all = np.where(assigned > 0, rng.randint(0, 80, n), -1).astype(np.int64)
+    k = 300
+    inds = rng.choice(n, k, replace=False).astype(np.int64)
+    flags = np.where(assigned[inds] > 0, 3, np.where(assigned[inds] == 0, 1, 0)).astype(np.uint8)
+    means, stds = (0., 0., 0., 0.), (.1, .1, .2, .2)
+    b, d, gi, lab = ops.bbox_targets(dev(torch.from_numpy(rois)), dev(torch.from_numpy(inds)), dev(torch.from_numpy(flags)),
+                                     dev(torch.from_numpy(assigned)), dev(torch.from_numpy(gts)), means, stds,
+                                     dev(torch.from_numpy(labels_all)), bg_label=80)
+    pos, used = flags == 3, flags >= 1
+    eb = np.where(used[:, None], rois[inds], np.array([0, 0, 1, 1], np.float32))
+    np.testing.assert_array_equal(b.cpu().numpy(), eb)
+    np.testing.assert_array_equal(gi.cpu().numpy(), np.where(used, np.maximum(assigned[inds] - 1, 0), 0))
+    np.testing.assert_array_equal(lab.cpu().numpy(), np.where(pos, labels_all[inds], 80))
+    p64, g64 = rois[inds].astype(np.float64), gts[np.maximum(assigned[inds] - 1, 0)].astype(np.float64)
+    pw, ph = p64[:, 2] - p64[:, 0], p64[:, 3] - p64[:, 1]
+    gw, gh = g64[:, 2] - g64[:, 0], g64[:, 3] - g64[:, 1]
+    enc = np.stack([((g64[:, 0] + g64[:, 2]) - (p64[:, 0] + p64[:, 2])) * 0.5 / pw, ((g64[:, 1] + g64[:, 3]) - (p64[:, 1] + p64[:, 3])) * 0.5 / ph,
+                    np.log(gw / pw), np.log(gh / ph)], 1) / np.array(stds)
+    enc = np.where(pos[:, None], enc, 0.0)
+    np.testing.assert_allclose(d.cpu().numpy(), enc, rtol=1e-5, atol=1e-4)
+    # round trip: decode(encode(gt)) == gt for the positives
+    back = ops.delta2bbox(b, d, means, stds, None, wh_ratio_clip=1e-9)
+    np.testing.assert_allclose(back.cpu().numpy()[pos], g64[pos], rtol=1e-5, atol=2e-3)
