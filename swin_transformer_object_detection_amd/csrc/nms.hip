@@ -39,21 +39,23 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
     mask[(int64_t)row * col_blocks + cb] = bits;
 }
 
-// one workgroup: walks the 64-box blocks in order; the in-block greedy scan is done by one
-// lane on the 64 diagonal words staged in LDS, then all threads OR the kept rows into `remv`
-// (4 independent loads in flight per thread).  Stops as soon as `max_num` boxes are kept (> 0):
-// the callers slice `dets[:max_per_img]` (rpn_head.py:235, bbox_nms.py:86-88), so later boxes never matter.
-__global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks,
-                                                         uint8_t* __restrict__ keep, int32_t* __restrict__ num_kept,
-                                                         int max_num, int32_t* __restrict__ kept_pos, int kept_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t remv[];   // col_blocks words
+// one workgroup of 1024 threads walks the 64-box blocks in order.  Per block: one lane does the greedy scan of the 64
+// diagonal words (staged in LDS); then the kept rows are OR-ed into `remv` for the later column words with the
+// (row, column) pairs spread over ALL threads -- 4 independent loads in flight per thread, LDS atomicOr to combine
+// -- so a block costs about two memory latencies instead of cnt/4.  Stops as soon as `max_num` boxes are kept
+// (> 0): the callers slice `dets[:max_per_img]` (rpn_head.py:235, bbox_nms.py:86-88), so later boxes never matter.
+#define NMS_RT 1024
+__global__ __launch_bounds__(NMS_RT) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks,
+                                                            uint8_t* __restrict__ keep, int32_t* __restrict__ num_kept,
+                                                            int max_num, int32_t* __restrict__ kept_pos, int kept_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];   // col_blocks words
     __shared__ uint64_t diag[64];
     __shared__ uint64_t kept_bits;
     __shared__ int kept_rows[64];
     __shared__ int kept_cnt, total;
     const int t = threadIdx.x;
-    for (int j = t; j < col_blocks; j += 256) remv[j] = 0;
-    if (kept_pos) for (int i = t; i < kept_cap; i += 256) kept_pos[i] = -1;     // fixed-size, -1 padded output
+    for (int j = t; j < col_blocks; j += NMS_RT) remv[j] = 0;
+    if (kept_pos) for (int i = t; i < kept_cap; i += NMS_RT) kept_pos[i] = -1;     // fixed-size, -1 padded output
     if (t == 0) total = 0;
     __syncthreads();
     int b = 0;
@@ -78,23 +80,21 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
         if (t < lim) keep[b * 64 + t] = (uint8_t)((kb >> t) & 1);
         if (kept_pos && t < cnt && total - cnt + t < kept_cap) kept_pos[total - cnt + t] = kept_rows[t];
         if (max_num > 0 && total >= max_num) { ++b; break; }
-        for (int j = b + 1 + t; j < col_blocks; j += 256) {
-            uint64_t acc = remv[j];
-            int k = 0;
-            for (; k + 4 <= cnt; k += 4) {
-                uint64_t a0 = mask[(int64_t)kept_rows[k] * col_blocks + j];
-                uint64_t a1 = mask[(int64_t)kept_rows[k + 1] * col_blocks + j];
-                uint64_t a2 = mask[(int64_t)kept_rows[k + 2] * col_blocks + j];
-                uint64_t a3 = mask[(int64_t)kept_rows[k + 3] * col_blocks + j];
-                acc |= (a0 | a1) | (a2 | a3);
-            }
-            for (; k < cnt; ++k) acc |= mask[(int64_t)kept_rows[k] * col_blocks + j];
-            remv[j] = acc;
+        // work item = (column j, group of 4 kept rows); items spread over the whole workgroup
+        const int ncol = col_blocks - (b + 1), ngrp = (cnt + 3) >> 2;
+        for (int it = t; it < ncol * ngrp; it += NMS_RT) {
+            const int j = b + 1 + it % ncol, k0 = (it / ncol) << 2;
+            const uint64_t a0 = mask[(int64_t)kept_rows[k0] * col_blocks + j];
+            const uint64_t a1 = k0 + 1 < cnt ? mask[(int64_t)kept_rows[k0 + 1] * col_blocks + j] : 0;
+            const uint64_t a2 = k0 + 2 < cnt ? mask[(int64_t)kept_rows[k0 + 2] * col_blocks + j] : 0;
+            const uint64_t a3 = k0 + 3 < cnt ? mask[(int64_t)kept_rows[k0 + 3] * col_blocks + j] : 0;
+            const uint64_t acc = (a0 | a1) | (a2 | a3);
+            if (acc) atomicOr(&remv[j], (unsigned long long)acc);
         }
         __syncthreads();
     }
     // early stop: everything after the last processed block is dropped
-    for (int i = b * 64 + t; i < n; i += 256) keep[i] = 0;
+    for (int i = b * 64 + t; i < n; i += NMS_RT) keep[i] = 0;
     __syncthreads();
     if (t == 0) *num_kept = total;
 }
@@ -121,7 +121,7 @@ extern "C" int nms_sorted(const float* boxes_sorted, int64_t n, float iou_thresh
     dim3 grid(col_blocks, col_blocks);
     nms_mask_kernel<<<grid, 64, 0, s>>>((const float4*)boxes_sorted, (int)n, iou_threshold, (float)offset,
                                         (uint64_t*)workspace, col_blocks);
-    nms_reduce_kernel<<<1, 256, (size_t)col_blocks * 8, s>>>((const uint64_t*)workspace, (int)n, col_blocks, keep_flags,
+    nms_reduce_kernel<<<1, NMS_RT, (size_t)col_blocks * 8, s>>>((const uint64_t*)workspace, (int)n, col_blocks, keep_flags,
                                                             num_kept, max_num, kept_pos, kept_cap);
     return swin_launch_status();
 }

@@ -78,6 +78,37 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nchw(const T* __restrict__ 
     }
 }
 
+// NCHW forward with ONE WAVE per output bin: the lanes share the bin's sampling grid (adjacent lanes = adjacent sample
+// columns, <= 1 px apart: coalesced) and the partial sums are folded with a wave reduction.  For few outputs with large
+// adaptive grids -- the mask targets (mask_target.py:66-122: 28x28 bins over RoIs hundreds of pixels wide on the
+// full-resolution 1-channel gt mask), where a thread per bin would walk hundreds of samples serially.
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_nchw_wave(const T* __restrict__ in, const float* __restrict__ rois,
+                                                               float* __restrict__ out, int C, int H, int W, int64_t total,
+                                                               int ph, int pw, float scale, int sr, int aligned) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); idx < total; idx += (int64_t)gridDim.x * 4) {
+        int j = (int)(idx % pw), i = (int)((idx / pw) % ph);
+        int c = (int)((idx / pw / ph) % C);
+        int64_t k = idx / pw / ph / C;
+        RoiGeom g = roi_geom(rois + 5 * k, scale, aligned, ph, pw, sr);
+        const T* p = in + ((int64_t)g.batch * C + c) * H * W;
+        float acc = 0.f;
+        const int ns = g.grid_h * g.grid_w;
+        for (int s = lane; s < ns; s += 64) {
+            const int iy = s / g.grid_w, ix = s - iy * g.grid_w;
+            float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+            float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+            Bilin b = bilin_setup(H, W, y, x);
+            if (!b.valid) continue;
+            acc += b.w1 * Elt<T>::ld(p + b.yl * W + b.xl) + b.w2 * Elt<T>::ld(p + b.yl * W + b.xh) +
+                   b.w3 * Elt<T>::ld(p + b.yh * W + b.xl) + b.w4 * Elt<T>::ld(p + b.yh * W + b.xh);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[idx] = acc / g.count;
+    }
+}
+
 __global__ __launch_bounds__(256) void roi_align_bwd_nchw(const float* __restrict__ gout, const float* __restrict__ rois,
                                                           float* __restrict__ gin, int C, int H, int W, int64_t total,
                                                           int ph, int pw, float scale, int sr, int aligned) {
@@ -394,13 +425,22 @@ extern "C" int roi_align_fwd(const void* input, const float* rois, float* output
         else return SWIN_ERR_UNSUPPORTED;
     } else {
         int64_t total = (int64_t)K * C * ph * pw;
-        if (in_dtype == SWIN_F32)
+        const bool wave = sampling_ratio <= 0 && total <= (1 << 18);      // few bins, adaptive grid: wave per bin
+        if (in_dtype != SWIN_F32 && in_dtype != SWIN_BF16) return SWIN_ERR_UNSUPPORTED;
+        if (wave) {
+            int blocks = (int)((total + 3) / 4);
+            if (in_dtype == SWIN_F32)
+                roi_align_fwd_nchw_wave<float><<<blocks, 256, 0, s>>>((const float*)input, rois, output, C, H, W, total, ph, pw,
+                                                                      spatial_scale, sampling_ratio, aligned);
+            else
+                roi_align_fwd_nchw_wave<bf16><<<blocks, 256, 0, s>>>((const bf16*)input, rois, output, C, H, W, total, ph, pw,
+                                                                     spatial_scale, sampling_ratio, aligned);
+        } else if (in_dtype == SWIN_F32)
             roi_align_fwd_nchw<float><<<ra_blocks(total), 256, 0, s>>>((const float*)input, rois, output, C, H, W, total, ph, pw,
                                                                       spatial_scale, sampling_ratio, aligned);
-        else if (in_dtype == SWIN_BF16)
+        else
             roi_align_fwd_nchw<bf16><<<ra_blocks(total), 256, 0, s>>>((const bf16*)input, rois, output, C, H, W, total, ph, pw,
                                                                      spatial_scale, sampling_ratio, aligned);
-        else return SWIN_ERR_UNSUPPORTED;
     }
     return swin_launch_status();
 }

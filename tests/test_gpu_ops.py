@@ -605,3 +605,14 @@ def test_delta2bbox_and_bbox_targets(ops):
     # round trip: decode(encode(gt)) == gt for the positives
     back = ops.delta2bbox(b, d, means, stds, None, wh_ratio_clip=1e-9)
     np.testing.assert_allclose(back.cpu().numpy()[pos], g64[pos], rtol=1e-5, atol=2e-3)
+
+
+def test_roi_align_nchw_thread_per_bin_path(ops):
+    """> 2^18 output bins: the NCHW forward takes the thread-per-bin kernel (the wave-per-bin one serves small outputs)."""
+    rng = np.random.RandomState(9)
+    inp = rng.randn(1, 32, 20, 24).astype(np.float32)
+    rois = _rand_rois(rng, 200, 1, 96, 80)
+    ref = D.roi_align_c(inp, rois, 7, 0.25, 0, True)
+    assert ref.size > (1 << 18)
+    out = ops.roi_align(torch.from_numpy(inp).cuda(), torch.from_numpy(rois).cuda(), 7, 0.25, 0, 'avg', True)
+    close(out, torch.from_numpy(ref), ATOL32)
