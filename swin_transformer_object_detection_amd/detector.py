@@ -301,6 +301,7 @@ class RPNHead(nn.Module):
             w = torch.cat([_cast(self.rpn_cls.weight, dt).view(A, C), _cast(self.rpn_reg.weight, dt).view(4 * A, C),
                            torch.zeros(pad, C, device=self.rpn_cls.weight.device, dtype=dt)], 0)
             b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias, torch.zeros(pad, device=w.device)], 0).to(dt)
+        ys = []
         for x in feats:
             x = _conv(x, self.rpn_conv, dt, padding=1, relu=True)
             if dt == torch.bfloat16:
@@ -308,10 +309,27 @@ class RPNHead(nn.Module):
                 y = ops.linear(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w, b, dt).view(N, H, W, -1)
                 cls.append(y[..., :A].permute(0, 3, 1, 2))
                 reg.append(y[..., A:5 * A].permute(0, 3, 1, 2))
+                ys.append(y.view(N, H * W, -1))
             else:
                 cls.append(_conv(x, self.rpn_cls, dt))
                 reg.append(_conv(x, self.rpn_reg, dt))
+        self._flat = None
+        if ys:
+            # the anchor-major flattening that loss() and get_bboxes() need (anchor_head.py:474-486, rpn_head.py:119-125):
+            # one strided concatenation per head straight from the token-major GEMM outputs
+            N = ys[0].size(0)
+            self._flat = (cls, torch.cat([y[:, :, :A] for y in ys], 1).reshape(N, -1),
+                          torch.cat([y[:, :, A:5 * A] for y in ys], 1).reshape(N, -1, 4))
         return cls, reg
+
+    def _flattened(self, cls_scores, bbox_preds):
+        """(B, sum_l H_l W_l A) logits and (B, same, 4) deltas, levels concatenated in (h, w, a) order."""
+        f = getattr(self, '_flat', None)
+        if f is not None and f[0] is cls_scores:
+            return f[1], f[2]
+        B = cls_scores[0].size(0)
+        return (torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1),
+                torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1))
 
     # ---- training targets + loss (anchor_head.py:175-493) ----
     def loss(self, cls_scores, bbox_preds, gt_bboxes, img_shapes):
@@ -323,8 +341,7 @@ class RPNHead(nn.Module):
         sizes = [tuple(c.shape[-2:]) for c in cls_scores]
         anchors = self.anchor_generator.grid_anchors_cat(sizes, cls_scores[0].device)
         B = cls_scores[0].size(0)
-        cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1)
-        reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
+        cls, reg = self._flattened(cls_scores, bbox_preds)
         loss_cls = loss_bbox = total = 0.
         for i in range(B):
             _, tgt, _, _, is_pos, valid, idx = assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg, self.means, self.stds)
@@ -344,9 +361,13 @@ class RPNHead(nn.Module):
         B = cls_scores[0].size(0)
         nms_pre = cfg['nms_pre']
         sc_l, bp_l, an_l, id_l = [], [], [], []
-        for lvl, (cs, bp) in enumerate(zip(cls_scores, bbox_preds)):
-            s = cs.detach().permute(0, 2, 3, 1).reshape(B, -1).float().sigmoid()
-            d = bp.detach().permute(0, 2, 3, 1).reshape(B, -1, 4).float()
+        cls_all, reg_all = self._flattened(cls_scores, bbox_preds)
+        s_all, d_all = cls_all.detach().float().sigmoid(), reg_all.detach().float()
+        off = 0
+        for lvl in range(len(cls_scores)):
+            na = mlvl_anchors[lvl].size(0)
+            s, d = s_all[:, off:off + na], d_all[:, off:off + na]
+            off += na
             an = mlvl_anchors[lvl][None].expand(B, -1, -1)
             if s.shape[1] > nms_pre:
                 ranked, rank_inds = s.sort(dim=1, descending=True, stable=True)

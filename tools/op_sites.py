@@ -45,4 +45,4 @@ bysite = collections.Counter()
 for (n, site, shp), k in s.c.items():
     bysite[site] += k
 print("== by site"); [print(f"{k:5d} {site}") for site, k in bysite.most_common(45)]
-print("== by (op, site, first-arg)"); [print(f"{k:5d} {n:28s} {site:26s} {shp}") for (n, site, shp), k in s.c.most_common(90)]
+print("== by (op, site, first-arg)"); [print(f"{k:5d} {n:28s} {site:26s} {shp}") for (n, site, shp), k in s.c.most_common()]
