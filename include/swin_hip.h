@@ -55,7 +55,11 @@ int swin_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
 int swin_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                        const float* rstd, const void* dres, void* dx, void* dx_scaled, const float* scale,
                        int64_t rows_per_sample, float* dgamma, float* dbeta,
-                       int64_t rows, int C, int dtype, void* stream);
+                       int64_t rows, int C, int dtype, void* workspace, void* stream);
+/* workspace (nullable): swin_layernorm_bwd_workspace_bytes(rows, C, dtype) bytes of scratch, no initialisation needed.
+ * With it the per-block partial sums of dgamma / dbeta are stored and summed by a second small kernel; without it they
+ * are added with float atomics (hundreds of blocks on the same 2C addresses: several times slower). */
+int64_t swin_layernorm_bwd_workspace_bytes(int64_t rows, int C, int dtype);
 
 /* Fused residual + LayerNorm:  xo = x + scale[b] * y ;  n = LN(xo).
  * Replaces swin_transformer.py:252 (`shortcut + drop_path(x)`) followed by :253's norm2, and
@@ -120,7 +124,8 @@ int swin_patch_merge_ln_fwd(const void* x, const float* gamma, const float* beta
                             float* rstd, int B, int H, int W, int C, float eps, int dtype, void* stream);
 int swin_patch_merge_ln_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                             const float* rstd, void* dx, float* dgamma, float* dbeta,
-                            int B, int H, int W, int C, int dtype, void* stream);
+                            int B, int H, int W, int C, int dtype, void* workspace, void* stream);
+/* workspace (nullable): swin_layernorm_bwd_workspace_bytes(B*ceil(H/2)*ceil(W/2), 4*C, dtype) bytes. */
 
 /* PatchEmbed im2row: img (B,3,Hi,Wi) f32 NCHW -> rows (B*ceil(Hi/4)*ceil(Wi/4), 48) dtype, zero pad
  * right/bottom (swin_transformer.py:433-438; column index = c*16 + ky*4 + kx = conv weight layout). */

@@ -15,7 +15,8 @@ _p, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 SIGNATURES = {
     "swin_hip_abi_version": [],
     "swin_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _i, _p],
-    "swin_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i, _i, _p],
+    "swin_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i, _i, _p, _p],
+    "swin_layernorm_bwd_workspace_bytes": [_i64, _i, _i],
     "swin_add_layernorm_fwd": [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _i, _p],
     "swin_window_attn_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "swin_window_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
@@ -25,7 +26,7 @@ SIGNATURES = {
     "swin_bias_gelu_fwd": [_p, _p, _p, _i64, _i, _i, _p],
     "swin_bias_gelu_bwd": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
     "swin_patch_merge_ln_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
-    "swin_patch_merge_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "swin_patch_merge_ln_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "swin_patch_im2row": [_p, _p, _i, _i, _i, _i, _p],
     "fpn_upsample_add_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "fpn_upsample_add_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -46,7 +47,7 @@ SIGNATURES = {
     "det_bbox_targets": [_p, _p, _p, _p, _p, _i, _p, _i64, _p, _p, _i, _p, _p, _p, _p, _p],
     "det_delta2bbox": [_p, _p, _i64, _p, _p, _f, _f, _f, _p, _p],
 }
-_RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
+_RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
             "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64}
 
 _lib = None

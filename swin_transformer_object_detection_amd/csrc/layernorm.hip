@@ -134,14 +134,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(Src src, const T* __restric
                                                      const T* __restrict__ dres, T* __restrict__ dx,
                                                      T* __restrict__ dy2, const float* __restrict__ scale,
                                                      int64_t rows_per_sample, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t rows, int C) {
+                                                     float* __restrict__ dbeta, int64_t rows, int C, int use_slab,
+                                                     float* __restrict__ partials) {
     constexpr int VEC = Vec16<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // dgamma[C] | dbeta[C]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // NSLAB x (dgamma[C] | dbeta[C]), or one such row
     const int chunks = C / VEC;
     const int lig = threadIdx.x % G, gid = threadIdx.x / G;
     const int rpb = 256 / G;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
-    __syncthreads();
+    if (!use_slab) {
+        for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
+        __syncthreads();
+    }
     float ag[NV][VEC], ab[NV][VEC];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -153,9 +156,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(Src src, const T* __restric
         const bool rv = row < rows;
         float mean = 0.f, rstd = 0.f;
         if (rv) { mean = mean_in[row]; rstd = rstd_in[row]; }
-        Vec16<T> xv[NV], gv[NV];
+        Vec16<T> xv[NV], gv[NV], rsv[NV];
         bool real[NV];
         float s1 = 0.f, s2 = 0.f;
+        const bool has_res = !MERGE && dres != nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int vi = lig + i * G;
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(Src src, const T* __restric
             if (rv && vi < chunks) {
                 real[i] = src.load(row, vi, xv[i]);
                 gv[i].load(dy + row * C + vi * VEC);
+                if (has_res) rsv[i].load(dres + row * C + vi * VEC);      // issued with the other loads: one latency
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float xh = (xv[i].get(e) - mean) * rstd;
@@ -180,8 +185,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(Src src, const T* __restric
         for (int i = 0; i < NV; ++i) {
             int vi = lig + i * G;
             if (rv && vi < chunks) {
-                Vec16<T> o, o2, r;
-                if (!MERGE && dres) r.load(dres + row * C + vi * VEC);
+                Vec16<T> o, o2;
                 float sc = 1.f;
                 if (!MERGE && dy2 && scale) sc = scale[row / rows_per_sample];
 #pragma unroll
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(Src src, const T* __restric
                     float xh = (xv[i].get(e) - mean) * rstd;
                     float gg = gv[i].get(e) * gamma[vi * VEC + e];
                     float d = rstd * (gg - s1 - xh * s2);
-                    if (!MERGE && dres) d += r.get(e);
+                    if (has_res) d += rsv[i].get(e);
                     o.set(e, d);
                     if (!MERGE && dy2) o2.set(e, d * sc);
                 }
@@ -208,7 +212,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(Src src, const T* __restric
             }
         }
     }
-    // block reduction of the parameter gradients: LDS atomics, then one global atomic per channel
+    // block reduction of the parameter gradients.  slab form (use_slab): row groups that share a wave are folded with one
+    // shuffle step, then every remaining group stores its partial row [2C] with plain LDS writes and the block sums the
+    // NSLAB rows -- LDS float atomics here are 16-way same-address conflicts and cost more than the streaming loop.
+    constexpr int NSLAB = (G == 16) ? 8 : 256 / G;
+    if (use_slab) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int vi = lig + i * G;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float a = ag[i][e], b = ab[i][e];
+                if (G == 16) { a += __shfl_xor(a, 16); b += __shfl_xor(b, 16); }
+                if (vi < chunks && (G != 16 || (gid & 1) == 0)) {
+                    const int slab = (G == 16) ? (gid >> 1) : gid;
+                    sm[slab * 2 * C + vi * VEC + e] = a;
+                    sm[slab * 2 * C + C + vi * VEC + e] = b;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < NSLAB; ++q) a += sm[q * 2 * C + i];
+            if (partials) partials[(int64_t)blockIdx.x * 2 * C + i] = a;      // plain store; ln_param_reduce_kernel sums
+            else atomicAdd(i < C ? &dgamma[i] : &dbeta[i - C], a);
+        }
+        return;
+    }
+    // wide rows whose slabs would not fit the LDS: LDS atomics (4-way conflicts at G = 64), one global atomic per channel
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int vi = lig + i * G;
@@ -247,16 +281,57 @@ static int ln_fwd_launch(Src src, const T* addy, const float* scale, int64_t rps
     return swin_launch_status();
 }
 
+// dgamma / dbeta += sum over the blocks' partial rows [nblk][2C] (written with plain stores: hundreds of blocks adding
+// to the same 2C addresses with float atomics run an order of magnitude below the atomic rate, guide G12)
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;                      // column of [dgamma | dbeta]; the 16 waves split the rows
+    float a = 0.f;
+    if (i < 2 * C) {
+        const float* p = partials + i;
+        int b = w;
+        for (; b + 48 < nblk; b += 64) {                       // 4 independent loads in flight per lane
+            const float v0 = p[(int64_t)b * 2 * C], v1 = p[(int64_t)(b + 16) * 2 * C];
+            const float v2 = p[(int64_t)(b + 32) * 2 * C], v3 = p[(int64_t)(b + 48) * 2 * C];
+            a += (v0 + v1) + (v2 + v3);
+        }
+        for (; b < nblk; b += 16) a += p[(int64_t)b * 2 * C];
+    }
+    red[w][lane] = a;
+    __syncthreads();
+    if (w == 0 && i < 2 * C) {
+        a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += red[q][lane];
+        float* dst = i < C ? dgamma + i : dbeta + (i - C);
+        *dst += a;
+    }
+}
+
+template <typename T> static int ln_bwd_blocks(int64_t rows, int C) {
+    LnLaunch p = ln_plan<T>(rows, C);
+    return p.blocks < 512 ? p.blocks : 512;
+}
+
 template <typename T, typename Src, bool MERGE>
 static int ln_bwd_launch(Src src, const T* dy, const float* gamma, const float* mean, const float* rstd,
                          const T* dres, T* dx, T* dy2, const float* scale, int64_t rps, float* dgamma, float* dbeta,
-                         int64_t rows, int C, hipStream_t s) {
+                         int64_t rows, int C, hipStream_t s, float* workspace = nullptr) {
     if (C % Vec16<T>::N != 0) return SWIN_ERR_UNSUPPORTED;
     LnLaunch p = ln_plan<T>(rows, C);
-    int blocks = p.blocks < 1024 ? p.blocks : 1024;
-    size_t shm = 2 * (size_t)C * sizeof(float);
+    int blocks = p.blocks < 512 ? p.blocks : 512;
+    const int nslab = p.G == 16 ? 8 : 256 / p.G;
+    size_t shm = (size_t)nslab * 2 * C * sizeof(float);
+    int use_slab = 1;
+    if (shm > 60000) { use_slab = 0; shm = 2 * (size_t)C * sizeof(float); }
+    float* partials = use_slab ? workspace : nullptr;
     LN_DISPATCH((ln_bwd_kernel<T, G, NV, Src, MERGE><<<blocks, 256, shm, s>>>(src, dy, gamma, mean, rstd, dres, dx, dy2,
-                                                                              scale, rps, dgamma, dbeta, rows, C)))
+                                                                              scale, rps, dgamma, dbeta, rows, C, use_slab,
+                                                                              partials)))
+    if (partials)
+        ln_param_reduce_kernel<<<(2 * C + 63) / 64, 1024, 0, s>>>(partials, blocks, C, dgamma, dbeta);
     return swin_launch_status();
 }
 
@@ -294,10 +369,18 @@ extern "C" int swin_add_layernorm_fwd(const void* x, const void* yadd, const flo
     return SWIN_ERR_UNSUPPORTED;
 }
 
+// bytes of the optional parameter-gradient workspace of swin_layernorm_bwd (C = row width) and
+// swin_patch_merge_ln_bwd (pass 4 * C): one partial [dgamma | dbeta] row per thread block
+extern "C" int64_t swin_layernorm_bwd_workspace_bytes(int64_t rows, int C, int dtype) {
+    if (rows <= 0 || C <= 0) return 16;
+    int blocks = dtype == SWIN_BF16 ? ln_bwd_blocks<bf16>(rows, C) : ln_bwd_blocks<float>(rows, C);
+    return (int64_t)blocks * 2 * C * (int64_t)sizeof(float);
+}
+
 extern "C" int swin_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, void* dx_scaled, const float* scale,
                                   int64_t rows_per_sample, float* dgamma, float* dbeta, int64_t rows, int C,
-                                  int dtype, void* stream) {
+                                  int dtype, void* workspace, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0)
         return SWIN_ERR_BAD_ARG;
     if (rows_per_sample <= 0) rows_per_sample = 1;
@@ -306,12 +389,12 @@ extern "C" int swin_layernorm_bwd(const void* dy, const void* x, const float* ga
         PlainSrc<bf16> src{(const bf16*)x, C};
         return ln_bwd_launch<bf16, PlainSrc<bf16>, false>(src, (const bf16*)dy, gamma, mean, rstd, (const bf16*)dres,
                                                           (bf16*)dx, (bf16*)dx_scaled, scale, rows_per_sample, dgamma,
-                                                          dbeta, rows, C, s);
+                                                          dbeta, rows, C, s, (float*)workspace);
     } else if (dtype == SWIN_F32) {
         PlainSrc<float> src{(const float*)x, C};
         return ln_bwd_launch<float, PlainSrc<float>, false>(src, (const float*)dy, gamma, mean, rstd,
                                                             (const float*)dres, (float*)dx, (float*)dx_scaled, scale,
-                                                            rows_per_sample, dgamma, dbeta, rows, C, s);
+                                                            rows_per_sample, dgamma, dbeta, rows, C, s, (float*)workspace);
     }
     return SWIN_ERR_UNSUPPORTED;
 }
@@ -338,7 +421,7 @@ extern "C" int swin_patch_merge_ln_fwd(const void* x, const float* gamma, const 
 
 extern "C" int swin_patch_merge_ln_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                        const float* rstd, void* dx, float* dgamma, float* dbeta, int B, int H, int W,
-                                       int C, int dtype, void* stream) {
+                                       int C, int dtype, void* workspace, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || B <= 0 || H <= 0 || W <= 0 || C <= 0)
         return SWIN_ERR_BAD_ARG;
     int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
@@ -348,12 +431,12 @@ extern "C" int swin_patch_merge_ln_bwd(const void* dy, const void* x, const floa
         if (C % 8) return SWIN_ERR_UNSUPPORTED;
         MergeSrc<bf16> src{(const bf16*)x, C, H, W, Ho, Wo};
         return ln_bwd_launch<bf16, MergeSrc<bf16>, true>(src, (const bf16*)dy, gamma, mean, rstd, nullptr, (bf16*)dx,
-                                                         nullptr, nullptr, 1, dgamma, dbeta, rows, 4 * C, s);
+                                                         nullptr, nullptr, 1, dgamma, dbeta, rows, 4 * C, s, (float*)workspace);
     } else if (dtype == SWIN_F32) {
         if (C % 4) return SWIN_ERR_UNSUPPORTED;
         MergeSrc<float> src{(const float*)x, C, H, W, Ho, Wo};
         return ln_bwd_launch<float, MergeSrc<float>, true>(src, (const float*)dy, gamma, mean, rstd, nullptr, (float*)dx,
-                                                           nullptr, nullptr, 1, dgamma, dbeta, rows, 4 * C, s);
+                                                           nullptr, nullptr, 1, dgamma, dbeta, rows, 4 * C, s, (float*)workspace);
     }
     return SWIN_ERR_UNSUPPORTED;
 }

@@ -64,6 +64,12 @@ def _grad_buf(param):
 # --------------------------------------------------------------------------------------
 # LayerNorm
 # --------------------------------------------------------------------------------------
+def _ln_ws(rows, C, like):
+    """scratch for the per-block partial sums of the LayerNorm parameter gradients (no initialisation needed)"""
+    n = _lib.lib().swin_layernorm_bwd_workspace_bytes(rows, C, _dt(like))
+    return torch.empty(n // 4, device=like.device, dtype=torch.float32)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):
@@ -88,7 +94,7 @@ class _LayerNorm(torch.autograd.Function):
         dwb, dw, nw = _grad_buf(w)
         dbb, db, nb = _grad_buf(ctx.bias)
         call("swin_layernorm_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), None, _p(dx), None, None, 1,
-             _p(dwb), _p(dbb), rows, C, _dt(x), _s())
+             _p(dwb), _p(dbb), rows, C, _dt(x), _p(_ln_ws(rows, C, x)), _s())
         nw(); nb()
         return dx, dw, db, None
 
@@ -128,7 +134,7 @@ class _AddLayerNorm(torch.autograd.Function):
         dwb, dw, nw = _grad_buf(w)
         dbb, db, nb = _grad_buf(ctx.bias)
         call("swin_layernorm_bwd", _p(dn), _p(xo), _p(w), _p(mean), _p(rstd), _p(dxo), _p(dx), _p(dyb), _p(scale),
-             ctx.rps, _p(dwb), _p(dbb), rows, C, _dt(xo), _s())
+             ctx.rps, _p(dwb), _p(dbb), rows, C, _dt(xo), _p(_ln_ws(rows, C, xo)), _s())
         nw(); nb()
         return dx, (dyb if scale is not None else dx), None, None, dw, db, None
 
@@ -280,8 +286,9 @@ class _PatchMergeLN(torch.autograd.Function):
         dx = torch.empty_like(x)
         dwb, dw, nw = _grad_buf(w)
         dbb, db, nb = _grad_buf(ctx.bias)
+        ws = _ln_ws(B * ((H + 1) // 2) * ((W + 1) // 2), 4 * C, x)
         call("swin_patch_merge_ln_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dwb), _p(dbb), B, H, W, C,
-             _dt(x), _s())
+             _dt(x), _p(ws), _s())
         nw(); nb()
         return dx, dw, db, None, None, None, None
 

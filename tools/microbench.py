@@ -149,6 +149,18 @@ def roi():
         print(f"roi_align 1024 rois lvl{lvl}: fwd {med:7.1f} us  bwd {medb:7.1f} us")
 
 
+def lnbwd():
+    for (H, W, C, nH) in STAGES:
+        rows = 2 * H * W
+        x = torch.randn(rows, C, device="cuda").bfloat16(); dy = torch.randn_like(x); dres = torch.randn_like(x)
+        w = torch.ones(C, device="cuda"); mean = torch.zeros(rows, device="cuda"); rstd = torch.ones(rows, device="cuda")
+        dx = torch.empty_like(x); dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+        ws = Fn._ln_ws(rows, C, x)
+        med, _ = timeit(lambda: Fn.call("swin_layernorm_bwd", Fn._p(dy), Fn._p(x), Fn._p(w), Fn._p(mean), Fn._p(rstd), Fn._p(dres),
+                                        Fn._p(dx), None, None, 1, Fn._p(dg), Fn._p(db), rows, C, 1, Fn._p(ws), Fn._s()))
+        print(f"ln_bwd rows={rows} C={C}: {med:7.1f} us ({8.0 * x.numel() / med / 1e3:7.1f} GB/s)")
+
+
 def gelu():
     for (H, W, C, nH) in STAGES:
         rows, C4 = 2 * H * W, 4 * C
