@@ -56,16 +56,21 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t0, int col0, in
     return f;
 }
 
-template <typename XLoader>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ dy, XLoader X, float* __restrict__ dw,
-                                                       float* __restrict__ dbias, int64_t T, int N1, int N2,
-                                                       int64_t t_per_split, int use_atomic) {
-    __shared__ __attribute__((aligned(16))) bf16 lds[2][WT * WROW];        // [dY|X], single stage (40 KB -> 2 blocks/CU);
-                                                                           // the next stage waits in registers
+// KG k-groups of 4 waves per block: group g takes the stages g, g + KG, ... of the block's t range with its own LDS
+// stage buffer; the groups' accumulators are folded through LDS before the global atomics.  The float-atomic rate is
+// a chip-wide byte rate (guide G12): blocks x tile bytes is what it prices, so KG = 2 halves that cost at the same
+// number of resident waves.
+template <typename XLoader, int WKG>
+__global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(const bf16* __restrict__ dy, XLoader X, float* __restrict__ dw,
+                                                         float* __restrict__ dbias, int64_t T, int N1, int N2,
+                                                         int64_t t_per_split, int use_atomic) {
+    extern __shared__ __attribute__((aligned(16))) bf16 lds_all[];         // [WKG][dY|X][WT * WROW]: 40 KB per group
     const int n1_0 = blockIdx.y * WN, n2_0 = blockIdx.x * WN;
     const int64_t t_begin = (int64_t)blockIdx.z * t_per_split;
     const int64_t t_end = min(T, t_begin + t_per_split);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    bf16* ldsA = lds_all + (size_t)grp * 2 * WT * WROW;
+    bf16* ldsB = ldsA + WT * WROW;
     const int w1 = wave >> 1, w2 = wave & 1;                 // wave -> 64x64 sub-tile (n1, n2)
     const int c = lane & 31, h = lane >> 5;
     // staging: tile = 64 rows x 16 pieces of 16 B; thread handles rows (tid/16 + 16 i), piece tid%16
@@ -84,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int row = srow + 16 * i;
-            *(uint4*)&lds[0][row * WROW + spiece * 8] = ra[i];
-            *(uint4*)&lds[1][row * WROW + spiece * 8] = rb[i];
+            *(uint4*)&ldsA[row * WROW + spiece * 8] = ra[i];
+            *(uint4*)&ldsB[row * WROW + spiece * 8] = rb[i];
         }
     };
     f32x16 acc[2][2];
@@ -105,23 +110,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ 
         }
     };
 
-    if (t_begin < t_end) {
-        gload(t_begin);
+    // every group runs the same number of iterations (block-wide barriers); a stage beyond t_end loads zeros
+    const int64_t stages = (t_end - t_begin + WT - 1) / WT;
+    const int iters = (int)((stages + WKG - 1) / WKG);
+    if (iters > 0) {
+        int64_t t0 = t_begin + (int64_t)grp * WT;
+        gload(t0);
         if (do_bias) bias_acc();
         lstore();
         __syncthreads();
-        for (int64_t t0 = t_begin; t0 < t_end; t0 += WT) {
-            const bool more = t0 + WT < t_end;
-            if (more) { gload(t0 + WT); if (do_bias) bias_acc(); }
-            const bf16* As = lds[0];
-            const bf16* Bs = lds[1];
+        for (int it = 0; it < iters; ++it, t0 += (int64_t)WKG * WT) {
+            const bool more = it + 1 < iters;
+            if (more) { gload(t0 + (int64_t)WKG * WT); if (do_bias) bias_acc(); }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {                     // 16 t per MFMA k-step
                 bf16x8 af[2], bfr[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    af[i] = tr_frag(As, 16 * s, w1 * 64 + 32 * i, lane);     // A[row n1][k = t]
-                    bfr[i] = tr_frag(Bs, 16 * s, w2 * 64 + 32 * i, lane);    // B[k = t][col n2]
+                    af[i] = tr_frag(ldsA, 16 * s, w1 * 64 + 32 * i, lane);     // A[row n1][k = t]
+                    bfr[i] = tr_frag(ldsB, 16 * s, w2 * 64 + 32 * i, lane);    // B[k = t][col n2]
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -134,19 +141,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ 
             __syncthreads();
         }
     }
-    if (do_bias) {           // 16 threads (srow) share a piece column: reduce through LDS, one atomic per channel
+    float* red = reinterpret_cast<float*>(lds_all);           // 80 KB: [128][128] tile or [WKG*16][128] bias rows
+    if (do_bias) {           // 16 threads (srow) x WKG groups share a piece column: reduce through LDS, one atomic per channel
         __syncthreads();
-        float* red = reinterpret_cast<float*>(&lds[0][0]);          // [16 srow][128 cols]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[srow * WN + spiece * 8 + e] = bsum[e];
+        for (int e = 0; e < 8; ++e) red[(grp * 16 + srow) * WN + spiece * 8 + e] = bsum[e];
         __syncthreads();
-        if (tid < WN) {
+        if (threadIdx.x < WN) {
             float a = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a += red[r * WN + tid];
-            if (n1_0 + tid < N1) atomicAdd(dbias + n1_0 + tid, a);
+            for (int r = 0; r < 16 * WKG; ++r) a += red[r * WN + threadIdx.x];
+            if (n1_0 + (int)threadIdx.x < N1) atomicAdd(dbias + n1_0 + threadIdx.x, a);
         }
     }
+    // fold the k-groups: groups > 0 park their accumulators in LDS ([n1][n2] fp32, 64 KB), group 0 adds them
+    for (int g = 1; g < WKG; ++g) {
+        __syncthreads();
+        if (grp == g) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        red[(w1 * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h) * WN + w2 * 64 + 32 * j + c] = acc[i][j][reg];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        acc[i][j][reg] += red[(w1 * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h) * WN + w2 * 64 + 32 * j + c];
+        }
+    }
+    if (grp != 0) return;
     // D[row n1][col n2]: lane = n2 column, registers = n1 rows -> 32 consecutive n2 per half-wave: 128-B segments
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -165,20 +196,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16* __restrict__ 
         }
 }
 
-template <typename XLoader>
-static int wgrad_launch(const bf16* dy, XLoader X, float* dw, float* dbias, int64_t T, int N1, int N2, hipStream_t s) {
+template <typename XLoader, int WKG>
+static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, int64_t T, int N1, int N2, hipStream_t s) {
+    const size_t lds_bytes = (size_t)WKG * 2 * WT * WROW * sizeof(bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wgrad_kernel<XLoader, WKG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess)
+            return SWIN_ERR_LAUNCH;
+        attr_set = true;
+    }
     int g1 = (N1 + WN - 1) / WN, g2 = (N2 + WN - 1) / WN;
-    // enough splits to fill the chip (~2 blocks per CU), each split a multiple of the t-stage
+    // enough splits to fill the chip with 8 waves per CU (2 blocks of 4 waves or 1 block of 8), each split a multiple
+    // of WKG t-stages
     int64_t stages = (T + WT - 1) / WT;
-    int splits = (int)((512 + (int64_t)g1 * g2 - 1) / ((int64_t)g1 * g2));
-    if (splits > stages) splits = (int)stages;
+    int splits = (int)((512 / WKG + (int64_t)g1 * g2 - 1) / ((int64_t)g1 * g2));
+    int64_t max_splits = (stages + WKG - 1) / WKG;
+    if (splits > max_splits) splits = (int)max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
-    int64_t per = ((stages + splits - 1) / splits) * WT;
+    int64_t per = ((stages + splits - 1) / splits);
+    per = ((per + WKG - 1) / WKG) * WKG * WT;
     splits = (int)((T + per - 1) / per);
     dim3 grid(g2, g1, splits);
-    wgrad_kernel<XLoader><<<grid, 256, 0, s>>>(dy, X, dw, dbias, T, N1, N2, per, 1);
+    wgrad_kernel<XLoader, WKG><<<grid, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, 1);
     return swin_launch_status();
+}
+
+template <typename XLoader>
+static int wgrad_launch(const bf16* dy, XLoader X, float* dw, float* dbias, int64_t T, int N1, int N2, hipStream_t s) {
+    // few output tiles and a long t axis: the split-T atomics dominate -> two k-groups per block (half the atomic bytes);
+    // many tiles: two independent 4-wave blocks per CU overlap each other's barriers better
+    const int tiles = ((N1 + WN - 1) / WN) * ((N2 + WN - 1) / WN);
+    if (tiles <= 16) return wgrad_launch_kg<XLoader, 2>(dy, X, dw, dbias, T, N1, N2, s);
+    return wgrad_launch_kg<XLoader, 1>(dy, X, dw, dbias, T, N1, N2, s);
 }
 
 // dw (N1, N2) f32 += dy(T, N1)^T x(T, N2);  dbias (N1) f32 += column sums of dy (NULL to skip).
