@@ -231,7 +231,11 @@ class SwinTransformer(nn.Module):
                     probs += [blk.drop_path_prob, blk.drop_path_prob]
         if not probs:
             return
-        keep = 1.0 - torch.tensor(probs, device=device, dtype=torch.float32)[:, None]
+        ck = (tuple(probs), str(device))
+        if getattr(self, '_dp_keep_key', None) != ck:            # constant over training: one host->device copy, ever
+            self._dp_keep = 1.0 - torch.tensor(probs, device=device, dtype=torch.float32)[:, None]
+            self._dp_keep_key = ck
+        keep = self._dp_keep
         f = torch.floor(keep + torch.rand(len(probs), B, device=device, dtype=torch.float32)) / keep
         self._dp_pool = list(f.unbind(0))
 

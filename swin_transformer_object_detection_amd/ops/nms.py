@@ -55,7 +55,7 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
         boxes_for_nms = boxes
     else:
         max_coordinate = boxes.max()
-        offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+        offsets = idxs.to(boxes) * (max_coordinate + 1.0)        # mmcv: `+ torch.tensor(1).to(boxes)`; no host->device copy
         boxes_for_nms = boxes + offsets[:, None]
     nms_type = nms_cfg_.pop('type', 'nms')
     if nms_type != 'nms':
@@ -109,7 +109,7 @@ def nms_static(boxes, scores, iou_threshold, max_num, offset=0):
 def batched_nms_static(boxes, scores, idxs, iou_threshold, max_num):
     """batched_nms (single-pass branch, n < split_thr) with a fixed-size result: (dets (max_num,5), valid (max_num,))."""
     max_coordinate = boxes.max()
-    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    offsets = idxs.to(boxes) * (max_coordinate + 1.0)        # mmcv: `+ torch.tensor(1).to(boxes)`; no host->device copy
     inds, valid = nms_static(boxes + offsets[:, None], scores, iou_threshold, max_num)
     dets = torch.cat([boxes[inds], scores[inds, None]], -1)
     return torch.where(valid[:, None], dets, torch.zeros_like(dets)), valid
