@@ -10,6 +10,8 @@ synthetic batch of 2 images per GPU (BASELINE.json configs[1]; weak scaling).  R
 line.  Besides the contract keys it carries
   roofline     : the WindowAttention forward kernel (stage-1 geometry of this workload) timed live with
                  HIP events on the launch stream, against the HBM roofline (DESIGN.md section 5);
+  roofline_mfma_kernels : the same measurement for the MFMA-bound kernels with the largest share of the step
+                 (3x3 conv forward/data-gradient, conv weight gradient, linear weight gradient);
   cpu_baseline : the CPU oracle (torch-CPU fp32 restatement + C RoIAlign/NMS) timed on the host cores
                  on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -27,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 IMG_H, IMG_W, PER_GPU_BATCH = 800, 1280, 2
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
 def parse():
@@ -91,6 +94,51 @@ def attention_roofline(device, steps=30):
             "avg_launch_ms": round(avg_ms, 5), "median_launch_ms": round(ms[len(ms) // 2], 5),
             "algorithmic_bytes_per_launch": alg_bytes,
             "shape": {"B": B, "H": H, "W": W, "C": C, "heads": nH, "shift": 3, "windows": B * 29 * 46}}
+
+
+def gemm_rooflines(device, steps=20):
+    """The MFMA-bound kernels that take the largest share of the step, timed the same way (HIP events around the
+    C-ABI launch on the launch stream) at the workload's geometry: 3x3 conv on the P2 map (2x200x320, 256 -> 256,
+    forward = data-gradient kernel), its weight gradient, and the weight gradient of a stage-3 MLP linear.
+    Algorithmic flops per launch: SURVEY 8(d) formulas (2*B*H*W*256*256*9; 2*T*N1*N2)."""
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    B, H, W, C = PER_GPU_BATCH, IMG_H // 4, IMG_W // 4, 256
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H, W, C, generator=g).to(device=device, dtype=torch.bfloat16)
+    dy = torch.randn(B, H, W, C, generator=g).to(device=device, dtype=torch.bfloat16)
+    w = (torch.randn(C, 3, 3, C, generator=g) * 0.02).to(device=device, dtype=torch.bfloat16)
+    b = torch.zeros(C, device=device)
+    y = torch.empty_like(x)
+    dw = torch.zeros(C, 3, 3, C, device=device)
+    db = torch.zeros(C, device=device)
+    T, N1, N2 = PER_GPU_BATCH * (IMG_H // 16) * (IMG_W // 16), 1536, 384
+    ldy = torch.randn(T, N1, generator=g).to(device=device, dtype=torch.bfloat16)
+    lx = torch.randn(T, N2, generator=g).to(device=device, dtype=torch.bfloat16)
+    ldw = torch.zeros(N1, N2, device=device)
+    ldb = torch.zeros(N1, device=device)
+    cases = [
+        ("gemm_bf16_kernel<ConvA> (3x3 conv fwd/dgrad, P2 2x200x320x256)", 2.0 * B * H * W * C * C * 9,
+         lambda: Fn.call("conv3x3_nhwc_bf16", Fn._p(x), Fn._p(w), Fn._p(b), Fn._p(y), B, H, W, C, C, 0, Fn._s())),
+        ("wgrad_kernel<ConvX> (3x3 conv weight gradient, P2)", 2.0 * B * H * W * C * C * 9,
+         lambda: Fn.call("wgrad_conv3x3_nhwc_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), B, H, W, C, C, Fn._s())),
+        (f"wgrad_kernel<PlainX> (fc1 weight gradient, stage 3: T={T}, {N1}x{N2})", 2.0 * T * N1 * N2,
+         lambda: Fn.call("wgrad_linear_bf16", Fn._p(ldy), Fn._p(lx), Fn._p(ldw), Fn._p(ldb), T, N1, N2, Fn._s())),
+    ]
+    out = []
+    for name, flops, fn in cases:
+        for _ in range(3):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for s_, e_ in ev:
+            s_.record(); fn(); e_.record()
+        torch.cuda.synchronize()
+        ms = sorted(s_.elapsed_time(e_) for s_, e_ in ev)
+        avg = sum(ms) / len(ms)
+        tf = flops / (avg * 1e-3) / 1e12
+        out.append({"kernel": name, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg, 5),
+                    "algorithmic_flops_per_launch": flops})
+    return out
 
 
 def cpu_baseline():
@@ -203,6 +251,7 @@ def main():
         raise SystemExit(f"non-finite loss in the timed region: {logs}")
 
     roof = attention_roofline(device) if rank == 0 else None
+    roof_gemm = gemm_rooflines(device) if rank == 0 else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -217,7 +266,7 @@ def main():
                                    "AdamW, DropPath 0.1 (BASELINE.json configs[1])",
                        "global_batch": gb, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
             "losses": {k: round(v, 4) for k, v in logs.items()},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_mfma_kernels": roof_gemm, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

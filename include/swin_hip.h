@@ -237,6 +237,12 @@ int det_bbox_targets(const float* bboxes, const int64_t* inds, const uint8_t* fl
 int det_delta2bbox(const float* rois, const float* deltas, int64_t n, const float* means, const float* stds,
                    float max_h, float max_w, float wh_ratio_clip, float* out, void* stream);
 
+/* det_paste_masks: test-time FCNMaskHead.get_seg_masks / _do_paste_mask (fcn_mask_head.py:169-300, :303-377):
+ *   mask_logits (N, num_classes, mh, mw) f32|bf16, labels (N) i64, boxes (N,4) f32 in output-image coordinates ->
+ *   out (N, img_h, img_w) u8 = (bilinear resample of sigmoid(logits[n, labels[n]]) into the box) >= thr. */
+int det_paste_masks(const void* mask_logits, const int64_t* labels, const float* boxes, int N, int num_classes,
+                    int mh, int mw, int img_h, int img_w, float thr, int in_dtype, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

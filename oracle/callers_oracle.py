@@ -197,3 +197,64 @@ def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0,
         p = assigned > 0
         labels[p] = np.asarray(gt_labels, np.int64)[assigned[p] - 1]
     return assigned, max_ov, labels
+
+
+# ---- test-time path (checker for detector.simple_test and csrc/mask_paste.hip) -----------------------------------
+def paste_masks(mask_logits, labels, boxes, img_h, img_w, thr=0.5):
+    """FCNMaskHead.get_seg_masks + _do_paste_mask (mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:218-300, :303-377;
+    GPU branch: whole image, skip_empty=False): sigmoid, class channel, F.grid_sample(bilinear, zeros padding,
+    align_corners=False) on the normalised grid of the box, `>= thr`.  -> (bool (N,img_h,img_w), float32 values)."""
+    m = np.asarray(mask_logits, np.float32)
+    N, nc, mh, mw = m.shape
+    boxes = np.asarray(boxes, np.float32).reshape(-1, 4)
+    vals = np.zeros((N, img_h, img_w), np.float32)
+    ys = np.arange(img_h, dtype=np.float32) + np.float32(0.5)
+    xs = np.arange(img_w, dtype=np.float32) + np.float32(0.5)
+    for n in range(N):
+        p = (np.float32(1) / (np.float32(1) + np.exp(-m[n, int(labels[n])]))).astype(np.float32)
+        x0, y0, x1, y1 = boxes[n]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            gy = (ys - y0) / (y1 - y0) * np.float32(2) - np.float32(1)
+            gx = (xs - x0) / (x1 - x0) * np.float32(2) - np.float32(1)
+        gy[np.isinf(gy)] = 0
+        gx[np.isinf(gx)] = 0
+        iy = ((gy + np.float32(1)) * np.float32(mh) - np.float32(1)) / np.float32(2)
+        ix = ((gx + np.float32(1)) * np.float32(mw) - np.float32(1)) / np.float32(2)
+        fy, fx = np.floor(iy), np.floor(ix)
+        wy1, wx1 = (iy - fy).astype(np.float32), (ix - fx).astype(np.float32)
+        wy0, wx0 = np.float32(1) - wy1, np.float32(1) - wx1
+        y0i, x0i = fy.astype(np.int64), fx.astype(np.int64)
+
+        def tap(yy, xx):
+            ok = ((yy >= 0) & (yy < mh))[:, None] & ((xx >= 0) & (xx < mw))[None, :]
+            v = p[np.clip(yy, 0, mh - 1)[:, None], np.clip(xx, 0, mw - 1)[None, :]]
+            return np.where(ok, v, np.float32(0))
+        v = tap(y0i, x0i) * (wy0[:, None] * wx0[None, :])
+        v = v + tap(y0i, x0i + 1) * (wy0[:, None] * wx1[None, :])
+        v = v + tap(y0i + 1, x0i) * (wy1[:, None] * wx0[None, :])
+        v = v + tap(y0i + 1, x0i + 1) * (wy1[:, None] * wx1[None, :])
+        vals[n] = np.nan_to_num(v.astype(np.float32), nan=0.0)
+    return vals >= np.float32(thr), vals
+
+
+def bbox2result(bboxes, labels, num_classes):
+    """mmdet/core/bbox/transforms.py:99-117."""
+    bboxes, labels = np.asarray(bboxes, np.float32).reshape(-1, 5), np.asarray(labels, np.int64)
+    return [bboxes[labels == i] for i in range(num_classes)]
+
+
+def bbox_head_get_bboxes(rois, cls_score, bbox_pred, img_shape, scale_factor, rescale, score_thr, nms_cfg, max_per_img,
+                         means=(0., 0., 0., 0.), stds=(.1, .1, .2, .2)):
+    """BBoxHead.get_bboxes (mmdet/models/roi_heads/bbox_heads/bbox_head.py:270-373) for one image, class-specific
+    regression: softmax, per-class decode clipped to img_shape, optional division by scale_factor, multiclass_nms."""
+    cls_score = np.asarray(cls_score, np.float32)
+    e = np.exp(cls_score - cls_score.max(1, keepdims=True))
+    scores = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    rois = np.asarray(rois, np.float32)
+    n, nc = scores.shape[0], scores.shape[1] - 1
+    d = np.asarray(bbox_pred, np.float32).reshape(n * nc, 4)
+    r = np.repeat(rois[:, 1:5], nc, axis=0)
+    boxes = delta2bbox(r, d, means, stds, img_shape).reshape(n, nc * 4)
+    if rescale:
+        boxes = (boxes.reshape(n, nc, 4) / np.asarray(scale_factor, np.float32)).reshape(n, nc * 4)
+    return multiclass_nms(boxes, scores, score_thr, nms_cfg, max_per_img)

@@ -260,6 +260,45 @@ def _conv(x, conv, dtype, padding=0, relu=False):
     return F.relu(y, inplace=True) if relu else y
 
 
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1):
+    """mmdet/core/post_processing/bbox_nms.py:7-93 (no score_factors): multi_bboxes (n, 4) or (n, 4*num_classes),
+    multi_scores (n, num_classes + 1) with the background LAST.  -> (dets (k,5), labels (k,))."""
+    num_classes = multi_scores.size(1) - 1
+    if multi_bboxes.shape[1] > 4:
+        bboxes = multi_bboxes.view(multi_scores.size(0), -1, 4)
+    else:
+        bboxes = multi_bboxes[:, None].expand(multi_scores.size(0), num_classes, 4)
+    scores = multi_scores[:, :-1]
+    labels = torch.arange(num_classes, dtype=torch.long, device=scores.device).view(1, -1).expand_as(scores)
+    bboxes, scores, labels = bboxes.reshape(-1, 4), scores.reshape(-1), labels.reshape(-1)
+    inds = (scores > score_thr).nonzero(as_tuple=False).squeeze(1)            # test time: a host sync is acceptable
+    bboxes, scores, labels = bboxes[inds], scores[inds], labels[inds]
+    if bboxes.numel() == 0:
+        return torch.cat([bboxes, scores[:, None]], -1), labels
+    dets, keep = ops.batched_nms(bboxes.float().contiguous(), scores.float().contiguous(), labels, nms_cfg)   # HIP nms
+    if max_num > 0:
+        dets, keep = dets[:max_num], keep[:max_num]
+    return dets, labels[keep]
+
+
+def _sf4(scale_factor):
+    """img_meta['scale_factor'] as (w, h, w, h) floats (a scalar or the 4-vector of the Resize transform)."""
+    try:
+        v = [float(t) for t in scale_factor]
+    except TypeError:
+        v = [float(scale_factor)] * 4
+    return v if len(v) == 4 else [v[0]] * 4
+
+
+def bbox2result(bboxes, labels, num_classes):
+    """mmdet/core/bbox/transforms.py:99-117: per-class list of (k_c, 5) numpy arrays."""
+    import numpy as np
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)]
+    b, l = bboxes.detach().float().cpu().numpy(), labels.detach().cpu().numpy()
+    return [b[l == i, :] for i in range(num_classes)]
+
+
 # ------------------------------------------------------------------------------------------
 # RPN
 # ------------------------------------------------------------------------------------------
@@ -330,6 +369,11 @@ class RPNHead(nn.Module):
         B = cls_scores[0].size(0)
         return (torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1),
                 torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1))
+
+    def simple_test_rpn(self, x, img_metas):
+        """dense_test_mixins.py:29-49: proposals of the test-time config, one (n, 5) tensor per image."""
+        cls_scores, bbox_preds = self(x)
+        return self.get_bboxes(cls_scores, bbox_preds, [m['img_shape'] for m in img_metas], self.test_cfg)
 
     # ---- training targets + loss (anchor_head.py:175-493) ----
     def loss(self, cls_scores, bbox_preds, gt_bboxes, img_shapes):
@@ -523,6 +567,22 @@ class Shared2FCBBoxHead(nn.Module):
         return dict(loss_cls=loss_cls * self.loss_cls_weight, acc=acc, loss_bbox=loss_bbox * self.loss_bbox_weight)
 
 
+    @torch.no_grad()
+    def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+        """bbox_head.py:270-373 for one image: rois (n,5), class-specific deltas (n, 4*num_classes)."""
+        scores = F.softmax(cls_score.float(), dim=-1)
+        n, nc = scores.size(0), self.num_classes
+        deltas = bbox_pred.float().reshape(n * nc, 4)
+        boxes = rois[:, 1:5].float()[:, None, :].expand(n, nc, 4).reshape(n * nc, 4)
+        dec = ops.delta2bbox if boxes.is_cuda else delta2bbox
+        bboxes = dec(boxes.contiguous(), deltas.contiguous(), self.means, self.stds, max_shape=img_shape).view(n, nc * 4)
+        if rescale and n > 0:
+            bboxes = (bboxes.view(n, nc, 4) / bboxes.new_tensor(_sf4(scale_factor))).view(n, nc * 4)
+        if cfg is None:
+            return bboxes, scores
+        return multiclass_nms(bboxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+
+
 @HEADS.register_module()
 class FCNMaskHead(nn.Module):
     """fcn_mask_head.py:20-126: 4x (conv3x3+ReLU), deconv 2x2 s2 + ReLU, conv1x1 -> num_classes."""
@@ -577,6 +637,32 @@ class FCNMaskHead(nn.Module):
             return dict(loss_mask=per_roi.mean() * self.loss_mask_weight)
         loss = (per_roi * valid).sum() / valid.sum().clamp(min=1)
         return dict(loss_mask=loss * self.loss_mask_weight)
+
+
+    @torch.no_grad()
+    def get_seg_masks(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale):
+        """fcn_mask_head.py:169-300: per-class lists of (img_h, img_w) bool numpy masks.  Sigmoid, class select,
+        bilinear paste into the box and the `mask_thr_binary` test run as one HIP kernel (ops.paste_masks)."""
+        import numpy as np
+        cls_segms = [[] for _ in range(self.num_classes)]
+        bboxes = det_bboxes[:, :4].float()
+        if rescale:
+            img_h, img_w = int(ori_shape[0]), int(ori_shape[1])
+            bboxes = bboxes / bboxes.new_tensor(_sf4(scale_factor))
+        else:
+            img_h = int(np.round(ori_shape[0] * _sf4(scale_factor)[1]))
+            img_w = int(np.round(ori_shape[1] * _sf4(scale_factor)[0]))
+        thr = rcnn_test_cfg['mask_thr_binary']
+        if thr < 0:
+            raise NotImplementedError("get_seg_masks: soft (uint8-scaled) masks")
+        n = mask_pred.size(0)
+        if n == 0:
+            return cls_segms
+        im_mask = ops.paste_masks(mask_pred, det_labels, bboxes, img_h, img_w, thr).cpu().numpy()
+        labels = det_labels.cpu().numpy()
+        for i in range(n):
+            cls_segms[labels[i]].append(im_mask[i])
+        return cls_segms
 
 
 @HEADS.register_module()
@@ -648,6 +734,42 @@ class StandardRoIHead(nn.Module):
         return losses
 
 
+    # ---- test time (standard_roi_head.py:221-247, test_mixins.py:52-157, :246-317) ----
+    @torch.no_grad()
+    def simple_test(self, x, proposal_list, img_metas, rescale=False):
+        cfg = self.test_cfg
+        bbox_results, segm_results = [], []
+        nc = self.bbox_head.num_classes
+        feats = x[:self.bbox_roi_extractor.num_inputs]
+        for i, (props, meta) in enumerate(zip(proposal_list, img_metas)):
+            rois = bbox2roi([props[:, :4]])
+            rois[:, 0] = i
+            if rois.size(0) == 0:
+                det_bboxes, det_labels = rois.new_zeros((0, 5)), rois.new_zeros((0,), dtype=torch.long)
+            else:
+                cls_score, bbox_pred = self.bbox_head(self.bbox_roi_extractor(feats, rois))
+                det_bboxes, det_labels = self.bbox_head.get_bboxes(rois, cls_score, bbox_pred, meta['img_shape'],
+                                                                   meta['scale_factor'], rescale, cfg)
+            bbox_results.append(bbox2result(det_bboxes, det_labels, nc))
+            if self.mask_head is None:
+                continue
+            if det_bboxes.size(0) == 0:
+                segm_results.append([[] for _ in range(self.mask_head.num_classes)])
+                continue
+            # boxes back at the test scale for the RoI features (test_mixins.py:277-281)
+            mb = det_bboxes[:, :4]
+            if rescale:
+                mb = mb * mb.new_tensor(_sf4(meta['scale_factor']))
+            mask_rois = torch.cat([mb.new_full((mb.size(0), 1), i), mb], 1)
+            mask_pred = self.mask_head(self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], mask_rois))
+            # get_seg_masks receives the TEST-scale boxes and undoes the scale itself (test_mixins.py:299, fcn_mask_head.py:245)
+            segm_results.append(self.mask_head.get_seg_masks(mask_pred, mb, det_labels, cfg, meta['ori_shape'],
+                                                             meta['scale_factor'], rescale))
+        if self.mask_head is None:
+            return bbox_results
+        return list(zip(bbox_results, segm_results))
+
+
 @DETECTORS.register_module()
 class MaskRCNN(nn.Module):
     """TwoStageDetector wiring (two_stage.py:17-167) for the Mask R-CNN swin configs."""
@@ -688,6 +810,13 @@ class MaskRCNN(nn.Module):
         proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_shapes, proposal_cfg, static=True)
         losses.update(self.roi_head.forward_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks))
         return losses
+
+    @torch.no_grad()
+    def simple_test(self, img, img_metas, proposals=None, rescale=False):
+        """two_stage.py:187-204: per image (bbox_results, segm_results) in the reference's result format."""
+        x = self.extract_feat(img)
+        proposal_list = self.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
+        return self.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
 
     @staticmethod
     def parse_losses(losses):

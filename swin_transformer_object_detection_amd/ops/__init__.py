@@ -8,4 +8,5 @@ from .functional import (add_layer_norm, add_scaled, bias_gelu, conv3x3, layer_n
                          patch_merge_layer_norm, rel_bias_expand, upsample_add, window_attention)
 from .nms import batched_nms, batched_nms_static, nms, nms_static  # noqa: F401
 from .roi_align import RoIAlign, roi_align, roi_align_multilevel  # noqa: F401
-from .targets import bbox_targets, delta2bbox, max_iou_assign, random_sample, random_sample_raw  # noqa: F401
+from .targets import (bbox_targets, delta2bbox, max_iou_assign, paste_masks, random_sample,  # noqa: F401
+                      random_sample_raw)

@@ -106,3 +106,21 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
     call("det_delta2bbox", _p(r), _p(d), r.size(0), _f4(means), _f4(stds), mh, mw, float(wh_ratio_clip), _p(out), _s())
     return out
+
+
+def paste_masks(mask_logits, labels, boxes, img_h, img_w, thr):
+    """FCNMaskHead.get_seg_masks pasting (fcn_mask_head.py:257-300 with _do_paste_mask :303-377) in one kernel:
+    mask_logits (N, num_classes, mh, mw), labels (N,), boxes (N,4) in output-image coordinates ->
+    (N, img_h, img_w) bool: sigmoid mask of the labelled class resampled into its box, >= thr."""
+    if not mask_logits.is_cuda:
+        raise SwinHipError("paste_masks: GPU tensors only")
+    if mask_logits.dtype not in (torch.float32, torch.bfloat16):
+        mask_logits = mask_logits.float()
+    m = mask_logits.detach().contiguous()
+    N, nc, mh, mw = m.shape
+    out = torch.empty((N, int(img_h), int(img_w)), dtype=torch.uint8, device=m.device)
+    if N:
+        from .._lib import SWIN_BF16, SWIN_F32
+        call("det_paste_masks", _p(m), _p(labels.long().contiguous()), _p(boxes.detach().float().contiguous()), N, nc, mh, mw,
+             int(img_h), int(img_w), float(thr), SWIN_F32 if m.dtype == torch.float32 else SWIN_BF16, _p(out), _s())
+    return out.bool()
