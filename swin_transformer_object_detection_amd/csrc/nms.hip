@@ -49,7 +49,6 @@ __global__ __launch_bounds__(NMS_RT) void nms_reduce_kernel(const uint64_t* __re
                                                             uint8_t* __restrict__ keep, int32_t* __restrict__ num_kept,
                                                             int max_num, int32_t* __restrict__ kept_pos, int kept_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];   // col_blocks words
-    __shared__ uint64_t diag[64];
     __shared__ uint64_t kept_bits;
     __shared__ int kept_rows[64];
     __shared__ int kept_cnt, total;
@@ -59,20 +58,34 @@ __global__ __launch_bounds__(NMS_RT) void nms_reduce_kernel(const uint64_t* __re
     if (t == 0) total = 0;
     __syncthreads();
     int b = 0;
+    // wave 0 keeps the 64 diagonal words of the current block one per lane (prefetched one block ahead) and runs the
+    // greedy scan on SCALAR registers: `r` is wave-uniform, the word of a kept row comes by v_readlane, and the loop
+    // visits only the surviving bits (ctz) -- no LDS round trip and no 64 serial iterations on the critical path
+    uint64_t dnext = 0;
+    if (t < 64 && t < n) dnext = mask[(int64_t)t * col_blocks];
     for (; b < col_blocks; ++b) {
         const int lim = min(64, n - b * 64);
-        if (t < lim) diag[t] = mask[(int64_t)(b * 64 + t) * col_blocks + b];
-        __syncthreads();
-        if (t == 0) {
+        if (t < 64) {
+            const uint64_t dcur = dnext;
+            if (b + 1 < col_blocks && (b + 1) * 64 + t < n) dnext = mask[(int64_t)((b + 1) * 64 + t) * col_blocks + b + 1];
+            const unsigned dlo = (unsigned)dcur, dhi = (unsigned)(dcur >> 32);
             uint64_t r = remv[b], kb = 0;
-            int cnt = 0, tot = total;
-            for (int bit = 0; bit < lim; ++bit) {
-                if ((r >> bit) & 1) continue;
+            const uint64_t valid = lim == 64 ? ~0ull : ((1ull << lim) - 1);
+            int cnt = 0;
+            const int tot = total;
+            uint64_t cand = ~r & valid;
+            while (cand) {
                 if (max_num > 0 && tot + cnt >= max_num) break;
-                kb |= 1ull << bit; r |= diag[bit];
-                kept_rows[cnt++] = b * 64 + bit;
+                const int bit = __builtin_ctzll(cand);
+                kb |= 1ull << bit;
+                const uint64_t row = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dhi, bit) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)dlo, bit);
+                r |= row | (1ull << bit);
+                if (t == 0) kept_rows[cnt] = b * 64 + bit;
+                ++cnt;
+                cand = ~r & valid;
             }
-            kept_bits = kb; kept_cnt = cnt; total = tot + cnt;
+            if (t == 0) { kept_bits = kb; kept_cnt = cnt; total = tot + cnt; }
         }
         __syncthreads();
         const uint64_t kb = kept_bits;
