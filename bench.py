@@ -214,7 +214,8 @@ def main():
     if shadows:
         shadows.refresh()
     opt_cfg = presets.OPTIMIZER
-    optim = torch.optim.AdamW(build_param_groups(model, opt_cfg), lr=opt_cfg["lr"], betas=opt_cfg["betas"], fused=True)
+    from swin_transformer_object_detection_amd.optim import FusedAdamW
+    optim = FusedAdamW(build_param_groups(model, opt_cfg), lr=opt_cfg["lr"], betas=opt_cfg["betas"])      # one launch, refreshes the bf16 shadows
     batch = data.synthetic_batch(PER_GPU_BATCH, IMG_H, IMG_W, device, seed=rank)     # per-rank data
     torch.manual_seed(1000 + rank)             # per-rank sampling / DropPath randomness
 
@@ -224,9 +225,7 @@ def main():
         loss, log_vars = model.parse_losses(losses)
         loss.backward()
         reducer.finish()
-        optim.step()
-        if shadows:
-            shadows.refresh()
+        optim.step()                            # AdamW + bf16 shadow refresh, one HIP launch
         return log_vars
 
     def barrier():

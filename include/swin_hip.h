@@ -243,6 +243,16 @@ int det_delta2bbox(const float* rois, const float* deltas, int64_t n, const floa
 int det_paste_masks(const void* mask_logits, const int64_t* labels, const float* boxes, int N, int num_classes,
                     int mh, int mw, int img_h, int img_w, float thr, int in_dtype, uint8_t* out, void* stream);
 
+/* swin_adamw_step: AdamW over all parameters in ONE launch (+ the bf16 operand copy of the GEMM/conv weights).
+ * Replaces torch.optim.AdamW.step as configured by configs/swin/*_coco.py:64-67 and the master->half copy of apex O1
+ * (mmdet/apis/train.py:82-89).  segs: DEVICE array of {float* p; const float* g; float* m; float* v; bf16* shadow
+ * (nullable); int64 n; int32 group; int32 pad} (56 bytes each); chunks: DEVICE array of int32 pairs (segment, chunk
+ * index), one per swin_adamw_chunk_elems() elements of a segment; lr / weight_decay: HOST arrays of n_groups <= 8. */
+int swin_adamw_step(const void* segs, const void* chunks, int n_chunks, const float* lr, const float* weight_decay,
+                    int n_groups, float beta1, float beta2, float eps, float bias_correction1,
+                    float bias_correction2, void* stream);
+int swin_adamw_chunk_elems(void);
+
 #ifdef __cplusplus
 }
 #endif

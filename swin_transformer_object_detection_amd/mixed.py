@@ -108,6 +108,17 @@ def weight(p, dtype):
     return p.to(dtype)
 
 
+def shadow_of(p):
+    """The bf16 copy an optimizer should refresh together with ``p`` (leaf shadow or constant), or None."""
+    s = _SHADOW.get(id(p))
+    return s if s is not None else _CONST.get(id(p))
+
+
+def shadows_refreshed():
+    """Called by an optimizer that has rewritten the shadows itself: drops the per-step derived tensors."""
+    _DERIVED.clear()
+
+
 def const(p, dtype):
     """A compute-dtype copy of ``p`` that is NOT part of the autograd graph (None if there is none): the caller
     must deliver the gradient of ``p`` itself."""

@@ -1,0 +1,112 @@
+"""AdamW on the HIP kernel: one launch per step for all parameters, bf16 shadows refreshed in the same pass.
+
+Stands in for ``torch.optim.AdamW`` as the swin configs build it (``configs/swin/*_coco.py:64-67``: lr 1e-4,
+betas (0.9, 0.999), weight_decay 0.05 with 0 for norm / position-bias parameters via ``paramwise_cfg``) plus the
+master->half copy of apex O1 (``mmdet/apis/train.py:82-89``).  Gradients are read from ``p.grad`` -- with
+``ddp.BucketedGradReducer`` these are stable views of the flat all-reduce buckets."""
+import ctypes
+import struct
+
+import torch
+
+from . import _lib, mixed
+from ._lib import SwinHipError, call
+
+
+class FusedAdamW:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        groups = list(params)
+        if groups and not isinstance(groups[0], dict):
+            groups = [dict(params=groups)]
+        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.param_groups = []
+        for g in groups:
+            g = dict(g)
+            g['params'] = [p for p in g['params']]
+            for k, v in self.defaults.items():
+                g.setdefault(k, v)
+            self.param_groups.append(g)
+        if len(self.param_groups) > 8:
+            raise SwinHipError("FusedAdamW: at most 8 parameter groups")
+        if len({(tuple(g['betas']), g['eps']) for g in self.param_groups}) != 1:
+            raise SwinHipError("FusedAdamW: betas / eps must be shared by all groups")
+        self.state = {}
+        self.step_count = 0
+        self._tables = None
+
+    # -- tables: built on the first step (gradients must exist), rebuilt if any pointer moved --------------------
+    def _signature(self):
+        return tuple((p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0, id(mixed.shadow_of(p)))
+                     for g in self.param_groups for p in g['params'])
+
+    def _build(self):
+        chunk = _lib.lib().swin_adamw_chunk_elems()
+        segs, chunks = [], []
+        dev = None
+        for gi, g in enumerate(self.param_groups):
+            for p in g['params']:
+                if not p.requires_grad or p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.dtype == torch.float32
+                        and p.grad.is_contiguous()):
+                    raise SwinHipError("FusedAdamW: contiguous fp32 GPU parameters and gradients only")
+                dev = p.device
+                st = self.state.setdefault(p, {})
+                if 'exp_avg' not in st:
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                sh = mixed.shadow_of(p)
+                if sh is not None and not (sh.dtype == torch.bfloat16 and sh.is_contiguous() and sh.numel() == p.numel()):
+                    raise SwinHipError("FusedAdamW: shadows must be contiguous bf16 copies")
+                n = p.numel()
+                si = len(segs)
+                segs.append(struct.pack("<QQQQQqii", p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
+                                        st['exp_avg_sq'].data_ptr(), sh.data_ptr() if sh is not None else 0, n, gi, 0))
+                chunks += [(si, c) for c in range((n + chunk - 1) // chunk)]
+        if not segs:
+            self._tables = (None, None, 0)
+            return
+        seg_t = torch.frombuffer(bytearray(b"".join(segs)), dtype=torch.uint8).to(dev)
+        ck_t = torch.tensor(chunks, dtype=torch.int32).to(dev)
+        self._tables = (seg_t, ck_t, len(chunks))
+        self._sig = self._signature()
+
+    @torch.no_grad()
+    def step(self):
+        if self._tables is None or self._sig != self._signature():
+            self._build()
+        seg_t, ck_t, n_chunks = self._tables
+        self.step_count += 1
+        if n_chunks == 0:
+            return
+        g0 = self.param_groups[0]
+        b1, b2 = g0['betas']
+        ng = len(self.param_groups)
+        lr = (ctypes.c_float * ng)(*[float(g['lr']) for g in self.param_groups])
+        wd = (ctypes.c_float * ng)(*[float(g['weight_decay']) for g in self.param_groups])
+        call("swin_adamw_step", seg_t.data_ptr(), ck_t.data_ptr(), n_chunks, lr, wd, ng, float(b1), float(b2), float(g0['eps']),
+             1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count, torch.cuda.current_stream().cuda_stream)
+        mixed.shadows_refreshed()
+
+    def zero_grad(self, set_to_none=False):
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
+
+    def state_dict(self):
+        """torch.optim.AdamW-compatible layout (state per parameter index: step, exp_avg, exp_avg_sq)."""
+        idx, state, groups = 0, {}, []
+        for g in self.param_groups:
+            ids = []
+            for p in g['params']:
+                st = self.state.get(p)
+                if st:
+                    state[idx] = dict(step=torch.tensor(float(self.step_count)), exp_avg=st['exp_avg'], exp_avg_sq=st['exp_avg_sq'])
+                ids.append(idx)
+                idx += 1
+            groups.append({**{k: v for k, v in g.items() if k != 'params'}, 'params': ids})
+        return dict(state=state, param_groups=groups)

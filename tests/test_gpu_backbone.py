@@ -335,3 +335,41 @@ def test_simple_test_matches_oracle_callers():
     rh.bbox_head.forward, rh.mask_head.forward = orig_bbox, orig_mask
     out = model.simple_test(batch["img"], metas, rescale=True)        # the detector entry point wires the same pieces
     assert len(out) == 2 and len(out[0][0]) == 80 and len(out[0][1]) == 80
+
+
+@pytest.mark.gpu
+def test_fused_adamw_matches_torch_adamw():
+    """optim.FusedAdamW (one HIP launch, bf16 shadows written in the same pass) == torch.optim.AdamW over several
+    steps, two parameter groups (weight decay 0.05 / 0, as configs/swin/*_coco.py:64-67 build them)."""
+    import torch.nn as nn
+    from swin_transformer_object_detection_amd import mixed, optim
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(33, 65), nn.LayerNorm(65), nn.Linear(65, 1100), nn.Linear(1100, 7)).cuda()
+    ref = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    sh = mixed.ShadowParams(net, torch.bfloat16)
+    try:
+        params = list(net.parameters())
+        decay = [p for p in params if p.dim() > 1]
+        nodecay = [p for p in params if p.dim() <= 1]
+        rdecay = [r for r, p in zip(ref, params) if p.dim() > 1]
+        rnodecay = [r for r, p in zip(ref, params) if p.dim() <= 1]
+        mine = optim.FusedAdamW([dict(params=decay, weight_decay=0.05), dict(params=nodecay, weight_decay=0.0)], lr=1e-2,
+                                betas=(0.9, 0.999))
+        theirs = torch.optim.AdamW([dict(params=rdecay, weight_decay=0.05), dict(params=rnodecay, weight_decay=0.0)], lr=1e-2,
+                                   betas=(0.9, 0.999))
+        for step in range(4):
+            for p, r in zip(params, ref):
+                g = torch.randn_like(p) * (0.1 + step)
+                p.grad = g.clone(); r.grad = g.clone()
+            mine.step(); theirs.step()
+            for p, r in zip(params, ref):
+                torch.testing.assert_close(p.detach(), r.detach(), rtol=2e-5, atol=2e-6)
+            for p in params:
+                s = mixed.shadow_of(p)
+                if s is not None:
+                    assert torch.equal(s.detach(), p.detach().to(torch.bfloat16))
+        assert any(mixed.shadow_of(p) is not None for p in params)
+        sd = mine.state_dict()
+        assert len(sd['state']) == len(params) and len(sd['param_groups']) == 2
+    finally:
+        sh.release()
