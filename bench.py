@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--check-sync", action="store_true",
+                    help="after the timed steps, verify that all ranks hold bit-identical parameters (N > 1)")
     return ap.parse_args()
 
 
@@ -249,6 +251,19 @@ def main():
     if not all(map(lambda v: v == v and abs(v) != float("inf"), logs.values())):
         raise SystemExit(f"non-finite loss in the timed region: {logs}")
 
+    sync_check = None
+    if args.check_sync and world > 1:
+        # replicas start identical (broadcast) and apply the same averaged gradients: any rank-dependent gradient that
+        # slipped past the all-reduce (a missed bucket, a kernel writing after its bucket was launched) shows up here
+        with torch.no_grad():
+            sig = torch.stack([torch.stack([p.double().sum(), p.double().abs().sum()]) for p in model.parameters()]).flatten()
+        gathered = [torch.empty_like(sig) for _ in range(world)]
+        dist.all_gather(gathered, sig)
+        worst = max(float((g - gathered[0]).abs().max()) for g in gathered)
+        if worst != 0.0:
+            raise SystemExit(f"replicas diverged: max parameter-checksum difference {worst}")
+        sync_check = "replicas bit-identical after %d steps" % (args.warmup + args.steps)
+
     roof = attention_roofline(device) if rank == 0 else None
     roof_gemm = gemm_rooflines(device) if rank == 0 else None
     cpu = None
@@ -265,7 +280,7 @@ def main():
                                    "AdamW, DropPath 0.1 (BASELINE.json configs[1])",
                        "global_batch": gb, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
             "losses": {k: round(v, 4) for k, v in logs.items()},
-            "roofline": roof, "roofline_mfma_kernels": roof_gemm, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_mfma_kernels": roof_gemm, "cpu_baseline": cpu, "sync_check": sync_check,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -373,3 +373,22 @@ def test_fused_adamw_matches_torch_adamw():
         assert len(sd['state']) == len(params) and len(sd['param_groups']) == 2
     finally:
         sh.release()
+
+
+@pytest.mark.gpu
+def test_two_rank_replicas_stay_identical():
+    """N > 1 path on one GPU (2 ranks over gloo, `BENCH_REHEARSAL_GLOO`): bucketed all-reduce fed by autograd hooks AND
+    by the kernels that write the buckets directly, the fused AdamW; the replicas must stay bit-identical."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_REHEARSAL_GLOO="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--check-sync"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["sync_check"].startswith("replicas bit-identical")
