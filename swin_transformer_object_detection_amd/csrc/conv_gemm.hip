@@ -6,7 +6,7 @@
 // is the (Cout, ky, kx, Cin) weight, i.e. the channels_last memory of the (Cout,Cin,3,3) parameter.
 //
 // Tile 128(m) x 128(n) x 64(k), 256 threads = 2x2 waves of 64x64, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
-// LDS: two K-tiles (A 16 KB + W 16 KB each) filled by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no
+// LDS: one or two K-tiles (A 16 KB + W 16 KB each; see gemm_launch for the choice) filled by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no
 // ds_write traffic -- register staging left the kernel bound by the VGPR->LDS write path at ~500 TFLOP/s); a wave
 // instruction writes 1 KiB = 8 rows x 128 B linearly, so the 16-byte pieces are XOR-swizzled on the SOURCE
 // address (slot = piece ^ ((row >> 1) & 7)) and the same XOR is applied by the ds_read_b128 fragment reads, which
@@ -15,6 +15,7 @@
 // The weight tile is the MFMA "A" operand and the pixel tile the "B" operand, so a lane owns one pixel
 // and 4 consecutive output channels per accumulator group -> 8-byte stores into the NHWC output row.
 #include "common.h"
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -60,10 +61,17 @@ __device__ __forceinline__ int swz(int row, int piece) { return piece ^ ((row >>
 
 __device__ uint4 g_zero16[4];      // zero-initialised: source of padded 16-byte pieces
 
-template <typename ALoader, bool RELU>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
-                                                           bf16* __restrict__ C, int64_t M, int Nn, int K, int mtiles, int ntiles) {
-    __shared__ __attribute__((aligned(16))) uint4 lds[2][2][BM * 8];     // [buf][A|W][row*8 + piece]
+// WM = wave rows of the block: tile (64 WM) x 128 x 64 with 2 WM waves.  WM = 2 is the 128x128 tile (two blocks per
+// CU); WM = 4 doubles the pixel rows per weight tile (one 8-wave block per CU): 48 KB instead of 64 KB of operand
+// traffic per 4.2 MFLOP, for the large maps where the L2 -> LDS stream is the limit.
+template <typename ALoader, bool RELU, int WM, int NBUF>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : 2) : 1) void gemm_bf16_kernel(ALoader A, const bf16* __restrict__ Wt,
+                                                                              const float* __restrict__ bias, bf16* __restrict__ C,
+                                                                              int64_t M, int Nn, int K, int mtiles, int ntiles) {
+    constexpr int TM = 64 * WM;                                          // tile rows (pixels)
+    extern __shared__ __attribute__((aligned(16))) uint4 lds_raw[];      // [buf][A: TM*8 | W: BN*8]
+    auto ldsA = [&](int buf) { return lds_raw + (size_t)buf * (TM + BN) * 8; };
+    auto ldsW = [&](int buf) { return lds_raw + (size_t)buf * (TM + BN) * 8 + TM * 8; };
     // XCD-aware tile order: blocks that share an XCD (id % 8) get a contiguous run of tiles, n fastest
     const int nblk = mtiles * ntiles;
     int id = blockIdx.x;
@@ -72,19 +80,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
     }
     const int mt_ = id / ntiles, nt_ = id - mt_ * ntiles;
-    const int64_t m0 = (int64_t)mt_ * BM;
+    const int64_t m0 = (int64_t)mt_ * TM;
     const int n0 = nt_ * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int c = lane & 31, h = lane >> 5;
 
-    // DMA role: wave w fills rows [32w, 32w+32) of both operand tiles, 8 rows x 8 slots per instruction
+    // DMA role: wave w fills rows [32w, 32w+32) of the A tile and rows [WROWS w, WROWS (w+1)) of the W tile,
+    // 8 rows x 8 slots per instruction
+    constexpr int WROWS = BN / (2 * WM), WI = WROWS / 8;                 // W rows / instructions per wave
     const int drow = 32 * wave + (lane >> 3), dslot = lane & 7;
-    int64_t abase[4]; int ay[4], ax[4]; int64_t woff[4];
+    const int wrow = WROWS * wave + (lane >> 3);
+    int64_t abase[4]; int ay[4], ax[4]; int64_t woff[WI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        A.prep(m0 + drow + 8 * i, abase[i], ay[i], ax[i]);
-        int n = n0 + drow + 8 * i;
+    for (int i = 0; i < 4; ++i) A.prep(m0 + drow + 8 * i, abase[i], ay[i], ax[i]);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        int n = n0 + wrow + 8 * i;
         woff[i] = n < Nn ? (int64_t)n * K : -1;
     }
     const int nk = K / BK;
@@ -98,9 +110,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
             const int piece = dslot ^ ((row >> 1) & 7);            // slot s of LDS row holds piece s ^ f(row)
             int64_t ao = A.offset(abase[i], ay[i], ax[i], kt, piece);
             const bf16* asrc = ao >= 0 ? A.a + ao : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)asrc, (lptr_t)(ldsA(buf) + (32 * wave + 8 * i) * 8), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = wrow + 8 * i;
+            const int piece = dslot ^ ((row >> 1) & 7);
             const bf16* wsrc = woff[i] >= 0 ? Wt + woff[i] + kt * BK + piece * 8 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)asrc, (lptr_t)&lds[buf][0][(32 * wave + 8 * i) * 8], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)&lds[buf][1][(32 * wave + 8 * i) * 8], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(ldsW(buf) + (WROWS * wave + 8 * i) * 8), 16, 0, 0);
         }
     };
     f32x16 acc[2][2];
@@ -109,8 +126,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
     auto compute = [&](int buf) {
-        const uint4* As = lds[buf][0];
-        const uint4* Ws = lds[buf][1];
+        const uint4* As = ldsA(buf);
+        const uint4* Ws = ldsW(buf);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 wf[2], af[2];
@@ -130,16 +147,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
         }
     };
 
-    dma_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);       // lands while this tile feeds the MFMAs
-        compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt+1 have landed
-        __syncthreads();                                   // ... and everyone's; all reads of tile kt are done
-        cur ^= 1;
+    if constexpr (NBUF == 1) {
+        // one LDS buffer, two barriers per K-tile: 32 KB per block -> 4 blocks per CU overlap each other's DMA and MFMA
+        for (int kt = 0; kt < nk; ++kt) {
+            dma_tile(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    } else {
+        dma_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);       // lands while this tile feeds the MFMAs
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt+1 have landed
+            __syncthreads();                                   // ... and everyone's; all reads of tile kt are done
+            cur ^= 1;
+        }
     }
 
     // epilogue: lane = pixel m, registers = output channels
@@ -166,13 +194,44 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ALoader A, const bf16
     }
 }
 
+template <typename ALoader, bool RELU, int WM, int NBUF>
+static int gemm_launch_wm(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, hipStream_t s) {
+    constexpr int TM = 64 * WM;
+    const size_t lds_bytes = NBUF * (size_t)(TM + BN) * 8 * sizeof(uint4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<ALoader, RELU, WM, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess)
+            return SWIN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    int mtiles = (int)((M + TM - 1) / TM), ntiles = (Nn + BN - 1) / BN;
+    gemm_bf16_kernel<ALoader, RELU, WM, NBUF><<<mtiles * ntiles, 128 * WM, lds_bytes, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles);
+    return swin_launch_status();
+}
+
+static int g_conv_wm = 0;     // 0: choose by size; 2 / 4: forced (A/B experiments through SWIN_CONV_WM)
+
 template <typename ALoader>
 static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, int relu, hipStream_t s) {
-    int mtiles = (int)((M + BM - 1) / BM), ntiles = (Nn + BN - 1) / BN;
-    int blocks = mtiles * ntiles;
-    if (relu) gemm_bf16_kernel<ALoader, true><<<blocks, 256, 0, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles);
-    else gemm_bf16_kernel<ALoader, false><<<blocks, 256, 0, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles);
-    return swin_launch_status();
+    static bool env_read = false;
+    if (!env_read) { const char* e = getenv("SWIN_CONV_WM"); if (e) g_conv_wm = atoi(e); env_read = true; }
+    // large pixel counts: the 256-row tile (one 8-wave block per CU); otherwise the 128-row tile keeps the grid full
+    const int64_t blocks128 = ((M + 127) / 128) * ((Nn + BN - 1) / BN);
+    const bool big = g_conv_wm == 4;   // (measured: no gain over the 128-row tile, kept for experiments)
+    if (big) {
+        if (relu) return gemm_launch_wm<ALoader, true, 4, 2>(A, Wt, bias, C, M, Nn, K, s);
+        return gemm_launch_wm<ALoader, false, 4, 2>(A, Wt, bias, C, M, Nn, K, s);
+    }
+    // enough tiles for several blocks per CU: ONE LDS buffer (32 KB, two barriers per K-tile) at 4 blocks per CU -- the
+    // co-resident blocks overlap each other's DMA and MFMA phases better than a block's own double buffer does
+    // (P2 map: 535 -> 663 TFLOP/s, mask-head convs: 399 -> 593); few tiles: the double-buffered block hides more itself
+    if (g_conv_wm == 1 || (g_conv_wm == 0 && blocks128 > 512)) {
+        if (relu) return gemm_launch_wm<ALoader, true, 2, 1>(A, Wt, bias, C, M, Nn, K, s);
+        return gemm_launch_wm<ALoader, false, 2, 1>(A, Wt, bias, C, M, Nn, K, s);
+    }
+    if (relu) return gemm_launch_wm<ALoader, true, 2, 2>(A, Wt, bias, C, M, Nn, K, s);
+    return gemm_launch_wm<ALoader, false, 2, 2>(A, Wt, bias, C, M, Nn, K, s);
 }
 
 // x (N,H,W,Cin) bf16 channels-last; w (Cout,3,3,Cin) bf16; bias (Cout) f32 or NULL; y (N,H,W,Cout) bf16.
