@@ -120,30 +120,59 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : 2) : 1) void g
             __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(ldsW(buf) + (WROWS * wave + 8 * i) * 8), 16, 0, 0);
         }
     };
+    // two MFMA forms: 32x32x16 (2x2 accumulator tiles per wave) and 16x16x32 (4x4 tiles, same 64 registers); the
+    // second delivers more FLOP/s per cycle when every operand is re-read from LDS (guide section 3) -> the many-tile path
+    constexpr bool MF16 = (NBUF == 1);
     f32x16 acc[2][2];
+    f32x4 acc16[4][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc16[a][b] = f32x4{0};
+    const int fr = lane & 15, fq = lane >> 4;
     auto compute = [&](int buf) {
         const uint4* As = ldsA(buf);
         const uint4* Ws = ldsW(buf);
+        if constexpr (MF16) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 wf[2], af[2];
+            for (int s = 0; s < 2; ++s) {                 // 32 k per step: lane (fr, fq) holds row fr, k = 32 s + 8 fq .. +8
+                bf16x8 wf[4], af[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                int rw_ = wn * 64 + 32 * t + c, ra_ = wm * 64 + 32 * t + c;
-                uint4 u = Ws[rw_ * 8 + swz(rw_, 2 * s + h)];
-                uint4 v = As[ra_ * 8 + swz(ra_, 2 * s + h)];
-                wf[t] = *(bf16x8*)&u;
-                af[t] = *(bf16x8*)&v;
+                for (int t = 0; t < 4; ++t) {
+                    int rw_ = wn * 64 + 16 * t + fr, ra_ = wm * 64 + 16 * t + fr;
+                    uint4 u = Ws[rw_ * 8 + swz(rw_, 4 * s + fq)];
+                    uint4 v = As[ra_ * 8 + swz(ra_, 4 * s + fq)];
+                    wf[t] = *(bf16x8*)&u;
+                    af[t] = *(bf16x8*)&v;
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc16[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc16[nt][mt], 0, 0, 0);
             }
+        } else {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 wf[2], af[2];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+                for (int t = 0; t < 2; ++t) {
+                    int rw_ = wn * 64 + 32 * t + c, ra_ = wm * 64 + 32 * t + c;
+                    uint4 u = Ws[rw_ * 8 + swz(rw_, 2 * s + h)];
+                    uint4 v = As[ra_ * 8 + swz(ra_, 2 * s + h)];
+                    wf[t] = *(bf16x8*)&u;
+                    af[t] = *(bf16x8*)&v;
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+            }
         }
     };
 
@@ -171,6 +200,28 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : 2) : 1) void g
     }
 
     // epilogue: lane = pixel m, registers = output channels
+    if constexpr (MF16) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            int64_t m = m0 + wm * 64 + 16 * mt + fr;
+            if (m >= M) continue;
+            bf16* crow = C + m * Nn;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                int n = n0 + wn * 64 + 16 * nt + 4 * fq;            // C layout: row (= n) = 4 fq + j, column (= m) = fr
+                if (n >= Nn) continue;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc16[nt][mt][e] + (bias ? bias[n + e] : 0.f);
+                    if (RELU) v = fmaxf(v, 0.f);
+                    o[e] = (bf16)v;
+                }
+                *(bf16x4*)(crow + n) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         int64_t m = m0 + wm * 64 + 32 * mt + c;
