@@ -193,10 +193,13 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
     if (task >= n_tasks) return;
     const int head = task % g.nH;
 
-    // expanded bias of this head (pre-multiplied by log2 e), in accumulator layout, kept in registers
-    float biasr[2][2][16];
+    // expanded bias of this head in accumulator layout, kept in registers in the RAW-logit domain (bias / scale): it is
+    // the C operand of the first S MFMA, so the accumulators need no zero fill and no separate bias pass; the softmax
+    // scale (and log2 e) is applied once, inside the exponent's fused multiply-add
+    f32x16 biasr[2][2];
     {
         const float* bp = bias_exp + (size_t)head * TILE * TILE;
+        const float rs = 1.0f / scale;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -204,12 +207,13 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    biasr[kt][qt][reg] = bp[key * TILE + 32 * qt + c] * LOG2E;
+                    biasr[kt][qt][reg] = bp[key * TILE + 32 * qt + c] * rs;
                 }
     }
     uint64_t mrow = 0, mcol = 0;
     if (g.shift > 0) lane_mask_bits(lane, mrow, mcol);
     const float sl2 = scale * LOG2E;
+    const float mask_raw = -100.0f / scale;
 
     // staging role: 5 tokens per round x 12 16-byte pieces (q|k|v x 4); lanes 60..63 duplicate lanes 48..51
     {
@@ -288,42 +292,44 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
             f32x16 sacc[2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                f32x16 a = {0};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], a, 0, 0, 0);
-                sacc[kt] = a;
+                f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][0], qf[0], biasr[kt][qt], 0, 0, 0);   // + bias / scale
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][1], qf[1], a, 0, 0, 0);
             }
-            // ---- logits in the log2 domain, softmax over keys ------------------------------------
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) sacc[kt][reg] = fmaf(sacc[kt][reg], sl2, biasr[kt][qt][reg]);
+            // ---- raw logits (q.k + bias / scale); softmax over keys with the scale folded into the exponent ------
             if (edge) {                                       // wave-uniform: only last-row / last-column windows
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg)
-                        if ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1) sacc[kt][reg] += -100.0f * LOG2E;   // :389
+                        if ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1) sacc[kt][reg] += mask_raw;   // -100 / scale  (:389)
             }
             // 4 independent partial reductions (ILP), then a VALU half-swap instead of an LDS bpermute
-            float m4[4] = {NEG_BIG * 2.f, NEG_BIG * 2.f, NEG_BIG * 2.f, NEG_BIG * 2.f};
+            float m4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) m4[reg & 3] = fmaxf(m4[reg & 3], sacc[kt][reg]);
             float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
             m = half_swap_max(m);
-            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            // p = exp2(s * sl2 - m * sl2): one packed fma + one exp per element pair / element; packed partial sums
+            const f32x2 sc2 = {sl2, sl2};
+            const float mc = -m * sl2;
+            const f32x2 mc2 = {mc, mc};
+            f32x2 sum2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    float p = __builtin_amdgcn_exp2f(sacc[kt][reg] - m);
-                    sacc[kt][reg] = p;
-                    s4[reg & 3] += p;
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    f32x2 x = {sacc[kt][2 * r2], sacc[kt][2 * r2 + 1]};
+                    x = __builtin_elementwise_fma(x, sc2, mc2);
+                    f32x2 p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    sacc[kt][2 * r2] = p[0]; sacc[kt][2 * r2 + 1] = p[1];
+                    sum2[r2 & 1] += p;
                 }
-            float sum = half_swap_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+            const f32x2 st = sum2[0] + sum2[1];
+            float sum = half_swap_sum(st[0] + st[1]);
             const float inv = 1.0f / sum;
+            m = m * sl2;                                      // log2-domain maximum for the saved log-sum-exp
 
             // ---- O^T = V^T P^T  (P^T accumulator registers are the B operand) -----------------------
             f32x16 oacc = {0};
