@@ -332,17 +332,22 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
             m = m * sl2;                                      // log2-domain maximum for the saved log-sum-exp
 
             // ---- O^T = V^T P^T  (P^T accumulator registers are the B operand) -----------------------
-            f32x16 oacc = {0};
+            // two independent accumulation chains (one per key tile) instead of one chain of four dependent MFMAs
+            f32x16 oacc2[2];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 o = {0};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     bf16x8 vf = lds_tr_frag_perm(Vs, 32 * kt + 16 * s, lane);
                     bf16x8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s + j];
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o, 0, 0, 0);
                 }
+                oacc2[kt] = o;
+            }
+            const f32x16 oacc = oacc2[0] + oacc2[1];
 
             // ---- write O (window_reverse + roll back + crop == scatter to the source position) ----
             const int q = 32 * qt + c;
