@@ -32,6 +32,9 @@ struct PlainA {
     __device__ __forceinline__ int64_t offset(int64_t base, int y, int x, int kt, int piece) const {
         return base < 0 ? -1 : base + kt * BK + piece * 8;
     }
+    // K-tile kt = wave-uniform element offset from the row's base + the "tap" whose validity bit applies
+    __device__ __forceinline__ unsigned tapmask(int64_t base, int y, int x) const { return base < 0 ? 0u : 1u; }
+    __device__ __forceinline__ void kinfo(int kt, int64_t& koff, int& tap) const { koff = (int64_t)kt * BK; tap = 0; }
 };
 
 struct ConvA {
@@ -47,6 +50,22 @@ struct ConvA {
         int yy = y + dy, xx = x + dx;
         bool ok = base >= 0 && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
         return ok ? base + ((int64_t)dy * g.W + dx) * g.Cin + c0 + piece * 8 : -1;
+    }
+    // bit t set: filter tap t of this pixel lies inside the image (border predication, once per row and lane)
+    __device__ __forceinline__ unsigned tapmask(int64_t base, int y, int x) const {
+        if (base < 0) return 0u;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) m |= 1u << t;
+        }
+        return m;
+    }
+    __device__ __forceinline__ void kinfo(int kt, int64_t& koff, int& tap) const {
+        tap = kt / cpt;
+        const int c0 = (kt - tap * cpt) * BK, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        koff = ((int64_t)dy * g.W + dx) * g.Cin + c0;
     }
 };
 
@@ -65,7 +84,7 @@ __device__ uint4 g_zero16[4];      // zero-initialised: source of padded 16-byte
 // CU); WM = 4 doubles the pixel rows per weight tile (one 8-wave block per CU): 48 KB instead of 64 KB of operand
 // traffic per 4.2 MFLOP, for the large maps where the L2 -> LDS stream is the limit.
 template <typename ALoader, bool RELU, int WM, int NBUF>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : 2) : 1) void gemm_bf16_kernel(ALoader A, const bf16* __restrict__ Wt,
+__global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2 : 1)) : 1) void gemm_bf16_kernel(ALoader A, const bf16* __restrict__ Wt,
                                                                               const float* __restrict__ bias, bf16* __restrict__ C,
                                                                               int64_t M, int Nn, int K, int mtiles, int ntiles) {
     constexpr int TM = 64 * WM;                                          // tile rows (pixels)
@@ -91,33 +110,45 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : 2) : 1) void g
     constexpr int WROWS = BN / (2 * WM), WI = WROWS / 8;                 // W rows / instructions per wave
     const int drow = 32 * wave + (lane >> 3), dslot = lane & 7;
     const int wrow = WROWS * wave + (lane >> 3);
-    int64_t abase[4]; int ay[4], ax[4]; int64_t woff[WI];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) A.prep(m0 + drow + 8 * i, abase[i], ay[i], ax[i]);
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-        int n = n0 + wrow + 8 * i;
-        woff[i] = n < Nn ? (int64_t)n * K : -1;
-    }
-    const int nk = K / BK;
+    // per-lane constants of the DMA sources (computed once): byte address of this lane's 16-byte piece at K-tile 0 and
+    // the border mask of its pixel row.  Per K-tile only a wave-uniform offset is added and the pointer is selected
+    // against the zero line by value (v_cndmask) -- the former per-tile `offset()` + pointer select cost ~60
+    // instructions and two branches per piece, which one block per CU (small maps) could not hide.
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const bf16* zero = reinterpret_cast<const bf16*>(g_zero16);
+    const uint64_t zero64 = (uint64_t)reinterpret_cast<uintptr_t>(g_zero16);
+    uint64_t aptr[4]; unsigned amask[4]; uint64_t wptr[WI]; bool wok[WI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = drow + 8 * i;
+        const int piece = dslot ^ ((row >> 1) & 7);                // slot s of LDS row holds piece s ^ f(row)
+        int64_t base; int y, x;
+        A.prep(m0 + row, base, y, x);
+        amask[i] = A.tapmask(base, y, x);
+        aptr[i] = (uint64_t)reinterpret_cast<uintptr_t>(A.a + (base < 0 ? 0 : base) + piece * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = wrow + 8 * i;
+        const int piece = dslot ^ ((row >> 1) & 7);
+        const int n = n0 + row;
+        wok[i] = n < Nn;
+        wptr[i] = (uint64_t)reinterpret_cast<uintptr_t>(Wt + (wok[i] ? (int64_t)n * K : 0) + piece * 8);
+    }
+    const int nk = K / BK;
     auto dma_tile = [&](int kt, int buf) {
+        int64_t koff; int tap;
+        A.kinfo(kt, koff, tap);                                    // wave-uniform
+        const uint64_t abytes = (uint64_t)(koff * 2), wbytes = (uint64_t)kt * BK * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = drow + 8 * i;
-            const int piece = dslot ^ ((row >> 1) & 7);            // slot s of LDS row holds piece s ^ f(row)
-            int64_t ao = A.offset(abase[i], ay[i], ax[i], kt, piece);
-            const bf16* asrc = ao >= 0 ? A.a + ao : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)asrc, (lptr_t)(ldsA(buf) + (32 * wave + 8 * i) * 8), 16, 0, 0);
+            const uint64_t src = ((amask[i] >> tap) & 1u) ? aptr[i] + abytes : zero64;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ldsA(buf) + (32 * wave + 8 * i) * 8), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            const int row = wrow + 8 * i;
-            const int piece = dslot ^ ((row >> 1) & 7);
-            const bf16* wsrc = woff[i] >= 0 ? Wt + woff[i] + kt * BK + piece * 8 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(ldsW(buf) + (WROWS * wave + 8 * i) * 8), 16, 0, 0);
+            const uint64_t src = wok[i] ? wptr[i] + wbytes : zero64;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ldsW(buf) + (WROWS * wave + 8 * i) * 8), 16, 0, 0);
         }
     };
     // two MFMA forms: 32x32x16 (2x2 accumulator tiles per wave) and 16x16x32 (4x4 tiles, same 64 registers); the
@@ -176,7 +207,28 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : 2) : 1) void g
         }
     };
 
-    if constexpr (NBUF == 1) {
+    if constexpr (NBUF == 4) {
+        // ring of 4 LDS buffers, 3 K-tiles of LDS-DMA in flight, ONE raw barrier per K-tile, counted vmcnt: for shapes
+        // with at most one block per CU (small feature maps), where nothing else on the CU hides the DMA latency and a
+        // 36-step K loop costs 36 memory latencies with the two-buffer schedule.  Each wave issues DPT DMA
+        // instructions per tile, in order; tile kt has landed for this wave when at most DPT x (tiles issued after it)
+        // are outstanding; the barrier then publishes it to the other waves (read AFTER the barrier that follows the
+        // wait), and -- every wave having finished compute(kt-1) before arriving -- frees buffer (kt-1) % 4 for
+        // tile kt+3.  No __syncthreads() here: with a DMA in flight its fence would drain the ring (guide section 5).
+        constexpr int DPT = 4 + WI;
+        static_assert(DPT == 8, "vmcnt literals below assume 8 DMA instructions per tile and wave");
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < nk) dma_tile(i, i);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < nk) dma_tile(kt + 3, (kt + 3) & 3);
+            compute(kt & 3);
+        }
+    } else if constexpr (NBUF == 1) {
         // one LDS buffer, two barriers per K-tile: 32 KB per block -> 4 blocks per CU overlap each other's DMA and MFMA
         for (int kt = 0; kt < nk; ++kt) {
             dma_tile(kt, 0);
@@ -280,6 +332,10 @@ static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, in
     if (g_conv_wm == 1 || (g_conv_wm == 0 && blocks128 > 512)) {
         if (relu) return gemm_launch_wm<ALoader, true, 2, 1>(A, Wt, bias, C, M, Nn, K, s);
         return gemm_launch_wm<ALoader, false, 2, 1>(A, Wt, bias, C, M, Nn, K, s);
+    }
+    if (g_conv_wm == 3 || (g_conv_wm == 0 && blocks128 <= 256)) {      // at most one block per CU: 4-buffer DMA ring
+        if (relu) return gemm_launch_wm<ALoader, true, 2, 4>(A, Wt, bias, C, M, Nn, K, s);
+        return gemm_launch_wm<ALoader, false, 2, 4>(A, Wt, bias, C, M, Nn, K, s);
     }
     if (relu) return gemm_launch_wm<ALoader, true, 2, 2>(A, Wt, bias, C, M, Nn, K, s);
     return gemm_launch_wm<ALoader, false, 2, 2>(A, Wt, bias, C, M, Nn, K, s);
