@@ -15,24 +15,37 @@
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_w;
 
-// loaders return the ELEMENT OFFSET of 8 consecutive n at row t, or -1 for zero padding; the kernel loads from a
-// clamped address and masks by value (a pointer select against a local zero becomes a flat load + full wait)
+// X loaders keep an incremental per-row state (element offset of this thread's 8 columns at row t, plus the pixel
+// coordinates for the conv): a stage advances it by a constant row step with 32-bit adds.  The first version
+// recomputed t * N2 + n (64-bit multiply) and, for the conv, t % W and (t / W) % H (64-bit divisions) for every
+// 16-byte piece of every stage -- more integer work than MFMA work in the loop.  The kernel loads from a clamped
+// address and masks by value (a pointer select against a local zero becomes a flat load + full wait).
 struct PlainX {
     const bf16* x; int64_t T; int N2;
-    __device__ __forceinline__ int64_t offset(int64_t t, int n) const {
-        return (t >= T || n >= N2) ? -1 : t * N2 + n;
-    }
+    struct St { int64_t off; bool ok; };
+    __device__ __forceinline__ void init(St& s, int64_t t, int n) const { s.ok = n < N2; s.off = t * N2 + n; }
+    __device__ __forceinline__ void advance(St& s, int dt) const { s.off += (int64_t)dt * N2; }
+    __device__ __forceinline__ int64_t offset(const St& s) const { return s.ok ? s.off : -1; }
 };
 
 struct ConvX {
     const bf16* x; int64_t T; int H, W, Cin;
-    __device__ __forceinline__ int64_t offset(int64_t t, int n) const {
-        int tap = n / Cin, c = n - tap * Cin;
-        int xx = (int)(t % W); int64_t r = t / W; int yy = (int)(r % H);
-        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        yy += dy; xx += dx;
-        bool ok = t < T && tap < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        return ok ? (t + (int64_t)dy * W + dx) * Cin + c : -1;
+    struct St { int64_t off; int y, x, dy, dx; bool ok; };
+    __device__ __forceinline__ void init(St& s, int64_t t, int n) const {
+        const int tap = n / Cin, c = n - tap * Cin;
+        s.dy = tap / 3 - 1; s.dx = tap - (tap / 3) * 3 - 1;
+        s.ok = tap < 9;
+        s.x = (int)(t % W); s.y = (int)((t / W) % H);
+        s.off = (t + (int64_t)s.dy * W + s.dx) * Cin + c;       // the tap's source pixel, this thread's 8 channels
+    }
+    __device__ __forceinline__ void advance(St& s, int dt) const {
+        s.off += (int64_t)dt * Cin;
+        s.x += dt;
+        if (s.x >= W) { const int q = s.x / W; s.x -= q * W; s.y += q; if (s.y >= H) s.y %= H; }
+    }
+    __device__ __forceinline__ int64_t offset(const St& s) const {
+        const int yy = s.y + s.dy, xx = s.x + s.dx;
+        return (s.ok && yy >= 0 && yy < H && xx >= 0 && xx < W) ? s.off : -1;
     }
 };
 
@@ -76,13 +89,34 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
     // staging: tile = 64 rows x 16 pieces of 16 B; thread handles rows (tid/16 + 16 i), piece tid%16
     const int srow = tid >> 4, spiece = tid & 15;
     uint4 ra[4], rb[4];
-    auto gload = [&](int64_t t0) {
+    // row states of this thread's 4 staging rows (t = first stage row + srow + 16 i), advanced by a constant step
+    typename XLoader::St xs[4];
+    int64_t aoff[4], trow[4];
+    const int n1c = n1_0 + spiece * 8;
+    const bool n1ok = n1c < N1;
+    {
+        const int64_t tfirst = t_begin + (int64_t)grp * WT + srow;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int64_t t = t0 + srow + 16 * i;
-            int n1 = n1_0 + spiece * 8;
-            ra[i] = masked_load16w(dy, (t < t_end && n1 < N1) ? t * N1 + n1 : -1);
-            rb[i] = masked_load16w(X.x, t < t_end ? X.offset(t, n2_0 + spiece * 8) : -1);
+            trow[i] = tfirst + 16 * i;
+            aoff[i] = trow[i] * N1 + n1c;
+            X.init(xs[i], trow[i], n2_0 + spiece * 8);
+        }
+    }
+    auto gload = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool tin = trow[i] < t_end;
+            ra[i] = masked_load16w(dy, (tin && n1ok) ? aoff[i] : -1);
+            rb[i] = masked_load16w(X.x, tin ? X.offset(xs[i]) : -1);
+        }
+    };
+    auto gadvance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            trow[i] += WKG * WT;
+            aoff[i] += (int64_t)WKG * WT * N1;
+            X.advance(xs[i], WKG * WT);
         }
     };
     auto lstore = [&]() {
@@ -114,14 +148,13 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
     const int64_t stages = (t_end - t_begin + WT - 1) / WT;
     const int iters = (int)((stages + WKG - 1) / WKG);
     if (iters > 0) {
-        int64_t t0 = t_begin + (int64_t)grp * WT;
-        gload(t0);
+        gload();
         if (do_bias) bias_acc();
         lstore();
         __syncthreads();
-        for (int it = 0; it < iters; ++it, t0 += (int64_t)WKG * WT) {
+        for (int it = 0; it < iters; ++it) {
             const bool more = it + 1 < iters;
-            if (more) { gload(t0 + (int64_t)WKG * WT); if (do_bias) bias_acc(); }
+            if (more) { gadvance(); gload(); if (do_bias) bias_acc(); }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {                     // 16 t per MFMA k-step
                 bf16x8 af[2], bfr[2];
