@@ -253,6 +253,14 @@ int swin_adamw_step(const void* segs, const void* chunks, int n_chunks, const fl
                     float bias_correction2, void* stream);
 int swin_adamw_chunk_elems(void);
 
+/* swin_gemm_bf16: the plain GEMMs of the path (nn.Linear forward / data gradient, swin_transformer.py:33-36,129,151,296;
+ * 1x1 convs; head FCs) on hipBLASLt with cached plans -- one library launch per call, no framework dispatch.
+ *   c (M,N) bf16 = a (M,K) bf16 x op(b) [+ bias (N) bf16]; b_layout 0: b is (N,K) (c = a b^T), 1: b is (K,N) (c = a b).
+ *   workspace: swin_gemm_workspace_bytes() bytes of device scratch. */
+int64_t swin_gemm_workspace_bytes(void);
+int swin_gemm_bf16(const void* a, const void* b, const void* bias, void* c, int64_t M, int N, int K, int b_layout,
+                   void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

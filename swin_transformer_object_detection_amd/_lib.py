@@ -46,11 +46,13 @@ SIGNATURES = {
     "det_random_sample": [_p, _i64, _i, _i, ctypes.c_uint64, _p, _p, _p, _p],
     "det_bbox_targets": [_p, _p, _p, _p, _p, _i, _p, _i64, _p, _p, _i, _p, _p, _p, _p, _p],
     "det_delta2bbox": [_p, _p, _i64, _p, _p, _f, _f, _f, _p, _p],
+    "swin_gemm_workspace_bytes": [],
+    "swin_gemm_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p, _p],
     "swin_adamw_step": [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p],
     "swin_adamw_chunk_elems": [],
     "det_paste_masks": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p],
 }
-_RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
+_RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_gemm_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
             "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64}
 
 _lib = None

@@ -56,7 +56,9 @@ def build_library(force=False, verbose=False):
         with cf.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _newer(LIB, objs):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib")
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs +
+            [f"-L{rocm_lib}", "-lhipblaslt", f"-Wl,-rpath,{rocm_lib}"])     # gemm_lt.hip: plain GEMMs on hipBLASLt
     return LIB
 
 

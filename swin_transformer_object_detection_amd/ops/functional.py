@@ -6,6 +6,7 @@ bookkeeping.  There is deliberately no CPU / eager fallback: a tensor that is
 not on a GPU, or a missing library, raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -472,6 +473,25 @@ def conv3x3(x, weight, bias=None, relu=False, dtype=torch.bfloat16):
 # --------------------------------------------------------------------------------------
 # Linear layer with the weight gradient on the split-T MFMA kernel
 # --------------------------------------------------------------------------------------
+_GEMM_WS = {}
+_MIN_T = int(os.environ.get("SWIN_LINEAR_MIN_T", "1024"))   # rows below which nn.Linear stays on the framework path
+_DIRECT_GEMM = os.environ.get("SWIN_TORCH_GEMM") != "1"      # A/B switch (development): 1 = torch.nn.functional.linear / mm
+
+
+def gemm_bf16(a, b, bias=None, b_is_kn=False, out_shape=None):
+    """c (M,N) = a (M,K) @ (b.T if b is (N,K) else b) [+ bias] in bf16 with fp32 accumulation, straight on hipBLASLt
+    through the C ABI (swin_gemm_bf16: cached plans, no framework dispatch).  2-D contiguous bf16 GPU tensors."""
+    M, K = a.shape
+    N = b.shape[1] if b_is_kn else b.shape[0]
+    dev = a.device
+    ws = _GEMM_WS.get(dev)
+    if ws is None:
+        ws = _GEMM_WS[dev] = torch.empty(_lib.lib().swin_gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+    c = torch.empty((M, N) if out_shape is None else out_shape, dtype=torch.bfloat16, device=dev)   # not a view
+    call("swin_gemm_bf16", _p(a), _p(b), _p(bias), _p(c), M, N, K, 1 if b_is_kn else 0, _p(ws), _s())
+    return c
+
+
 class _LinearBf16(torch.autograd.Function):
     """y = x w^T + b.  Forward / data gradient: library GEMM.  Weight AND bias gradient: the split-T kernel
     (wgrad_gemm.hip), accumulating in fp32 -- straight into the parameters' all-reduce buckets when a reducer
@@ -490,6 +510,9 @@ class _LinearBf16(torch.autograd.Function):
         if ws is not None and ws[0].numel() == w.numel() and ws[0].is_contiguous() and ctx.needs_input_grad[1]:
             mixed.use_begin(w_master)
             ctx.counted = True
+        x2 = x.reshape(-1, w.shape[1])
+        if _DIRECT_GEMM and x2.is_contiguous() and w.is_contiguous() and (b is None or (b.dtype == torch.bfloat16 and b.is_contiguous())):
+            return gemm_bf16(x2, w, b, out_shape=tuple(x.shape[:-1]) + (w.shape[0],))
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -506,7 +529,7 @@ class _LinearBf16(torch.autograd.Function):
             x2 = x2.contiguous()
         dx = dw = db = dbm = None
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ w).view(x.shape)
+            dx = gemm_bf16(dy2, w, None, b_is_kn=True, out_shape=tuple(x.shape)) if (_DIRECT_GEMM and w.is_contiguous()) else (dy2 @ w).view(x.shape)
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and (ctx.needs_input_grad[2] or ctx.bias_to_master)
         if need_w or need_b:
@@ -549,7 +572,7 @@ def linear(x, weight, bias=None, dtype=None):
     if w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1:        # 1x1 conv weight (Cout,Cin,1,1)
         w = w.view(w.shape[0], w.shape[1])
     if (x.dtype == torch.bfloat16 and x.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[0] % 8 == 0
-            and w.shape[1] % 8 == 0 and x.numel() // w.shape[1] >= 1024):
+            and w.shape[1] % 8 == 0 and x.numel() // w.shape[1] >= _MIN_T):
         b = mixed.const(bias, dtype)                                # bf16 constant; gradient delivered to the master
         if b is None:
             b = mixed.weight(bias, dtype)

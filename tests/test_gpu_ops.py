@@ -616,3 +616,26 @@ def test_roi_align_nchw_thread_per_bin_path(ops):
     assert ref.size > (1 << 18)
     out = ops.roi_align(torch.from_numpy(inp).cuda(), torch.from_numpy(rois).cuda(), 7, 0.25, 0, 'avg', True)
     close(out, torch.from_numpy(ref), ATOL32)
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 288, 96), (1024, 1024, 12544), (2000, 768, 3072), (130, 88, 1024)])
+def test_gemm_bf16_direct(ops, M, N, K):
+    """swin_gemm_bf16 (hipBLASLt with cached plans) == fp32 matmul of the same bf16 operands, both layouts, with bias;
+    bf16 output: 1 ulp of bf16 on the result magnitude (fp32 accumulation inside)."""
+    from swin_transformer_object_detection_amd.ops.functional import gemm_bf16
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    ref = a.float() @ w.float().t() + b.float()
+    out = gemm_bf16(a, w, b)
+    assert out.dtype == torch.bfloat16 and out.shape == (M, N)
+    tol = float(ref.abs().max()) * 2.0 ** -8
+    assert float((out.float() - ref).abs().max()) <= tol
+    dy = torch.randn(M, N, generator=g).bfloat16().cuda()
+    ref2 = dy.float() @ w.float()
+    out2 = gemm_bf16(dy, w, None, b_is_kn=True)
+    assert out2.shape == (M, K)
+    assert float((out2.float() - ref2).abs().max()) <= float(ref2.abs().max()) * 2.0 ** -8
+    out3 = gemm_bf16(a, w, b)                          # cached plan, different bias pointer
+    assert torch.equal(out, out3)
