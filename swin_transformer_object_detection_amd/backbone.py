@@ -149,6 +149,7 @@ class SwinTransformer(nn.Module):
         self.embed_dim, self.ape, self.patch_norm = embed_dim, ape, patch_norm
         self.out_indices, self.frozen_stages = out_indices, frozen_stages
         self.compute_dtype = compute_dtype
+        self.fused_blocks = True       # one autograd node per block on the bf16 GPU path (ops/swin_block.py)
         self._dp_replay = None
         self._dp_pool = []
         self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, patch_norm)
@@ -245,6 +246,11 @@ class SwinTransformer(nn.Module):
         dt = self.compute_dtype
         a = blk.attn
         L = H * W
+        if (self.fused_blocks and dt == torch.bfloat16 and x.is_cuda and a.qkv.bias is not None and blk.mlp.fc1.bias is not None
+                and B * L >= 1024 and blk.dim % 8 == 0):
+            # the same kernels in the same order inside ONE autograd node (ops/swin_block.py): host overhead only
+            from .ops.swin_block import swin_block
+            return swin_block(x, n1, dp, (B, H, W, blk.num_heads, blk.shift_size), blk, next_norm, dt)
         qkv = _lin(n1, a.qkv.weight, a.qkv.bias, dt)                                     # :129
         qkv_bias = a.qkv.bias if a.qkv.bias is not None else torch.zeros(3 * blk.dim, device=x.device)
         o = ops.window_attention(qkv, qkv_bias, a.relative_position_bias_table, B, H, W, blk.num_heads,
