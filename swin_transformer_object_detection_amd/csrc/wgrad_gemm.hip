@@ -21,6 +21,7 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_w;
 // 16-byte piece of every stage -- more integer work than MFMA work in the loop.  The kernel loads from a clamped
 // address and masks by value (a pointer select against a local zero becomes a flat load + full wait).
 struct PlainX {
+    static constexpr int kBlocksManyTiles = 384;
     const bf16* x; int64_t T; int N2;
     struct St { int64_t off; bool ok; };
     __device__ __forceinline__ void init(St& s, int64_t t, int n) const { s.ok = n < N2; s.off = t * N2 + n; }
@@ -29,6 +30,7 @@ struct PlainX {
 };
 
 struct ConvX {
+    static constexpr int kBlocksManyTiles = 512;
     const bf16* x; int64_t T; int H, W, Cin;
     struct St { int64_t off; int y, x, dy, dx; bool ok; };
     __device__ __forceinline__ void init(St& s, int64_t t, int n) const {
@@ -243,7 +245,11 @@ static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, i
     // enough splits to fill the chip with 8 waves per CU (2 blocks of 4 waves or 1 block of 8), each split a multiple
     // of WKG t-stages
     int64_t stages = (T + WT - 1) / WT;
-    int splits = (int)((512 / WKG + (int64_t)g1 * g2 - 1) / ((int64_t)g1 * g2));
+    // blocks to aim for: 512 wave-quads for the two-k-group form (256 blocks of 8 waves); 384 for the many-tile form,
+    // of the Linear layers, where fewer splits (less atomic traffic) outweigh the fuller chip (47 -> 42 us at 1536x384;
+    // the conv form, 36 big-K tiles, prefers the 512: 303 vs 340 us at P2)
+    const int target = WKG == 1 ? XLoader::kBlocksManyTiles : 512;
+    int splits = (int)((target / WKG + (int64_t)g1 * g2 - 1) / ((int64_t)g1 * g2));
     int64_t max_splits = (stages + WKG - 1) / WKG;
     if (splits > max_splits) splits = (int)max_splits;
     if (splits < 1) splits = 1;

@@ -105,7 +105,8 @@ def gemmbb():
 
 
 def wgrad():
-    for (T, N1, N2) in [(128000, 288, 96), (128000, 384, 96), (128000, 96, 384), (32000, 768, 192), (8000, 1536, 384)]:
+    for (T, N1, N2) in [(128000, 288, 96), (128000, 384, 96), (128000, 96, 384), (32000, 768, 192), (8000, 1536, 384), (8000, 1152, 384),
+                        (2000, 3072, 768), (2000, 768, 768), (1024, 1024, 12544)]:
         dy = torch.randn(T, N1, device="cuda").bfloat16()
         x = torch.randn(T, N2, device="cuda").bfloat16()
         dw = torch.zeros(N1, N2, device="cuda")
