@@ -247,7 +247,7 @@ class SwinTransformer(nn.Module):
         a = blk.attn
         L = H * W
         if (self.fused_blocks and dt == torch.bfloat16 and x.is_cuda and a.qkv.bias is not None and blk.mlp.fc1.bias is not None
-                and B * L >= 1024 and blk.dim % 8 == 0):
+                and B * L >= ops.functional._MIN_T and blk.dim % 8 == 0):
             # the same kernels in the same order inside ONE autograd node (ops/swin_block.py): host overhead only
             from .ops.swin_block import swin_block
             return swin_block(x, n1, dp, (B, H, W, blk.num_heads, blk.shift_size), blk, next_norm, dt)

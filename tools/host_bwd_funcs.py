@@ -5,7 +5,7 @@ os.environ.setdefault("SWIN_LINEAR_MIN_T", "1")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swin_transformer_object_detection_amd import data, ddp, detector, mixed, presets
-from swin_transformer_object_detection_amd.ops import functional as Fn, roi_align as RA
+from swin_transformer_object_detection_amd.ops import functional as Fn, roi_align as RA, swin_block as SB
 from swin_transformer_object_detection_amd.optim import FusedAdamW
 acc = collections.defaultdict(lambda: [0.0, 0])
 def wrap(cls):
@@ -14,7 +14,7 @@ def wrap(cls):
         t0 = time.perf_counter(); r = orig(ctx, *a); e = acc[cls.__name__]; e[0] += time.perf_counter() - t0; e[1] += 1
         return r
     cls.backward = staticmethod(timed)
-for mod in (Fn, RA):
+for mod in (Fn, RA, SB):
     for name in dir(mod):
         c = getattr(mod, name)
         if isinstance(c, type) and issubclass(c, torch.autograd.Function) and c is not torch.autograd.Function:
