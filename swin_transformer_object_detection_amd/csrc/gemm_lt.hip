@@ -6,6 +6,7 @@
 // built once per (M, N, K, layout, bias) and a call is one hipblasLtMatmul.
 #include <hipblaslt/hipblaslt.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -34,7 +35,35 @@ hipblasLtHandle_t g_handle = nullptr;
 std::unordered_map<Key, Plan, KeyHash> g_plans;
 const size_t kWorkspace = 32u << 20;
 
-Plan* get_plan(int64_t M, int N, int K, int layout, int bias) {
+// First use of a shape: time the library's top candidates on the caller's own buffers and keep the fastest (the
+// heuristic's first choice is not always the best for these tall-skinny shapes).  One-off host synchronisation per
+// shape, during warm-up; SWIN_GEMM_TUNE=0 keeps the heuristic's first choice.
+static const int kCandidates = 12;
+
+static float time_algo(Plan& p, const hipblasLtMatmulHeuristicResult_t& h, const void* a, const void* b, const void* bias,
+                       void* c, void* workspace, hipStream_t s) {
+    const float alpha = 1.f, beta = 0.f;
+    if (h.workspaceSize > kWorkspace) return -1.f;
+    if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+    float best = -1.f;
+    for (int rep = 0; rep < 3; ++rep) {                      // rep 0 = warm-up
+        hipEventRecord(e0, s);
+        hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, b, p.a, a, p.b, &beta, c, p.c, c, p.c, &h.algo, workspace,
+                                             kWorkspace, s);
+        hipEventRecord(e1, s);
+        if (st != HIPBLAS_STATUS_SUCCESS || hipEventSynchronize(e1) != hipSuccess) { best = -1.f; break; }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && (best < 0.f || ms < best)) best = ms;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return best;
+}
+
+Plan* get_plan(int64_t M, int N, int K, int layout, int bias, const void* a = nullptr, const void* b = nullptr,
+               const void* bias_ptr = nullptr, void* c = nullptr, void* workspace = nullptr, hipStream_t stream = nullptr) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return nullptr;
     Key key{M, N, K, layout, bias};
@@ -67,12 +96,24 @@ Plan* get_plan(int64_t M, int N, int K, int layout, int bias) {
     int found = 0;
     // the bias pointer must be set for the heuristic of a bias epilogue on some versions; any non-null value does
     if (bias) {
-        const void* dummy = (const void*)0x1000;
+        const void* dummy = bias_ptr ? bias_ptr : (const void*)0x1000;
         hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &dummy, sizeof(dummy));
     }
-    hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.c, pref, 1, &p.algo, &found);
+    hipblasLtMatmulHeuristicResult_t cand[kCandidates];
+    static const bool tune = !(getenv("SWIN_GEMM_TUNE") && getenv("SWIN_GEMM_TUNE")[0] == '0');
+    const int want = (tune && a && b && c && workspace) ? kCandidates : 1;
+    hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.c, pref, want, cand, &found);
     hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) return nullptr;
+    int best = 0;
+    if (found > 1) {
+        float best_ms = -1.f;
+        for (int i = 0; i < found; ++i) {
+            const float ms = time_algo(p, cand[i], a, b, bias_ptr, c, workspace, stream);
+            if (ms >= 0.f && (best_ms < 0.f || ms < best_ms)) { best_ms = ms; best = i; }
+        }
+    }
+    p.algo = cand[best];
     p.ok = true;
     return &p;
 }
@@ -88,7 +129,7 @@ extern "C" int swin_gemm_bf16(const void* a, const void* b, const void* bias, vo
                               void* workspace, void* stream) {
     if (M == 0) return SWIN_OK;
     if (!a || !b || !c || !workspace || M < 0 || N <= 0 || K <= 0 || (b_layout != 0 && b_layout != 1)) return SWIN_ERR_BAD_ARG;
-    Plan* p = get_plan(M, N, K, b_layout, bias != nullptr);
+    Plan* p = get_plan(M, N, K, b_layout, bias != nullptr, a, b, bias, c, workspace, (hipStream_t)stream);
     if (!p) return SWIN_ERR_UNSUPPORTED;
     const float alpha = 1.f, beta = 0.f;
     hipblasStatus_t st;
