@@ -261,6 +261,31 @@ int64_t swin_gemm_workspace_bytes(void);
 int swin_gemm_bf16(const void* a, const void* b, const void* bias, void* c, int64_t M, int N, int K, int b_layout,
                    void* workspace, void* stream);
 
+/* ---- loss kernels of the detector heads (csrc/det_losses.hip): value + input gradients, fixed-size samples ----------
+ * det_rpn_loss_*:  AnchorHead.loss_single (anchor_head.py:375-434): sigmoid CE over the sampled anchors + L1 on the
+ *   positives, divided by the batch's sample count.  cls (B,A), reg (B,A,4) f32|bf16; inds/flags (B*S) from
+ *   det_random_sample, targets (B*S,4) from det_bbox_targets; out3 = {loss_cls, loss_bbox, n}.
+ * det_bbox_loss_*: BBoxHead.loss (bbox_head.py:188-238): softmax CE, accuracy, class-specific L1; out4 = {loss_cls,
+ *   acc %, loss_bbox, n_valid}.
+ * det_mask_loss_*: FCNMaskHead.loss / mask_cross_entropy (cross_entropy_loss.py): mean BCE of the labelled channel over
+ *   the valid RoIs; out2 = {loss, n_valid}.
+ * Backward entries take grad_out aligned with the forward's out array; dcls/dreg (rpn) and dpred (mask) must be zeroed
+ * by the caller, dcls/dbbox (bbox) are fully written. */
+int det_rpn_loss_fwd(const void* cls, const void* reg, int B, int64_t A, int S, const int64_t* inds, const uint8_t* flags,
+                     const float* targets, float* out3, int dtype, void* stream);
+int det_rpn_loss_bwd(const void* cls, const void* reg, int B, int64_t A, int S, const int64_t* inds, const uint8_t* flags,
+                     const float* targets, const float* out3, const float* grad_out, void* dcls, void* dreg, int dtype,
+                     void* stream);
+int det_bbox_loss_fwd(const void* cls, const void* bbox, int n, int num_classes, const int64_t* labels, const float* targets,
+                      const uint8_t* flags, float* out4, float* lse, int dtype, void* stream);
+int det_bbox_loss_bwd(const void* cls, const void* bbox, int n, int num_classes, const int64_t* labels, const float* targets,
+                      const uint8_t* flags, const float* out4, const float* lse, const float* grad_out, void* dcls,
+                      void* dbbox, int dtype, void* stream);
+int det_mask_loss_fwd(const void* pred, int n, int num_classes, int P, const float* target, const int64_t* labels,
+                      const uint8_t* valid, float* out2, float* per_roi, int dtype, void* stream);
+int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, const float* target, const int64_t* labels,
+                      const uint8_t* valid, const float* out2, const float* grad_out, void* dpred, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,12 @@ SIGNATURES = {
     "swin_gemm_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p, _p],
     "swin_adamw_step": [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p],
     "swin_adamw_chunk_elems": [],
+    "det_rpn_loss_fwd": [_p, _p, _i, _i64, _i, _p, _p, _p, _p, _i, _p],
+    "det_rpn_loss_bwd": [_p, _p, _i, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "det_bbox_loss_fwd": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _p],
+    "det_bbox_loss_bwd": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "det_mask_loss_fwd": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
+    "det_mask_loss_bwd": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "det_paste_masks": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p],
 }
 _RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_gemm_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,

@@ -200,7 +200,8 @@ def sample_static(assigned, num, pos_fraction):
 def assign_and_sample(bboxes, gt_bboxes, a_cfg, s_cfg, means, stds, gt_labels=None, num_leading_gt=0, valid=None, bg_label=0):
     """assigner.assign + sampler.sample + target encoding of one image (anchor_head.py:213-247,
     standard_roi_head.py:83-93 + bbox_head.py:140-186) with a fixed-size result:
-    (boxes (num,4), deltas (num,4), labels (num,), gt_inds (num,), is_pos (num,), valid (num,)).
+    (boxes (num,4), deltas (num,4), labels (num,), gt_inds (num,), is_pos (num,), valid (num,), inds (num,),
+    flags (num,) uint8: bit 0 used, bit 1 positive).
     On the GPU this is four HIP entry points (ops.max_iou_assign / random_sample_raw / bbox_targets); the torch
     forms above are the host restatement used on CPU."""
     num = s_cfg['num']
@@ -209,7 +210,7 @@ def assign_and_sample(bboxes, gt_bboxes, a_cfg, s_cfg, means, stds, gt_labels=No
                                               a_cfg.get('match_low_quality', True), gt_labels, num_leading_gt, valid)
         inds, flags = ops.random_sample_raw(assigned, num, s_cfg['pos_fraction'])
         boxes, deltas, gt_inds, labels = ops.bbox_targets(bboxes, inds, flags, assigned, gt_bboxes, means, stds, lab, bg_label)
-        return boxes, deltas, labels, gt_inds, flags >= 2, flags >= 1, inds
+        return boxes, deltas, labels, gt_inds, flags >= 2, flags >= 1, inds, flags
     g = num_leading_gt
     assigned, _, lab = max_iou_assign(bboxes[g:], gt_bboxes, a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'], a_cfg['min_pos_iou'],
                                       a_cfg.get('match_low_quality', True), gt_labels)
@@ -234,7 +235,7 @@ def assign_and_sample(bboxes, gt_bboxes, a_cfg, s_cfg, means, stds, gt_labels=No
     labels = None
     if lab is not None:
         labels = torch.where(is_pos, lab[idx], torch.full_like(idx, bg_label))
-    return boxes, deltas, labels, gt_inds, is_pos, ok, idx
+    return boxes, deltas, labels, gt_inds, is_pos, ok, idx, ok.to(torch.uint8) + 2 * is_pos.to(torch.uint8)
 
 
 def _cast(t, dtype):
@@ -386,9 +387,15 @@ class RPNHead(nn.Module):
         anchors = self.anchor_generator.grid_anchors_cat(sizes, cls_scores[0].device)
         B = cls_scores[0].size(0)
         cls, reg = self._flattened(cls_scores, bbox_preds)
+        samples = [assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg, self.means, self.stds) for i in range(B)]
+        if cls.is_cuda:
+            # both losses, over all images, in one forward and one backward launch (csrc/det_losses.hip)
+            lc, lb = ops.rpn_loss(cls, reg, torch.stack([s_[6] for s_ in samples]), torch.stack([s_[7] for s_ in samples]),
+                                  torch.stack([s_[1] for s_ in samples]))
+            return dict(loss_rpn_cls=lc * self.loss_cls_weight, loss_rpn_bbox=lb * self.loss_bbox_weight)
         loss_cls = loss_bbox = total = 0.
         for i in range(B):
-            _, tgt, _, _, is_pos, valid, idx = assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg, self.means, self.stds)
+            _, tgt, _, _, is_pos, valid, idx, _ = samples[i]
             c_i, r_i = cls[i][idx].float(), reg[i][idx].float()
             lc = F.binary_cross_entropy_with_logits(c_i, is_pos.float(), reduction='none')     # fg -> 1, bg -> 0
             loss_cls = loss_cls + (lc * valid).sum()
@@ -554,10 +561,14 @@ class Shared2FCBBoxHead(nn.Module):
     def loss(self, cls_score, bbox_pred, labels, bbox_targets, pos_mask, valid=None):
         """bbox_head.py loss: CE over the sampled RoIs (avg_factor = their count), class-specific L1 over the
         positives divided by the number of samples.  ``valid`` masks the unused slots of a fixed-size sample."""
-        cls_score, bbox_pred = cls_score.float(), bbox_pred.float()
         n = cls_score.size(0)
         if valid is None:
             valid = torch.ones(n, dtype=torch.bool, device=cls_score.device)
+        if cls_score.is_cuda and n > 0:
+            flags = valid.to(torch.uint8) + 2 * (pos_mask & valid).to(torch.uint8)
+            lc, acc, lb = ops.bbox_loss(cls_score, bbox_pred, labels, bbox_targets, flags, self.num_classes)
+            return dict(loss_cls=lc * self.loss_cls_weight, acc=acc, loss_bbox=lb * self.loss_bbox_weight)
+        cls_score, bbox_pred = cls_score.float(), bbox_pred.float()
         nv = valid.sum().clamp(min=1).float()
         ce = F.cross_entropy(cls_score, labels, reduction='none')
         loss_cls = (ce * valid).sum() / nv
@@ -631,6 +642,9 @@ class FCNMaskHead(nn.Module):
         n = mask_pred.size(0)
         if n == 0:
             return dict(loss_mask=mask_pred.sum() * 0)
+        if mask_pred.is_cuda:
+            v = valid if valid is not None else torch.ones(n, dtype=torch.bool, device=mask_pred.device)
+            return dict(loss_mask=ops.mask_loss(mask_pred, mask_targets, labels, v) * self.loss_mask_weight)
         pred = mask_pred.float()[torch.arange(n, device=mask_pred.device), labels]
         per_roi = F.binary_cross_entropy_with_logits(pred, mask_targets, reduction='none').mean(dim=(1, 2))
         if valid is None:
@@ -703,7 +717,7 @@ class StandardRoIHead(nn.Module):
                 props = torch.cat([gt_bboxes[i], props], 0)
                 pvalid = torch.cat([torch.ones(g, dtype=torch.bool, device=props.device), pvalid], 0)
             lead = g if s.get('add_gt_as_proposals', True) else 0
-            boxes, t_i, l_i, gt_ind, is_pos, valid, _ = assign_and_sample(
+            boxes, t_i, l_i, gt_ind, is_pos, valid, _, _ = assign_and_sample(
                 props, gt_bboxes[i], a, s, self.bbox_head.means, self.bbox_head.stds, gt_labels[i], lead, pvalid, bg_label=nc)
             roi_l.append(boxes); lab_l.append(l_i); tgt_l.append(t_i); pos_l.append(is_pos); val_l.append(valid)
             k = min(npos_max, num)                                    # positives come first in the sample

@@ -1,0 +1,106 @@
+"""Loss functions of the detector heads on the HIP kernels (csrc/det_losses.hip): one forward and one backward
+launch each, over the fixed-size samples produced by ops.random_sample_raw / ops.bbox_targets.
+
+Reference arithmetic: AnchorHead.loss_single (anchor_head.py:375-434), BBoxHead.loss (bbox_head.py:188-238),
+FCNMaskHead.loss -> mask_cross_entropy (losses/cross_entropy_loss.py)."""
+import torch
+
+from .._lib import SWIN_BF16, SWIN_F32, SwinHipError, call
+from .functional import _p, _s
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return SWIN_F32
+    if t.dtype == torch.bfloat16:
+        return SWIN_BF16
+    raise SwinHipError(f"loss kernels: float32 / bfloat16 logits only, got {t.dtype}")
+
+
+class _RPNLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls, reg, inds, flags, targets):
+        cls, reg = cls.contiguous(), reg.contiguous()
+        B, A = cls.shape
+        S = inds.numel() // B
+        out = torch.empty(3, device=cls.device, dtype=torch.float32)
+        call("det_rpn_loss_fwd", _p(cls), _p(reg), B, A, S, _p(inds), _p(flags), _p(targets), _p(out), _dt(cls), _s())
+        ctx.save_for_backward(cls, reg, inds, flags, targets, out)
+        ctx.mark_non_differentiable(inds, flags)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_bbox):
+        cls, reg, inds, flags, targets, out = ctx.saved_tensors
+        B, A = cls.shape
+        S = inds.numel() // B
+        g = torch.stack([g_cls if g_cls is not None else out.new_zeros(()), g_bbox if g_bbox is not None else out.new_zeros(())]).float()
+        dcls, dreg = torch.zeros_like(cls), torch.zeros_like(reg)
+        call("det_rpn_loss_bwd", _p(cls), _p(reg), B, A, S, _p(inds), _p(flags), _p(targets), _p(out), _p(g), _p(dcls), _p(dreg),
+             _dt(cls), _s())
+        return dcls, dreg, None, None, None
+
+
+def rpn_loss(cls, reg, inds, flags, targets):
+    """cls (B,A) logits, reg (B,A,4) deltas; inds / flags (B,S) and targets (B,S,4) of the sampled anchors ->
+    (loss_cls, loss_bbox): sums over the batch's samples divided by their count (anchor_head.py:375-434, 485-493)."""
+    return _RPNLoss.apply(cls, reg, inds.contiguous(), flags.contiguous(), targets.contiguous().float())
+
+
+class _BBoxLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls, bbox, labels, targets, flags, num_classes):
+        cls, bbox = cls.contiguous(), bbox.contiguous()
+        n = cls.size(0)
+        out = torch.empty(4, device=cls.device, dtype=torch.float32)
+        lse = torch.empty(n, device=cls.device, dtype=torch.float32)
+        call("det_bbox_loss_fwd", _p(cls), _p(bbox), n, num_classes, _p(labels), _p(targets), _p(flags), _p(out), _p(lse), _dt(cls),
+             _s())
+        ctx.save_for_backward(cls, bbox, labels, targets, flags, out, lse)
+        ctx.nc = num_classes
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_acc, g_bbox):
+        cls, bbox, labels, targets, flags, out, lse = ctx.saved_tensors
+        n = cls.size(0)
+        z = out.new_zeros(())
+        g = torch.stack([g_cls if g_cls is not None else z, z, g_bbox if g_bbox is not None else z, z]).float()
+        dcls, dbbox = torch.empty_like(cls), torch.empty_like(bbox)
+        call("det_bbox_loss_bwd", _p(cls), _p(bbox), n, ctx.nc, _p(labels), _p(targets), _p(flags), _p(out), _p(lse), _p(g), _p(dcls),
+             _p(dbbox), _dt(cls), _s())
+        return dcls, dbbox, None, None, None, None
+
+
+def bbox_loss(cls_score, bbox_pred, labels, targets, flags, num_classes):
+    """(loss_cls, acc %, loss_bbox) of BBoxHead.loss for a fixed-size sample (flags: bit 0 used, bit 1 positive)."""
+    return _BBoxLoss.apply(cls_score, bbox_pred, labels.contiguous(), targets.contiguous().float(), flags.contiguous(),
+                           int(num_classes))
+
+
+class _MaskLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, labels, valid):
+        pred = pred.contiguous()
+        n, nc = pred.shape[0], pred.shape[1]
+        P = pred.shape[2] * pred.shape[3]
+        out = torch.empty(2, device=pred.device, dtype=torch.float32)
+        per_roi = torch.empty(n, device=pred.device, dtype=torch.float32)
+        call("det_mask_loss_fwd", _p(pred), n, nc, P, _p(target), _p(labels), _p(valid), _p(out), _p(per_roi), _dt(pred), _s())
+        ctx.save_for_backward(pred, target, labels, valid, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, labels, valid, out = ctx.saved_tensors
+        n, nc = pred.shape[0], pred.shape[1]
+        P = pred.shape[2] * pred.shape[3]
+        dpred = torch.zeros_like(pred)
+        call("det_mask_loss_bwd", _p(pred), n, nc, P, _p(target), _p(labels), _p(valid), _p(out), _p(g.float().reshape(1)), _p(dpred),
+             _dt(pred), _s())
+        return dpred, None, None, None
+
+
+def mask_loss(mask_pred, mask_targets, labels, valid):
+    """mean sigmoid-BCE of the labelled class channel over the valid RoIs (mask_cross_entropy, reduction 'mean')."""
+    return _MaskLoss.apply(mask_pred, mask_targets.contiguous().float(), labels.contiguous(), valid.to(torch.uint8).contiguous())

@@ -639,3 +639,77 @@ def test_gemm_bf16_direct(ops, M, N, K):
     assert float((out2.float() - ref2).abs().max()) <= float(ref2.abs().max()) * 2.0 ** -8
     out3 = gemm_bf16(a, w, b)                          # cached plan, different bias pointer
     assert torch.equal(out, out3)
+
+
+# ------------------------------------------------------------------------------------------
+# loss kernels vs the reference formulas in torch fp32 (values and input gradients)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rpn_loss_kernel(ops, dtype):
+    """anchor_head.py:375-434: sigmoid CE over the sampled anchors + L1 on the positives, / number of samples."""
+    g = torch.Generator().manual_seed(3)
+    B, A, S = 2, 5000, 256
+    cls = (torch.randn(B, A, generator=g) * 2).to(dtype)
+    reg = torch.randn(B, A, 4, generator=g).to(dtype)
+    inds = torch.stack([torch.randperm(A, generator=g)[:S] for _ in range(B)])
+    flags = torch.randint(0, 3, (B, S), generator=g).to(torch.uint8)
+    flags = torch.where(flags == 2, torch.full_like(flags, 3), flags)          # 0 unused, 1 negative, 3 positive
+    tgt = torch.randn(B, S, 4, generator=g)
+    c0, r0 = cls.float().clone().requires_grad_(True), reg.float().clone().requires_grad_(True)
+    valid, pos = (flags & 1).bool(), (flags & 2).bool()
+    n = valid.sum().clamp(min=1).float()
+    ci = torch.gather(c0, 1, inds); ri = torch.gather(r0, 1, inds[..., None].expand(-1, -1, 4))
+    lc = (F.binary_cross_entropy_with_logits(ci, pos.float(), reduction='none') * valid).sum() / n
+    lb = ((ri - tgt).abs() * pos[..., None]).sum() / n
+    (lc * 1.5 + lb * 0.5).backward()
+    c1, r1 = cls.cuda().requires_grad_(True), reg.cuda().requires_grad_(True)
+    olc, olb = ops.rpn_loss(c1, r1, inds.cuda(), flags.cuda(), tgt.cuda())
+    (olc * 1.5 + olb * 0.5).backward()
+    close(olc, lc.detach(), 1e-5, 1e-5); close(olb, lb.detach(), 1e-5, 1e-5)
+    gtol = 1e-7 if dtype == torch.float32 else 2.0 ** -8 * float(c0.grad.abs().max())
+    close(c1.grad.float(), c0.grad, gtol, 1e-5 if dtype == torch.float32 else 2.0 ** -8)
+    close(r1.grad.float(), r0.grad, gtol, 1e-5 if dtype == torch.float32 else 2.0 ** -8)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bbox_and_mask_loss_kernels(ops, dtype):
+    """bbox_head.py:188-238 (CE, accuracy, class-specific L1) and mask_cross_entropy (mean BCE of the class channel)."""
+    g = torch.Generator().manual_seed(4)
+    n, nc = 300, 80
+    cls = (torch.randn(n, nc + 1, generator=g) * 2).to(dtype)
+    bbox = torch.randn(n, 4 * nc, generator=g).to(dtype)
+    labels = torch.randint(0, nc + 1, (n,), generator=g)
+    valid = torch.rand(n, generator=g) > 0.2
+    pos = (labels < nc) & valid & (torch.rand(n, generator=g) > 0.3)
+    labels = torch.where(pos, labels.clamp(max=nc - 1), torch.where(valid, torch.full_like(labels, nc), labels))
+    tgt = torch.randn(n, 4, generator=g)
+    flags = valid.to(torch.uint8) + 2 * pos.to(torch.uint8)
+    c0, b0 = cls.float().clone().requires_grad_(True), bbox.float().clone().requires_grad_(True)
+    nv = valid.sum().clamp(min=1).float()
+    lc = (F.cross_entropy(c0, labels, reduction='none') * valid).sum() / nv
+    acc = ((c0.argmax(1) == labels) & valid).sum() / nv * 100
+    pred = b0.view(n, nc, 4)[torch.arange(n), labels.clamp(max=nc - 1)]
+    lb = ((pred - tgt).abs() * pos[:, None]).sum() / nv
+    (lc * 2 + lb).backward()
+    c1, b1 = cls.cuda().requires_grad_(True), bbox.cuda().requires_grad_(True)
+    olc, oacc, olb = ops.bbox_loss(c1, b1, labels.cuda(), tgt.cuda(), flags.cuda(), nc)
+    (olc * 2 + olb).backward()
+    close(olc, lc.detach(), 1e-5, 1e-5); close(olb, lb.detach(), 1e-5, 1e-5); close(oacc, acc, 1e-4)
+    rel = 1e-5 if dtype == torch.float32 else 2.0 ** -8
+    close(c1.grad.float(), c0.grad, rel * float(c0.grad.abs().max()) + 1e-8, rel)
+    close(b1.grad.float(), b0.grad, rel * float(b0.grad.abs().max()) + 1e-8, rel)
+    # mask
+    m, P = 40, 28
+    mp = (torch.randn(m, nc, P, P, generator=g) * 2).to(dtype)
+    mt = (torch.rand(m, P, P, generator=g) > 0.5).float()
+    ml = torch.randint(0, nc, (m,), generator=g)
+    mv = torch.rand(m, generator=g) > 0.3
+    p0 = mp.float().clone().requires_grad_(True)
+    per = F.binary_cross_entropy_with_logits(p0[torch.arange(m), ml], mt, reduction='none').mean(dim=(1, 2))
+    lm = (per * mv).sum() / mv.sum().clamp(min=1)
+    (lm * 3).backward()
+    p1 = mp.cuda().requires_grad_(True)
+    olm = ops.mask_loss(p1, mt.cuda(), ml.cuda(), mv.cuda())
+    (olm * 3).backward()
+    close(olm, lm.detach(), 1e-5, 1e-5)
+    close(p1.grad.float(), p0.grad, rel * float(p0.grad.abs().max()) + 1e-9, rel)
