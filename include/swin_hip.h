@@ -286,6 +286,13 @@ int det_mask_loss_fwd(const void* pred, int n, int num_classes, int P, const flo
 int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, const float* target, const int64_t* labels,
                       const uint8_t* valid, const float* out2, const float* grad_out, void* dpred, int dtype, void* stream);
 
+/* swin_block_fwd / swin_block_bwd: the whole SwinTransformerBlock (swin_transformer.py:204-255) and its backward as ONE
+ * call each -- the library's own kernels launched in sequence from native code (csrc/block_runner.hip lists the
+ * pointer-table layouts).  p: HOST array of device pointers, iv: {B,H,W,C,nH,shift}, fv: {scale[, eps]}.  No allocation,
+ * no synchronisation; every buffer (saved activations, temporaries, gradient accumulators, workspaces) is the caller's. */
+int swin_block_fwd(const void* const* p, const int64_t* iv, const float* fv, void* stream);
+int swin_block_bwd(const void* const* p, const int64_t* iv, const float* fv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

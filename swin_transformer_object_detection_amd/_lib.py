@@ -46,6 +46,8 @@ SIGNATURES = {
     "det_random_sample": [_p, _i64, _i, _i, ctypes.c_uint64, _p, _p, _p, _p],
     "det_bbox_targets": [_p, _p, _p, _p, _p, _i, _p, _i64, _p, _p, _i, _p, _p, _p, _p, _p],
     "det_delta2bbox": [_p, _p, _i64, _p, _p, _f, _f, _f, _p, _p],
+    "swin_block_fwd": [_p, _p, _p, _p],
+    "swin_block_bwd": [_p, _p, _p, _p],
     "swin_gemm_workspace_bytes": [],
     "swin_gemm_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p, _p],
     "swin_adamw_step": [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p],

@@ -1,0 +1,113 @@
+// One C call per Swin block and direction: the launch sequence of SwinTransformerBlock.forward
+// (swin_transformer.py:204-255) and of its backward, issued from native code.  The kernels are the library's own entry
+// points (include/swin_hip.h); what this removes is the host cost of issuing them one by one from Python (13 forward /
+// 17 backward launches per block: ~150 / ~220 us of interpreter + ctypes + allocator time, against ~20 us here) --
+// the training step had become bound by exactly that.  All buffers are provided by the caller (pointer tables below);
+// nothing is allocated, nothing synchronises.
+#include <hip/hip_runtime.h>
+
+#include "../../include/swin_hip.h"
+#include "common.h"
+
+#define CHK(expr) do { int st_ = (expr); if (st_ != SWIN_OK) return st_; } while (0)
+
+// Forward pointer table (all device pointers; bf16 activations / weights unless noted):
+//  0 x            1 n1           2 dp0 (B f32|null)   3 dp1 (B f32|null)
+//  4 wqkv (3C,C)  5 bqkv16|null  6 bqkv32 (3C f32)    7 table (169,nH f32)   8 bias_exp (nH,64,64 f32, out)
+//  9 wproj (C,C)  10 bproj16|null 11 n2w f32 12 n2b f32 13 w1 (4C,C) 14 b1 (4C f32) 15 w2 (C,4C) 16 b216|null
+//  17 nnw f32|null 18 nnb f32|null
+//  outputs / saved: 19 qkv (T,3C) 20 lse (f32) 21 o 22 y (tmp) 23 x1 24 n2 25 mean2 26 rstd2 27 hpre (T,4C) 28 h (T,4C)
+//  29 y2 (tmp) 30 x2 31 nn|null 32 mean3|null 33 rstd3|null 34 gemm workspace
+// ints: B, H, W, C, nH, shift;  floats: scale, eps
+extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const float* fv, void* stream) {
+    if (!p || !iv || !fv) return SWIN_ERR_BAD_ARG;
+    const int B = (int)iv[0], H = (int)iv[1], W = (int)iv[2], C = (int)iv[3], nH = (int)iv[4], shift = (int)iv[5];
+    const float scale = fv[0], eps = fv[1];
+    const int64_t L = (int64_t)H * W, T = (int64_t)B * L;
+    void* ws = const_cast<void*>(p[34]);
+    CHK(swin_gemm_bf16(p[1], p[4], p[5], const_cast<void*>(p[19]), T, 3 * C, C, 0, ws, stream));
+    CHK(swin_rel_bias_expand((const float*)p[7], (float*)p[8], nH, stream));
+    CHK(swin_window_attn_fwd(p[19], (const float*)p[6], (const float*)p[8], const_cast<void*>(p[21]), (float*)p[20], B, H, W, C, nH,
+                             shift, scale, SWIN_BF16, stream));
+    CHK(swin_gemm_bf16(p[21], p[9], p[10], const_cast<void*>(p[22]), T, C, C, 0, ws, stream));
+    CHK(swin_add_layernorm_fwd(p[0], p[22], (const float*)p[2], L, (const float*)p[11], (const float*)p[12], const_cast<void*>(p[23]),
+                               const_cast<void*>(p[24]), (float*)p[25], (float*)p[26], T, C, eps, SWIN_BF16, stream));
+    CHK(swin_gemm_bf16(p[24], p[13], nullptr, const_cast<void*>(p[27]), T, 4 * C, C, 0, ws, stream));
+    CHK(swin_bias_gelu_fwd(p[27], (const float*)p[14], const_cast<void*>(p[28]), T, 4 * C, SWIN_BF16, stream));
+    CHK(swin_gemm_bf16(p[28], p[15], p[16], const_cast<void*>(p[29]), T, C, 4 * C, 0, ws, stream));
+    if (p[17])
+        CHK(swin_add_layernorm_fwd(p[23], p[29], (const float*)p[3], L, (const float*)p[17], (const float*)p[18],
+                                   const_cast<void*>(p[30]), const_cast<void*>(p[31]), (float*)p[32], (float*)p[33], T, C, eps,
+                                   SWIN_BF16, stream));
+    else
+        CHK(swin_add_layernorm_fwd(p[23], p[29], (const float*)p[3], L, nullptr, nullptr, const_cast<void*>(p[30]), nullptr, nullptr,
+                                   nullptr, T, C, eps, SWIN_BF16, stream));
+    return SWIN_OK;
+}
+
+// Backward pointer table:
+//  saved:  0 n1  1 qkv  2 bias_exp  3 lse  4 o  5 x1  6 mean2  7 rstd2  8 n2  9 hpre  10 h  11 x2  12 mean3|null  13 rstd3|null
+//          14 dp0|null  15 dp1|null  16 wqkv  17 wproj  18 w1  19 w2  20 n2w  21 nnw|null  22 b1 (f32)  23 qkv_bias (f32)
+//  grads in: 24 dx2 (residual-stream gradient; with a next norm it may be null)   25 dnn (gradient of the next norm's output;
+//          required with a next norm)
+//  out:    26 dx   27 dn1
+//  temporaries: 28 dx1  29 dy2 (INPUT when there is no next norm: dx2 scaled by DropPath, or dx2 itself)  30 dh (T,4C)
+//          31 dhpre (T,4C)  32 dn2  33 dy  34 do  35 dqkv (T,3C)  36 dbexp (nH,64,64 f32; zeroed here)
+//  fp32 gradient accumulators (null = not wanted): 37 dWqkv 38 dbqkv 39 dbqkv_pad 40 dWproj 41 dbproj 42 dW1 43 db1 44 dW2
+//          45 db2 46 dn2w 47 dn2b 48 dnnw 49 dnnb 50 dtable
+//  workspaces: 51 attention backward  52 LayerNorm backward (norm2)  53 LayerNorm backward (next norm)  54 gemm
+// ints: B, H, W, C, nH, shift;  floats: scale
+extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const float* fv, void* stream) {
+    if (!p || !iv || !fv) return SWIN_ERR_BAD_ARG;
+    const int B = (int)iv[0], H = (int)iv[1], W = (int)iv[2], C = (int)iv[3], nH = (int)iv[4], shift = (int)iv[5];
+    const float scale = fv[0];
+    const int64_t L = (int64_t)H * W, T = (int64_t)B * L;
+    void* gws = const_cast<void*>(p[54]);
+    auto M = [&](int i) { return const_cast<void*>(p[i]); };
+    const void* dx1 = p[28];
+    const void* dy2 = p[29];
+    if (p[21]) {                              // second residual + next norm
+        if (!p[25] || !p[48] || !p[49]) return SWIN_ERR_BAD_ARG;
+        CHK(swin_layernorm_bwd(p[25], p[11], (const float*)p[21], (const float*)p[12], (const float*)p[13], p[24], M(28),
+                               p[15] ? M(29) : nullptr, (const float*)p[15], L, (float*)p[48], (float*)p[49], T, C, SWIN_BF16, M(53),
+                               stream));
+        if (!p[15]) dy2 = p[28];
+    } else {
+        if (!p[24]) return SWIN_ERR_BAD_ARG;
+        dx1 = p[24];
+    }
+    // fc2: dh = dy2 w2 ; dW2 += dy2^T h ; db2 += colsum dy2
+    CHK(swin_gemm_bf16(dy2, p[19], nullptr, M(30), T, 4 * C, C, 1, gws, stream));
+    if (p[44] || p[45]) {
+        if (!p[44]) return SWIN_ERR_UNSUPPORTED;
+        CHK(wgrad_linear_bf16(dy2, p[10], (float*)p[44], (float*)p[45], T, C, 4 * C, stream));
+    }
+    // GELU
+    CHK(swin_bias_gelu_bwd(p[30], p[9], (const float*)p[22], M(31), (float*)p[43], T, 4 * C, SWIN_BF16, stream));
+    // fc1
+    CHK(swin_gemm_bf16(p[31], p[18], nullptr, M(32), T, C, 4 * C, 1, gws, stream));
+    if (p[42]) CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], nullptr, T, 4 * C, C, stream));
+    // first residual + norm2
+    if (!p[46] || !p[47]) return SWIN_ERR_BAD_ARG;
+    CHK(swin_layernorm_bwd(p[32], p[5], (const float*)p[20], (const float*)p[6], (const float*)p[7], dx1, M(26), p[14] ? M(33) : nullptr,
+                           (const float*)p[14], L, (float*)p[46], (float*)p[47], T, C, SWIN_BF16, M(52), stream));
+    const void* dy = p[14] ? p[33] : p[26];
+    // proj
+    CHK(swin_gemm_bf16(dy, p[17], nullptr, M(34), T, C, C, 1, gws, stream));
+    if (p[40] || p[41]) {
+        if (!p[40]) return SWIN_ERR_UNSUPPORTED;
+        CHK(wgrad_linear_bf16(dy, p[4], (float*)p[40], (float*)p[41], T, C, C, stream));
+    }
+    // window attention
+    if (hipMemsetAsync(M(36), 0, (size_t)nH * 64 * 64 * sizeof(float), (hipStream_t)stream) != hipSuccess) return SWIN_ERR_LAUNCH;
+    CHK(swin_window_attn_bwd(p[1], (const float*)p[23], (const float*)p[2], (const float*)p[3], p[34], M(35), (float*)p[36],
+                             (float*)p[39], M(51), B, H, W, C, nH, shift, scale, SWIN_BF16, stream));
+    if (p[50]) CHK(swin_rel_bias_reduce((const float*)p[36], (float*)p[50], nH, stream));
+    // qkv
+    CHK(swin_gemm_bf16(p[35], p[16], nullptr, M(27), T, C, 3 * C, 1, gws, stream));
+    if (p[37] || p[38]) {
+        if (!p[37]) return SWIN_ERR_UNSUPPORTED;
+        CHK(wgrad_linear_bf16(p[35], p[0], (float*)p[37], (float*)p[38], T, 3 * C, C, stream));
+    }
+    return SWIN_OK;
+}

@@ -6,6 +6,9 @@ separate autograd Functions each of them pays the Function.apply / graph-node / 
 forward, ~20 us backward on this stack): ~0.25 ms of pure host time per block, 3 ms per step, on a step whose GPU
 time is ~17 ms.  This module runs the same kernels, in the same order, inside ONE Function: the arithmetic is
 identical to ``backbone._block`` built from the individual ops (tests compare the two)."""
+import ctypes
+import os
+
 import torch
 
 from .. import _lib, mixed
@@ -58,6 +61,54 @@ def _bias16(b):
     return c if c is not None else b.detach().to(torch.bfloat16)
 
 
+# ---- native runner (csrc/block_runner.hip): one C call per block and direction ------------------------------------
+_RUNNER = os.environ.get("SWIN_BLOCK_RUNNER", "1") != "0"     # 0: issue the kernels one by one from Python (A/B, debugging)
+_SCRATCH = {}
+
+
+def _scratch(dev, key, nbytes):
+    """persistent scratch (contents never outlive one call on one stream)"""
+    k = (dev, key)
+    t = _SCRATCH.get(k)
+    if t is None or t.numel() < nbytes:
+        t = _SCRATCH[k] = torch.empty(max(int(nbytes), 16), device=dev, dtype=torch.uint8)
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _carve(flat, sizes):
+    out, off = [], 0
+    for n in sizes:
+        out.append(flat[off:off + n])
+        off += n
+    return out
+
+
+def _acc_weight(w, w_master, need):
+    """fp32 accumulator for a GEMM weight gradient -> (buffer | None, finish() -> gradient for autograd | None)."""
+    if not need:
+        return None, (lambda: None)
+    sk = mixed.grad_sink(w_master)
+    if sk is not None and sk[0].numel() == w.numel() and sk[0].is_contiguous():
+        return sk[0], (lambda: (sk[1](), None)[1])
+    z = torch.zeros(w.shape, device=w.device, dtype=torch.float32)
+    return z, (lambda: z.to(w.dtype))
+
+
+def _acc_param(p, need=True):
+    """fp32 accumulator for a small fp32 parameter -> (buffer | None, finish() -> gradient | None)."""
+    if p is None or not need:
+        return None, (lambda: None)
+    sk = mixed.grad_sink(p)
+    if sk is not None:
+        return sk[0], (lambda: (sk[1](), None)[1])
+    z = torch.zeros_like(p, dtype=torch.float32)
+    return z, (lambda: z)
+
+
 class _SwinBlockFn(torch.autograd.Function):
     """(x, n1) -> (x_out, n_next).  Tensor inputs, in order:
     x, n1, dp0, dp1, wqkv, bqkv, table, wproj, bproj, n2w, n2b, w1, b1, w2, b2, nnw, nnb
@@ -72,6 +123,9 @@ class _SwinBlockFn(torch.autograd.Function):
         dev = x.device
         x = x.contiguous()
         n1 = n1.contiguous()
+        if _RUNNER:
+            return _SwinBlockFn._forward_native(ctx, geom, masters, x, n1, dp0, dp1, wqkv, bqkv, table, wproj, bproj, n2w, n2b, w1,
+                                                b1, w2, b2, nnw, nnb)
         # ---- attention branch (:211-247, :129-151) ----
         qkv = gemm_bf16(n1.view(T, C), wqkv, _bias16(bqkv), out_shape=(B, L, 3 * C))
         bias_exp = rel_bias_expand(table.detach())
@@ -126,6 +180,8 @@ class _SwinBlockFn(torch.autograd.Function):
         L = H * W
         T = B * L
         dev = x1.device
+        if _RUNNER:
+            return _SwinBlockFn._backward_native(ctx, dx2, dnn)
         # needs_input_grad indices: 0 geom, 1 masters, 2 x, 3 n1, 4 dp0, 5 dp1, 6 wqkv, 7 bqkv, 8 table, 9 wproj, 10 bproj,
         # 11 n2w, 12 n2b, 13 w1, 14 b1, 15 w2, 16 b2, 17 nnw, 18 nnb
         nig = ctx.needs_input_grad
@@ -203,6 +259,116 @@ class _SwinBlockFn(torch.autograd.Function):
             gb = g['bqkv_pad'] if gb is None else gb + g['bqkv_pad']
         return (None, None, dx, dn1, None, None, g['wqkv'], gb, g['table'], g['wproj'], g['bproj'], g['n2w'], g['n2b'], g['w1'],
                 g['b1'], g['w2'], g['b2'], g.get('nnw'), g.get('nnb'))
+
+
+    # ---------------------------------------------------------------------------------------------- native runner
+    @staticmethod
+    def _forward_native(ctx, geom, masters, x, n1, dp0, dp1, wqkv, bqkv, table, wproj, bproj, n2w, n2b, w1, b1, w2, b2, nnw, nnb):
+        B, H, W, nH, shift = geom
+        C = x.shape[-1]
+        L = H * W
+        T = B * L
+        dev = x.device
+        has_next = nnw is not None
+        scale = float((C // nH) ** -0.5)
+        TC = T * C
+        flat = torch.empty(16 * TC, device=dev, dtype=torch.bfloat16)
+        qkv, o, y, x1, n2, hpre, h, y2 = _carve(flat, [3 * TC, TC, TC, TC, TC, 4 * TC, 4 * TC, TC])
+        nW = ((H + 6) // 7) * ((W + 6) // 7)
+        nl = B * nW * nH * 64
+        f32 = torch.empty(nl + 4 * T + nH * 4096, device=dev, dtype=torch.float32)
+        lse, mean2, rstd2, mean3, rstd3, bias_exp = _carve(f32, [nl, T, T, T, T, nH * 4096])
+        x2 = torch.empty_like(x)
+        nn_ = torch.empty_like(x) if has_next else None
+        qkv_bias = bqkv.detach() if bqkv is not None else torch.zeros(3 * C, device=dev)
+        gws = _scratch(dev, 'gemm', _lib.lib().swin_gemm_workspace_bytes())
+        tab = _f32(table.detach())
+        f_n2w, f_n2b = _f32(n2w), _f32(n2b)
+        f_nnw, f_nnb = (_f32(nnw), _f32(nnb)) if has_next else (None, None)
+        bq16, bp16, b216 = _bias16(bqkv), _bias16(bproj), _bias16(b2)
+        ptrs = (ctypes.c_void_p * 35)(
+            _ptr(x), _ptr(n1), _ptr(dp0), _ptr(dp1), _ptr(wqkv), _ptr(bq16), _ptr(qkv_bias), _ptr(tab), _ptr(bias_exp), _ptr(wproj),
+            _ptr(bp16), _ptr(f_n2w), _ptr(f_n2b), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b216), _ptr(f_nnw), _ptr(f_nnb), _ptr(qkv),
+            _ptr(lse), _ptr(o), _ptr(y), _ptr(x1), _ptr(n2), _ptr(mean2), _ptr(rstd2), _ptr(hpre), _ptr(h), _ptr(y2), _ptr(x2),
+            _ptr(nn_), _ptr(mean3) if has_next else None, _ptr(rstd3) if has_next else None, _ptr(gws))
+        iv = (ctypes.c_int64 * 6)(B, H, W, C, nH, shift)
+        fv = (ctypes.c_float * 2)(scale, LN_EPS)
+        call("swin_block_fwd", ptrs, iv, fv, _s())
+        shp = (B, L, C)
+        ctx.save_for_backward(n1, qkv.view(B, L, 3 * C), bias_exp.view(nH, 64, 64), lse, o.view(shp), x1.view(shp), mean2, rstd2,
+                              n2.view(shp), hpre.view(B, L, 4 * C), h.view(B, L, 4 * C), x2, mean3 if has_next else None,
+                              rstd3 if has_next else None, dp0, dp1, wqkv, wproj, w1, w2, n2w, nnw, b1, qkv_bias)
+        ctx.geom = (B, H, W, C, nH, shift, scale)
+        ctx.masters = masters
+        ctx.params = (bqkv, table, bproj, n2b, b2, nnb)
+        ctx.has_next = has_next
+        return x2, nn_
+
+    @staticmethod
+    def _backward_native(ctx, dx2, dnn):
+        (n1, qkv, bias_exp, lse, o, x1, mean2, rstd2, n2, hpre, h, x2, mean3, rstd3, dp0, dp1, wqkv, wproj, w1, w2, n2w, nnw, b1,
+         qkv_bias) = ctx.saved_tensors
+        B, H, W, C, nH, shift, scale = ctx.geom
+        m_wqkv, m_wproj, m_w1, m_w2 = ctx.masters
+        bqkv, table, bproj, n2b, b2, nnb = ctx.params
+        L = H * W
+        T = B * L
+        TC = T * C
+        dev = x1.device
+        nig = ctx.needs_input_grad
+        has_next = ctx.has_next
+        flat = torch.empty(16 * TC, device=dev, dtype=torch.bfloat16)
+        dx1, dy2, dh, dhpre, dn2, dy, do, dqkv = _carve(flat, [TC, TC, 4 * TC, 4 * TC, TC, TC, TC, 3 * TC])
+        if has_next:
+            dnn = torch.zeros_like(x2) if dnn is None else dnn.contiguous()
+            dx2 = None if dx2 is None else dx2.contiguous()
+        else:
+            dx2 = dx2.contiguous()
+            dy2 = dx2 if dp1 is None else (dx2.view(B, -1) * dp1.to(dx2.dtype).view(B, 1)).view_as(dx2)
+        dx = torch.empty_like(x1)
+        dn1 = torch.empty_like(x1)
+        dbexp = torch.empty(nH * 4096, device=dev, dtype=torch.float32)
+        padded = (H % 7 != 0) or (W % 7 != 0)
+        a_wqkv, f_wqkv = _acc_weight(wqkv, m_wqkv, nig[6])
+        a_wproj, f_wproj = _acc_weight(wproj, m_wproj, nig[9])
+        a_w1, f_w1 = _acc_weight(w1, m_w1, nig[13])
+        a_w2, f_w2 = _acc_weight(w2, m_w2, nig[15])
+        need_bq = bqkv is not None and bqkv.requires_grad
+        a_bqkv, f_bqkv = _acc_param(bqkv, need_bq and a_wqkv is not None)
+        a_bpad = a_bqkv if (padded and need_bq and a_bqkv is not None) else None
+        f_bpad = (lambda: None)
+        if padded and need_bq and a_bqkv is None:
+            a_bpad, f_bpad = _acc_param(bqkv)
+        a_bproj, f_bproj = _acc_param(bproj, bproj is not None and bproj.requires_grad and a_wproj is not None)
+        a_b2, f_b2 = _acc_param(b2, b2 is not None and b2.requires_grad and a_w2 is not None)
+        a_b1, f_b1 = _acc_param(b1)
+        a_n2w, f_n2w = _acc_param(n2w)
+        a_n2b, f_n2b = _acc_param(n2b)
+        a_nnw, f_nnw = _acc_param(nnw) if has_next else (None, (lambda: None))
+        a_nnb, f_nnb = _acc_param(nnb) if has_next else (None, (lambda: None))
+        a_tab, f_tab = _acc_param(table)
+        lib = _lib.lib()
+        ws_attn = _scratch(dev, 'attn_bwd', lib.swin_window_attn_bwd_workspace_bytes(B, H, W, nH, SWIN_BF16))
+        ln_bytes = lib.swin_layernorm_bwd_workspace_bytes(T, C, SWIN_BF16)
+        ws_ln2 = _scratch(dev, 'ln2', ln_bytes)
+        ws_ln3 = _scratch(dev, 'ln3', ln_bytes)
+        gws = _scratch(dev, 'gemm', lib.swin_gemm_workspace_bytes())
+        ptrs = (ctypes.c_void_p * 55)(
+            _ptr(n1), _ptr(qkv), _ptr(bias_exp), _ptr(lse), _ptr(o), _ptr(x1), _ptr(mean2), _ptr(rstd2), _ptr(n2), _ptr(hpre),
+            _ptr(h), _ptr(x2), _ptr(mean3), _ptr(rstd3), _ptr(dp0), _ptr(dp1), _ptr(wqkv), _ptr(wproj), _ptr(w1), _ptr(w2),
+            _ptr(n2w), _ptr(nnw) if has_next else None, _ptr(b1), _ptr(qkv_bias), _ptr(dx2), _ptr(dnn) if has_next else None, _ptr(dx),
+            _ptr(dn1), _ptr(dx1), _ptr(dy2), _ptr(dh), _ptr(dhpre), _ptr(dn2), _ptr(dy), _ptr(do), _ptr(dqkv), _ptr(dbexp),
+            _ptr(a_wqkv), _ptr(a_bqkv), _ptr(a_bpad), _ptr(a_wproj), _ptr(a_bproj), _ptr(a_w1), _ptr(a_b1), _ptr(a_w2), _ptr(a_b2),
+            _ptr(a_n2w), _ptr(a_n2b), _ptr(a_nnw), _ptr(a_nnb), _ptr(a_tab), _ptr(ws_attn), _ptr(ws_ln2), _ptr(ws_ln3), _ptr(gws))
+        iv = (ctypes.c_int64 * 6)(B, H, W, C, nH, shift)
+        fv = (ctypes.c_float * 1)(scale)
+        call("swin_block_bwd", ptrs, iv, fv, _s())
+        g_bq = f_bqkv()
+        g_pad = f_bpad()
+        if g_pad is not None:
+            g_bq = g_pad if g_bq is None else g_bq + g_pad
+        return (None, None, dx, dn1, None, None, f_wqkv(), g_bq, f_tab(), f_wproj(), f_bproj(), f_n2w(), f_n2b(), f_w1(), f_b1(),
+                f_w2(), f_b2(), f_nnw(), f_nnb())
 
 
 def swin_block(x, n1, dp, geom, blk, next_norm, dtype):
