@@ -188,11 +188,12 @@ int roi_align_bwd(const float* grad_output, const float* rois, float* grad_input
  * channels-last memory: RoI k reads level lvl[k] (host-side map_roi_levels, :47-51); lvl[k] < 0 skips the RoI
  * (zero output row).  feats / grads are HOST arrays of n_levels (<= 4) device pointers. */
 int roi_align_multilevel_fwd(const void* const* feats, const int* Hs, const int* Ws, const float* scales,
-                             int n_levels, const float* rois, const int* lvl, float* output, int C, int K,
-                             int ph, int pw, int sampling_ratio, int aligned, int in_dtype, void* stream);
+                             int n_levels, const float* rois, const int* lvl, void* output, int C, int K,
+                             int ph, int pw, int sampling_ratio, int aligned, int in_dtype, int out_dtype, void* stream);
 int roi_align_multilevel_bwd(float* const* grads, const int* Hs, const int* Ws, const float* scales, int n_levels,
-                             const float* grad_output, const float* rois, const int* lvl, int C, int K, int ph,
-                             int pw, int sampling_ratio, int aligned, void* stream);
+                             const void* grad_output, const float* rois, const int* lvl, int C, int K, int ph,
+                             int pw, int sampling_ratio, int aligned, int grad_dtype, void* stream);
+/* output / grad_output: (K, ph, pw, C) f32, or bf16 when out_dtype / grad_dtype = 1 (bf16 features only). */
 
 /* ------------------------------------------------------------------------------------
  * mmcv.ops.nms device part -- call sites rpn_head.py:233, bbox_nms.py:84 (through batched_nms).

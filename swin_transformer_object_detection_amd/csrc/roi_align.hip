@@ -227,7 +227,8 @@ __device__ __forceinline__ void bin_range(const int* P0, const int* NP, int nb, 
     lo = (unsigned char)(l < h ? l : 0); hi = (unsigned char)h;
 }
 
-__device__ __forceinline__ void roi_bwd_body(RoiBwdLds& L, float* __restrict__ gin, const float* __restrict__ gout,
+template <typename TG>
+__device__ __forceinline__ void roi_bwd_body(RoiBwdLds& L, float* __restrict__ gin, const TG* __restrict__ gout,
                                              const float* __restrict__ roi, int64_t k, int C, int H, int W, int ph, int pw,
                                              float scale, int sr, int aligned) {
     const int t = threadIdx.x;
@@ -262,7 +263,7 @@ __device__ __forceinline__ void roi_bwd_body(RoiBwdLds& L, float* __restrict__ g
         else if (t >= 32 && t < 32 + pw) axis_fill(g.start_w, g.bin_w, t - 32, g.grid_w, W, L.Wx + L.XO[t - 32], L.X0[t - 32], L.NX[t - 32]);
     }
     float* base = gin + (int64_t)g.batch * H * W * C;
-    const float* gob = gout + k * ph * pw * C;
+    const TG* gob = gout + k * ph * pw * C;
     if (!L.slow) {
         const int ny = L.ymax - L.ymin, nx = L.xmax - L.xmin;
         for (int q = t; q < ny; q += 256) bin_range(L.Y0, L.NY, ph, L.ymin + q, L.ylo[q], L.yhi[q]);
@@ -279,15 +280,15 @@ __device__ __forceinline__ void roi_bwd_body(RoiBwdLds& L, float* __restrict__ g
                     const int f0 = y - L.Y0[i0], f1 = y - L.Y0[i1];
                     const float w0 = (ihi > ilo && f0 >= 0 && f0 < L.NY[i0]) ? L.Wy[L.YO[i0] + f0] : 0.f;
                     const float w1 = (i1 != i0 && f1 >= 0 && f1 < L.NY[i1]) ? L.Wy[L.YO[i1] + f1] : 0.f;
-                    const float* g0 = gob + (int64_t)i0 * pw * C + c;
-                    const float* g1 = gob + (int64_t)i1 * pw * C + c;
-                    for (int j = 0; j < pw; ++j) L.R[j][t] = w0 * g0[j * C] + w1 * g1[j * C];
+                    const TG* g0 = gob + (int64_t)i0 * pw * C + c;
+                    const TG* g1 = gob + (int64_t)i1 * pw * C + c;
+                    for (int j = 0; j < pw; ++j) L.R[j][t] = w0 * Elt<TG>::ld(g0 + j * C) + w1 * Elt<TG>::ld(g1 + j * C);
                 } else {
                     for (int j = 0; j < pw; ++j) {
                         float r = 0.f;
                         for (int i = ilo; i < ihi; ++i) {
                             const int fy = y - L.Y0[i];
-                            if (fy >= 0 && fy < L.NY[i]) r += L.Wy[L.YO[i] + fy] * gob[((int64_t)i * pw + j) * C + c];
+                            if (fy >= 0 && fy < L.NY[i]) r += L.Wy[L.YO[i] + fy] * Elt<TG>::ld(gob + ((int64_t)i * pw + j) * C + c);
                         }
                         L.R[j][t] = r;
                     }
@@ -307,10 +308,10 @@ __device__ __forceinline__ void roi_bwd_body(RoiBwdLds& L, float* __restrict__ g
         }
     } else if (blockIdx.y == 0) {        // per-sample path (very large sampling grids / footprints)
         for (int c = t; c < C; c += 256) {
-            const float* go = gob + c;
+            const TG* go = gob + c;
             for (int i = 0; i < ph; ++i)
                 for (int j = 0; j < pw; ++j) {
-                    const float gv = go[(i * pw + j) * C];
+                    const float gv = Elt<TG>::ld(go + (i * pw + j) * C);
                     for (int iy = 0; iy < g.grid_h; ++iy) {
                         float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
                         for (int ix = 0; ix < g.grid_w; ++ix) {
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restric
                                                           int ph, int pw, float scale, int sr, int aligned) {
     __shared__ RoiBwdLds L;
     const int64_t k = blockIdx.x;
-    roi_bwd_body(L, gin, gout, rois + 5 * k, k, C, H, W, ph, pw, scale, sr, aligned);
+    roi_bwd_body<float>(L, gin, gout, rois + 5 * k, k, C, H, W, ph, pw, scale, sr, aligned);
 }
 
 // ----------------------------------------------------------------------------- multi-level (FPN) NHWC
@@ -343,9 +344,9 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restric
 // no host synchronisation.  RoIs with lvl < 0 are skipped (output rows stay zero): slots of a fixed-size sample.
 struct MLFeats { const void* p[4]; int H[4], W[4]; float scale[4]; };
 
-template <typename T>
+template <typename T, typename TO>
 __global__ __launch_bounds__(256) void roi_align_ml_fwd_nhwc(MLFeats F, const float* __restrict__ rois, const int* __restrict__ lvl,
-                                                             float* __restrict__ out, int C, int64_t total, int ph, int pw,
+                                                             TO* __restrict__ out, int C, int64_t total, int ph, int pw,
                                                              int sr, int aligned) {
     const int cg = C / 4;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -379,20 +380,26 @@ __global__ __launch_bounds__(256) void roi_align_ml_fwd_nhwc(MLFeats F, const fl
             }
             o = float4{acc[0] / g.count, acc[1] / g.count, acc[2] / g.count, acc[3] / g.count};
         }
-        *(float4*)(out + idx * 4) = o;
+        if constexpr (sizeof(TO) == 4) {
+            *(float4*)(out + idx * 4) = o;
+        } else {                                      // bf16 output: the RoI heads consume it directly (no cast pass)
+            bf16x4 ob = {(bf16)o.x, (bf16)o.y, (bf16)o.z, (bf16)o.w};
+            *(bf16x4*)(out + idx * 4) = ob;
+        }
     }
 }
 
 struct MLGrads { float* p[4]; int H[4], W[4]; float scale[4]; };
 
-__global__ __launch_bounds__(256) void roi_align_ml_bwd_nhwc(MLGrads G, const float* __restrict__ gout, const float* __restrict__ rois,
+template <typename TG>
+__global__ __launch_bounds__(256) void roi_align_ml_bwd_nhwc(MLGrads G, const TG* __restrict__ gout, const float* __restrict__ rois,
                                                              const int* __restrict__ lvl, int C, int K, int ph, int pw, int sr,
                                                              int aligned) {
     __shared__ RoiBwdLds L;
     const int64_t k = blockIdx.x;
     const int l = lvl[k];
     if (l < 0) return;
-    roi_bwd_body(L, G.p[l], gout, rois + 5 * k, k, C, G.H[l], G.W[l], ph, pw, G.scale[l], sr, aligned);
+    roi_bwd_body<TG>(L, G.p[l], gout, rois + 5 * k, k, C, G.H[l], G.W[l], ph, pw, G.scale[l], sr, aligned);
 }
 
 // row splits per RoI: enough blocks to fill the chip when K is small
@@ -464,10 +471,11 @@ extern "C" int roi_align_bwd(const float* grad_output, const float* rois, float*
 
 // Multi-level RoIAlign over an FPN pyramid in channels-last memory (see roi_align_ml_fwd_nhwc above).
 //   feats[l]: (N, H[l], W[l], C) in_dtype, l < n_levels <= 4;  lvl (K) int32 level per RoI, < 0 = skip (zero row);
-//   output (K, ph, pw, C) f32.
+//   output (K, ph, pw, C) f32, or bf16 (out_dtype) for bf16 features: one rounding of the fp32 result.
 extern "C" int roi_align_multilevel_fwd(const void* const* feats, const int* Hs, const int* Ws, const float* scales,
-                                        int n_levels, const float* rois, const int* lvl, float* output, int C, int K,
-                                        int ph, int pw, int sampling_ratio, int aligned, int in_dtype, void* stream) {
+                                        int n_levels, const float* rois, const int* lvl, void* output, int C, int K,
+                                        int ph, int pw, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
+                                        void* stream) {
     if (K == 0) return SWIN_OK;
     if (!feats || !Hs || !Ws || !scales || !rois || !lvl || !output || n_levels <= 0 || n_levels > 4 || C <= 0 || K < 0)
         return SWIN_ERR_BAD_ARG;
@@ -480,18 +488,20 @@ extern "C" int roi_align_multilevel_fwd(const void* const* feats, const int* Hs,
     }
     hipStream_t s = (hipStream_t)stream;
     int64_t total = (int64_t)K * ph * pw * (C / 4);
-    if (in_dtype == SWIN_F32)
-        roi_align_ml_fwd_nhwc<float><<<ra_blocks(total), 256, 0, s>>>(F, rois, lvl, output, C, total, ph, pw, sampling_ratio, aligned);
-    else if (in_dtype == SWIN_BF16)
-        roi_align_ml_fwd_nhwc<bf16><<<ra_blocks(total), 256, 0, s>>>(F, rois, lvl, output, C, total, ph, pw, sampling_ratio, aligned);
+    if (in_dtype == SWIN_F32 && out_dtype == SWIN_F32)
+        roi_align_ml_fwd_nhwc<float, float><<<ra_blocks(total), 256, 0, s>>>(F, rois, lvl, (float*)output, C, total, ph, pw, sampling_ratio, aligned);
+    else if (in_dtype == SWIN_BF16 && out_dtype == SWIN_F32)
+        roi_align_ml_fwd_nhwc<bf16, float><<<ra_blocks(total), 256, 0, s>>>(F, rois, lvl, (float*)output, C, total, ph, pw, sampling_ratio, aligned);
+    else if (in_dtype == SWIN_BF16 && out_dtype == SWIN_BF16)
+        roi_align_ml_fwd_nhwc<bf16, bf16><<<ra_blocks(total), 256, 0, s>>>(F, rois, lvl, (bf16*)output, C, total, ph, pw, sampling_ratio, aligned);
     else return SWIN_ERR_UNSUPPORTED;
     return swin_launch_status();
 }
 
 // grads[l]: (N, H[l], W[l], C) f32, zeroed by the caller; fp32 atomics.
 extern "C" int roi_align_multilevel_bwd(float* const* grads, const int* Hs, const int* Ws, const float* scales, int n_levels,
-                                        const float* grad_output, const float* rois, const int* lvl, int C, int K, int ph,
-                                        int pw, int sampling_ratio, int aligned, void* stream) {
+                                        const void* grad_output, const float* rois, const int* lvl, int C, int K, int ph,
+                                        int pw, int sampling_ratio, int aligned, int grad_dtype, void* stream) {
     if (K == 0) return SWIN_OK;
     if (!grads || !Hs || !Ws || !scales || !grad_output || !rois || !lvl || n_levels <= 0 || n_levels > 4 || C <= 0 || K < 0)
         return SWIN_ERR_BAD_ARG;
@@ -501,6 +511,11 @@ extern "C" int roi_align_multilevel_bwd(float* const* grads, const int* Hs, cons
         G.p[l] = grads[m]; G.H[l] = Hs[m]; G.W[l] = Ws[m]; G.scale[l] = scales[m];
         if (!G.p[l]) return SWIN_ERR_BAD_ARG;
     }
-    roi_align_ml_bwd_nhwc<<<dim3(K, ra_row_splits(K)), 256, 0, (hipStream_t)stream>>>(G, grad_output, rois, lvl, C, K, ph, pw, sampling_ratio, aligned);
+    const dim3 grid(K, ra_row_splits(K));
+    if (grad_dtype == SWIN_F32)
+        roi_align_ml_bwd_nhwc<float><<<grid, 256, 0, (hipStream_t)stream>>>(G, (const float*)grad_output, rois, lvl, C, K, ph, pw, sampling_ratio, aligned);
+    else if (grad_dtype == SWIN_BF16)
+        roi_align_ml_bwd_nhwc<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(G, (const bf16*)grad_output, rois, lvl, C, K, ph, pw, sampling_ratio, aligned);
+    else return SWIN_ERR_UNSUPPORTED;
     return swin_launch_status();
 }

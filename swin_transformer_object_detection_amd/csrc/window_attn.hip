@@ -60,23 +60,21 @@ __global__ void rel_bias_expand_kernel(const float* __restrict__ table, float* _
     out[i] = v;
 }
 
-__global__ void rel_bias_reduce_kernel(const float* __restrict__ dexp, float* __restrict__ dtable, int nH) {
-    // one thread per (idx, head): sum the (q,k) pairs that map to idx
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 169 * nH) return;
-    int h = i % nH, idx = i / nH;
-    int dh = idx / 13 - 6, dw = idx % 13 - 6;
-    float acc = 0.f;
-    for (int kh = 0; kh < 7; ++kh) {
-        int qh = kh + dh;
-        if (qh < 0 || qh >= 7) continue;
-        for (int kw = 0; kw < 7; ++kw) {
-            int qw = kw + dw;
-            if (qw < 0 || qw >= 7) continue;
-            acc += dexp[(h * TILE + kh * 7 + kw) * TILE + qh * 7 + qw];
-        }
+// one block per head: the 49 x 49 (query, key) gradients are scattered into a 169-entry LDS table (each entry collects
+// <= 49 pairs) and added to dtable.  (The first version gave each of the 169 x nH outputs one thread that walked its
+// <= 49 pairs serially: 13 us of dependent strided loads for 2 KB of output, twelve times per step.)
+__global__ __launch_bounds__(256) void rel_bias_reduce_kernel(const float* __restrict__ dexp, float* __restrict__ dtable, int nH) {
+    __shared__ float acc[169];
+    const int h = blockIdx.x, t = threadIdx.x;
+    if (t < 169) acc[t] = 0.f;
+    __syncthreads();
+    for (int i = t; i < NTOK * NTOK; i += 256) {
+        const int k = i / NTOK, q = i - k * NTOK;
+        const int qh = q / 7, qw = q % 7, kh = k / 7, kw = k % 7;
+        atomicAdd(&acc[(qh - kh + 6) * 13 + (qw - kw + 6)], dexp[(h * TILE + k) * TILE + q]);   // swin_transformer.py:105-110
     }
-    dtable[i] += acc;
+    __syncthreads();
+    if (t < 169) dtable[t * nH + h] += acc[t];
 }
 
 // ------------------------------------------------------------------------------------
@@ -936,8 +934,7 @@ extern "C" int swin_rel_bias_expand(const float* table, float* bias_exp, int nH,
 
 extern "C" int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int nH, void* stream) {
     if (!dbias_exp || !dtable || nH <= 0) return SWIN_ERR_BAD_ARG;
-    int n = 169 * nH;
-    rel_bias_reduce_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(dbias_exp, dtable, nH);
+    rel_bias_reduce_kernel<<<nH, 256, 0, (hipStream_t)stream>>>(dbias_exp, dtable, nH);
     return swin_launch_status();
 }
 

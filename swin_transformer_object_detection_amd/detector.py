@@ -491,7 +491,7 @@ class SingleRoIExtractor(nn.Module):
                 lvls = torch.where(valid, lvls, torch.full_like(lvls, -1))
             rl = self.roi_layers[0]
             return ops.roi_align_multilevel(list(feats), rois, lvls, out_size, self.featmap_strides[:num_levels],
-                                            rl.sampling_ratio, rl.aligned)
+                                            rl.sampling_ratio, rl.aligned, out_dtype=f0.dtype)   # bf16 in -> bf16 out: no cast pass
         cl = feats[0].is_contiguous(memory_format=torch.channels_last) and not feats[0].is_contiguous()
         roi_feats = torch.empty((rois.size(0), self.out_channels, *out_size), device=rois.device, dtype=torch.float32,
                                 memory_format=torch.channels_last if cl else torch.contiguous_format).zero_()

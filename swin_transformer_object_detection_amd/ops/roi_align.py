@@ -94,7 +94,7 @@ class _RoIAlignMultiLevelFn(torch.autograd.Function):
     """All pyramid levels in one launch (fwd) / one launch (bwd); see csrc/roi_align.hip."""
 
     @staticmethod
-    def forward(ctx, rois, lvls, output_size, strides, sampling_ratio, aligned, *feats):
+    def forward(ctx, rois, lvls, output_size, strides, sampling_ratio, aligned, out_dtype, *feats):
         import ctypes
         n = len(feats)
         assert 1 <= n <= 4
@@ -108,14 +108,16 @@ class _RoIAlignMultiLevelFn(torch.autograd.Function):
         lvls = lvls.to(torch.int32).contiguous()
         K = rois.shape[0]
         ph, pw = output_size
-        out = torch.empty((K, C, ph, pw), device=f0.device, dtype=torch.float32, memory_format=torch.channels_last)
+        if out_dtype is None or f0.dtype == torch.float32:
+            out_dtype = torch.float32
+        out = torch.empty((K, C, ph, pw), device=f0.device, dtype=out_dtype, memory_format=torch.channels_last)
         ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
         Hs = (ctypes.c_int * n)(*[f.shape[2] for f in feats])
         Ws = (ctypes.c_int * n)(*[f.shape[3] for f in feats])
         sc = (ctypes.c_float * n)(*[1.0 / s for s in strides])
         if K > 0:
             call("roi_align_multilevel_fwd", ptrs, Hs, Ws, sc, n, _p(rois), _p(lvls), _p(out), C, K, ph, pw,
-                 int(sampling_ratio), int(bool(aligned)), dt, _s())
+                 int(sampling_ratio), int(bool(aligned)), dt, SWIN_F32 if out_dtype == torch.float32 else SWIN_BF16, _s())
         ctx.save_for_backward(rois, lvls)
         ctx.cfg = (n, C, K, ph, pw, tuple(strides), int(sampling_ratio), int(bool(aligned)),
                    [tuple(f.shape) for f in feats], f0.dtype)
@@ -131,18 +133,22 @@ class _RoIAlignMultiLevelFn(torch.autograd.Function):
         flat = torch.zeros(sum(sizes), device=gout.device, dtype=torch.float32)
         offs = [sum(sizes[:i]) for i in range(n)]
         if K > 0:
-            gout = gout.float().contiguous(memory_format=torch.channels_last)
+            if gout.dtype not in (torch.float32, torch.bfloat16):
+                gout = gout.float()
+            gout = gout.contiguous(memory_format=torch.channels_last)
             ptrs = (ctypes.c_void_p * n)(*[flat.data_ptr() + 4 * o for o in offs])
             Hs = (ctypes.c_int * n)(*[s[2] for s in shapes])
             Ws = (ctypes.c_int * n)(*[s[3] for s in shapes])
             sc = (ctypes.c_float * n)(*[1.0 / s for s in strides])
-            call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, n, _p(gout), _p(rois), _p(lvls), C, K, ph, pw, sr, aligned, _s())
+            call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, n, _p(gout), _p(rois), _p(lvls), C, K, ph, pw, sr, aligned,
+                 SWIN_F32 if gout.dtype == torch.float32 else SWIN_BF16, _s())
         flat = flat.to(in_dtype)
         grads = tuple(flat[o:o + m].view(s[0], s[2], s[3], s[1]).permute(0, 3, 1, 2) for o, m, s in zip(offs, sizes, shapes))
-        return (None, None, None, None, None, None) + grads
+        return (None, None, None, None, None, None, None) + grads
 
 
-def roi_align_multilevel(feats, rois, lvls, output_size, strides, sampling_ratio=0, aligned=True):
+def roi_align_multilevel(feats, rois, lvls, output_size, strides, sampling_ratio=0, aligned=True, out_dtype=None):
     """feats: list of (N,C,H_l,W_l) channels-last maps; rois (K,5); lvls (K,) level per RoI (< 0: skip, zero row).
-    -> (K, C, ph, pw) float32 (channels-last).  Same arithmetic as RoIAlign level by level."""
-    return _RoIAlignMultiLevelFn.apply(rois, lvls, _pair(output_size), tuple(strides), sampling_ratio, aligned, *feats)
+    -> (K, C, ph, pw) float32 (channels-last), or ``out_dtype`` = bfloat16 for bf16 features (the fp32 result rounded
+    once, what the bf16 heads would do with a separate cast).  Same arithmetic as RoIAlign level by level."""
+    return _RoIAlignMultiLevelFn.apply(rois, lvls, _pair(output_size), tuple(strides), sampling_ratio, aligned, out_dtype, *feats)

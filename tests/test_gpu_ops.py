@@ -450,11 +450,23 @@ def test_roi_align_multilevel(ops, dtype, out_size):
         sel = np.nonzero(lvls == l)[0]
         ref[sel] = D.roi_align_c(feats_np[l], rois[sel], out_size, 1.0 / strides[l], 0, True)
     close(out, torch.from_numpy(ref), ATOL32)
+    if dtype == torch.bfloat16:      # bf16 output option: the fp32 result rounded once; bf16 gradient in
+        ob = ops.roi_align_multilevel([f.detach() for f in feats], torch.from_numpy(rois).cuda(), torch.from_numpy(lvls).cuda(),
+                                      out_size, strides, 0, True, out_dtype=torch.bfloat16)
+        assert ob.dtype == torch.bfloat16 and torch.equal(ob, out.detach().bfloat16())
     gy = rng.randn(*ref.shape).astype(np.float32)
+    if dtype == torch.bfloat16:
+        gy = torch.from_numpy(gy).bfloat16().float().numpy()
+        f2 = [f.detach().clone().requires_grad_(True) for f in feats]
+        o2 = ops.roi_align_multilevel(f2, torch.from_numpy(rois).cuda(), torch.from_numpy(lvls).cuda(), out_size, strides, 0, True,
+                                      out_dtype=torch.bfloat16)
+        (o2.float() * torch.from_numpy(gy).cuda()).sum().backward()          # gradient reaches the op in bf16
     (out * torch.from_numpy(gy).cuda()).sum().backward()
     for l in range(4):
         sel = np.nonzero(lvls == l)[0]
         gref = D.roi_align_bwd_c(gy[sel], rois[sel], feats_np[l].shape, 1.0 / strides[l], 0, True)
+        if dtype == torch.bfloat16:
+            close(f2[l].grad.float(), torch.from_numpy(gref).float(), 2e-4, 2.0 ** -8)
         assert feats[l].grad is not None and feats[l].grad.dtype == dtype
         if dtype == torch.float32:
             close(feats[l].grad, torch.from_numpy(gref).float(), 2e-4, 1e-4)

@@ -212,7 +212,7 @@ def roiml():
         ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in grads])
         Hs = (ctypes.c_int * 4)(*[t.shape[2] for t in grads]); Ws = (ctypes.c_int * 4)(*[t.shape[3] for t in grads])
         sc = (ctypes.c_float * 4)(0.25, 0.125, 0.0625, 0.03125)
-        medb, _ = timeit(lambda: Fn.call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, 4, Fn._p(g), Fn._p(rois), Fn._p(lv), 256, K, out, out, 0, 1, Fn._s()), n=10)
+        medb, _ = timeit(lambda: Fn.call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, 4, Fn._p(g), Fn._p(rois), Fn._p(lv), 256, K, out, out, 0, 1, 0, Fn._s()), n=10)
         print(f"roi_align_multilevel K={K} out={out}: fwd {med:7.1f} us  bwd {medb:7.1f} us  levels {torch.bincount(lv, minlength=4).tolist()}")
 
 
