@@ -210,6 +210,12 @@ int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int of
                uint8_t* keep_flags, int32_t* num_kept, int32_t* kept_pos, int kept_cap, void* workspace,
                void* stream);
 
+/* nms_sorted for `batch` images of the same n in one pair of launches (leading batch dimension on every buffer;
+ * workspace batch * swin_nms_workspace_bytes(n)): the per-image single-workgroup reductions run concurrently. */
+int nms_sorted_batch(const float* boxes_sorted, int batch, int64_t n, float iou_threshold, int offset, int max_num,
+                     uint8_t* keep_flags, int32_t* num_kept, int32_t* kept_pos, int kept_cap, void* workspace,
+                     void* stream);
+
 /* ---- training targets of the detector heads (csrc/det_targets.hip) --------------------------------------------
  * det_max_iou_assign replaces MaxIoUAssigner.assign (mmdet/core/bbox/assigners/max_iou_assigner.py:128-212 with
  * BboxOverlaps2D, iou2d_calculator.py) as called from anchor_head.py:215 and standard_roi_head.py:85:

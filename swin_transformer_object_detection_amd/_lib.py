@@ -38,6 +38,7 @@ SIGNATURES = {
     "wgrad_conv3x3_nhwc_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "swin_nms_workspace_bytes": [_i64],
     "nms_sorted": [_p, _i64, _f, _i, _i, _p, _p, _p, _i, _p, _p],
+    "nms_sorted_batch": [_p, _i, _i64, _f, _i, _i, _p, _p, _p, _i, _p, _p],
     "roi_align_multilevel_fwd": [_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "roi_align_multilevel_bwd": [_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "det_assign_workspace_bytes": [_i64, _i],

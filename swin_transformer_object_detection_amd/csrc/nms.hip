@@ -24,6 +24,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
                                                       uint64_t* __restrict__ mask, int col_blocks) {
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (cb < rb) return;
+    boxes += (int64_t)blockIdx.z * n;                                    // image of a batched call
+    mask += (int64_t)blockIdx.z * n * col_blocks;
     __shared__ float4 cbox[64];
     const int t = threadIdx.x;
     const int ncol = min(64, n - cb * 64);
@@ -49,6 +51,10 @@ __global__ __launch_bounds__(NMS_RT) void nms_reduce_kernel(const uint64_t* __re
                                                             uint8_t* __restrict__ keep, int32_t* __restrict__ num_kept,
                                                             int max_num, int32_t* __restrict__ kept_pos, int kept_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];   // col_blocks words
+    mask += (int64_t)blockIdx.x * n * col_blocks;                        // image of a batched call
+    keep += (int64_t)blockIdx.x * n;
+    num_kept += blockIdx.x;
+    if (kept_pos) kept_pos += (int64_t)blockIdx.x * kept_cap;
     __shared__ uint64_t kept_bits;
     __shared__ int kept_rows[64];
     __shared__ int kept_cnt, total;
@@ -136,5 +142,24 @@ extern "C" int nms_sorted(const float* boxes_sorted, int64_t n, float iou_thresh
                                         (uint64_t*)workspace, col_blocks);
     nms_reduce_kernel<<<1, NMS_RT, (size_t)col_blocks * 8, s>>>((const uint64_t*)workspace, (int)n, col_blocks, keep_flags,
                                                             num_kept, max_num, kept_pos, kept_cap);
+    return swin_launch_status();
+}
+
+// Batched form for fixed-size proposal lists: `batch` images with the SAME n, all buffers with a leading batch
+// dimension (boxes (batch,n,4), keep_flags (batch,n), num_kept (batch), kept_pos (batch,kept_cap), workspace
+// batch * swin_nms_workspace_bytes(n)).  One pair of launches for all images: the single-workgroup reductions of the
+// images run side by side on different CUs instead of back to back.
+extern "C" int nms_sorted_batch(const float* boxes_sorted, int batch, int64_t n, float iou_threshold, int offset, int max_num,
+                                uint8_t* keep_flags, int32_t* num_kept, int32_t* kept_pos, int kept_cap, void* workspace,
+                                void* stream) {
+    if (batch <= 0 || n <= 0 || !boxes_sorted || !keep_flags || !num_kept || !workspace) return SWIN_ERR_BAD_ARG;
+    int col_blocks = (int)((n + 63) / 64);
+    if (col_blocks > 65535 || (size_t)col_blocks * 8 > 60000 || batch > 65535) return SWIN_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(col_blocks, col_blocks, batch);
+    nms_mask_kernel<<<grid, 64, 0, s>>>((const float4*)boxes_sorted, (int)n, iou_threshold, (float)offset, (uint64_t*)workspace,
+                                        col_blocks);
+    nms_reduce_kernel<<<batch, NMS_RT, (size_t)col_blocks * 8, s>>>((const uint64_t*)workspace, (int)n, col_blocks, keep_flags,
+                                                                   num_kept, max_num, kept_pos, kept_cap);
     return swin_launch_status();
 }

@@ -431,6 +431,14 @@ class RPNHead(nn.Module):
         scores, deltas = torch.cat(sc_l, 1), torch.cat(bp_l, 1)
         anchors, ids = torch.cat(an_l, 1), torch.cat(id_l, 1)
         out = []
+        if (static and anchors.is_cuda and cfg.get('min_bbox_size', 0) <= 0 and anchors.size(1) < cfg['nms'].get('split_thr', 10000)
+                and all(tuple(sh[:2]) == tuple(img_shapes[0][:2]) for sh in img_shapes)):
+            # all images at once: one decode, one sort, one pair of NMS launches (the per-image reductions run side by side)
+            n = anchors.size(1)
+            props = ops.delta2bbox(anchors.reshape(B * n, 4), deltas.reshape(B * n, 4), self.means, self.stds,
+                                   max_shape=img_shapes[0]).view(B, n, 4)
+            dets, valid = ops.batched_nms_static_multi(props, scores, ids, cfg['nms']['iou_threshold'], cfg['max_per_img'])
+            return [(dets[i], valid[i]) for i in range(B)]
         for i in range(B):
             dec = ops.delta2bbox if anchors.is_cuda else delta2bbox
             props = dec(anchors[i], deltas[i], self.means, self.stds, max_shape=img_shapes[i])

@@ -113,3 +113,29 @@ def batched_nms_static(boxes, scores, idxs, iou_threshold, max_num):
     inds, valid = nms_static(boxes + offsets[:, None], scores, iou_threshold, max_num)
     dets = torch.cat([boxes[inds], scores[inds, None]], -1)
     return torch.where(valid[:, None], dets, torch.zeros_like(dets)), valid
+
+
+def batched_nms_static_multi(boxes, scores, idxs, iou_threshold, max_num):
+    """batched_nms_static for a BATCH of images with the same candidate count, in one set of launches:
+    boxes (B,n,4), scores (B,n), idxs (B,n) -> (dets (B,max_num,5), valid (B,max_num)).  Per image identical to
+    batched_nms_static (same per-image coordinate offset, stable descending sort, greedy suppression)."""
+    if not boxes.is_cuda:
+        raise SwinHipError("nms: HIP path needs GPU tensors (no CPU fallback)")
+    boxes, scores = boxes.float(), scores.float()
+    B, n = scores.shape
+    if n == 0:
+        return boxes.new_zeros((B, max_num, 5)), torch.zeros((B, max_num), dtype=torch.bool, device=boxes.device)
+    max_coordinate = boxes.amax(dim=(1, 2))                                        # per image, as one call per image would
+    offsets = idxs.to(boxes) * (max_coordinate + 1.0)[:, None]
+    order = torch.sort(scores, dim=1, descending=True, stable=True)[1]
+    bs = torch.gather(boxes + offsets[..., None], 1, order[..., None].expand(B, n, 4)).contiguous()
+    ws = torch.empty(B * lib().swin_nms_workspace_bytes(n), dtype=torch.uint8, device=boxes.device)
+    flags = torch.empty((B, n), dtype=torch.uint8, device=boxes.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=boxes.device)
+    pos = torch.empty((B, max_num), dtype=torch.int32, device=boxes.device)
+    call("nms_sorted_batch", _p(bs), B, n, float(iou_threshold), 0, int(max_num), _p(flags), _p(cnt), _p(pos), int(max_num), _p(ws),
+         _s())
+    valid = pos >= 0
+    inds = torch.gather(order, 1, pos.clamp(min=0).long())
+    dets = torch.cat([torch.gather(boxes, 1, inds[..., None].expand(B, max_num, 4)), torch.gather(scores, 1, inds)[..., None]], -1)
+    return torch.where(valid[..., None], dets, torch.zeros_like(dets)), valid

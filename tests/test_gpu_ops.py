@@ -725,3 +725,18 @@ def test_bbox_and_mask_loss_kernels(ops, dtype):
     (olm * 3).backward()
     close(olm, lm.detach(), 1e-5, 1e-5)
     close(p1.grad.float(), p0.grad, rel * float(p0.grad.abs().max()) + 1e-9, rel)
+
+
+def test_batched_nms_static_multi_equals_per_image(ops):
+    """All images in one set of launches == batched_nms_static image by image (which is checked against the oracle)."""
+    rng = np.random.RandomState(44)
+    B, n, m = 3, 2500, 600
+    xy = rng.rand(B, n, 2).astype(np.float32) * 500
+    boxes = torch.from_numpy(np.concatenate([xy, xy + rng.rand(B, n, 2).astype(np.float32) * 90 + 1], 2)).cuda()
+    scores = torch.from_numpy(rng.rand(B, n).astype(np.float32)).cuda()
+    idxs = torch.from_numpy(rng.randint(0, 5, (B, n))).cuda()
+    dets, valid = ops.batched_nms_static_multi(boxes, scores, idxs, 0.7, m)
+    assert dets.shape == (B, m, 5) and valid.shape == (B, m)
+    for i in range(B):
+        d1, v1 = ops.batched_nms_static(boxes[i], scores[i], idxs[i], 0.7, m)
+        assert torch.equal(valid[i], v1) and torch.equal(dets[i], d1)
