@@ -743,15 +743,29 @@ class StandardRoIHead(nn.Module):
             mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois, valid=mvalid)
             mask_pred = self.mask_head(mask_feats)
             size = cfg.get('mask_size', 28)
-            tg = []
-            for i in range(nimg):                                                 # mask_target.py:66-122, on device
-                if m_roi[i].size(0) == 0 or gt_masks[i].size(0) == 0:
-                    tg.append(m_roi[i].new_zeros((m_roi[i].size(0), size, size)))
-                    continue
-                m = gt_masks[i].to(torch.bfloat16)[:, None].contiguous()          # 0/1 exact in bf16
-                r = torch.cat([m_gt[i].to(m_roi[i].dtype)[:, None], m_roi[i]], 1)
+            # mask_target.py:66-122 on the device.  When every image has gt masks of one size, all images go through ONE
+            # RoIAlign launch (the gt masks stacked along the batch axis, the RoI's batch index offset by its image's
+            # first mask): the per-image launches are latency-bound and would run back to back.
+            same = (all(g_.size(0) > 0 for g_ in gt_masks) and all(r_.size(0) > 0 for r_ in m_roi)
+                    and all(g_.shape[1:] == gt_masks[0].shape[1:] for g_ in gt_masks))
+            if same:
+                m = torch.cat(list(gt_masks), 0).to(torch.bfloat16)[:, None]      # 0/1 exact in bf16
+                offs, o_ = [], 0
+                for g_ in gt_masks:
+                    offs.append(o_); o_ += g_.size(0)
+                r = torch.cat([torch.cat([(m_gt[i] + offs[i]).to(m_roi[i].dtype)[:, None], m_roi[i]], 1) for i in range(nimg)], 0)
                 t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)        # structures.py:353-354
-                tg.append((t[:, 0] >= 0.5).float())
+                tg = [(t[:, 0] >= 0.5).float()]
+            else:
+                tg = []
+                for i in range(nimg):
+                    if m_roi[i].size(0) == 0 or gt_masks[i].size(0) == 0:
+                        tg.append(m_roi[i].new_zeros((m_roi[i].size(0), size, size)))
+                        continue
+                    m = gt_masks[i].to(torch.bfloat16)[:, None].contiguous()
+                    r = torch.cat([m_gt[i].to(m_roi[i].dtype)[:, None], m_roi[i]], 1)
+                    t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)
+                    tg.append((t[:, 0] >= 0.5).float())
             losses.update(self.mask_head.loss(mask_pred, torch.cat(tg), torch.cat(m_lab), mvalid))
         return losses
 
