@@ -300,6 +300,14 @@ int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, const flo
 int swin_block_fwd(const void* const* p, const int64_t* iv, const float* fv, void* stream);
 int swin_block_bwd(const void* const* p, const int64_t* iv, const float* fv, void* stream);
 
+/* det_rpn_flatten_*: per-level fused RPN head outputs (B, hw[l], CH) [A cls | 4A deltas | pad] <-> the anchor-major
+ * concatenation over levels cls_all (B, sum hw*A), reg_all (B, sum hw*A, 4) that AnchorHead.loss (anchor_head.py:474-486)
+ * and RPNHead._get_bboxes (rpn_head.py:119-125) consume; one kernel each way.  ys / dys: HOST arrays of device pointers. */
+int det_rpn_flatten_fwd(const void* const* ys, const int* hw, int L, int B, int A, int CH, void* cls_all, void* reg_all,
+                        int dtype, void* stream);
+int det_rpn_flatten_bwd(void* const* dys, const int* hw, int L, int B, int A, int CH, const void* dcls_all,
+                        const void* dreg_all, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

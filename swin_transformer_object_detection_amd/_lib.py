@@ -59,6 +59,8 @@ SIGNATURES = {
     "det_bbox_loss_bwd": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "det_mask_loss_fwd": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "det_mask_loss_bwd": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
+    "det_rpn_flatten_fwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
+    "det_rpn_flatten_bwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
     "det_paste_masks": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p],
 }
 _RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_gemm_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,

@@ -193,6 +193,41 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const T* __restrict_
         Elt<T>::st(dpred + base + k, (sigmoidf(Elt<T>::ld(pred + base + k)) - t[k]) * g);
 }
 
+// ------------------------------------------------------------------------------------------------ RPN flatten
+// The fused RPN head GEMM yields, per level, (B, HW, CH) rows [A cls logits | 4A deltas | padding] (CH = 5A rounded up
+// to 8).  loss() and get_bboxes() want the anchor-major concatenation over levels: cls_all (B, sum HW*A) and
+// reg_all (B, sum HW*A, 4) (anchor_head.py:474-486, rpn_head.py:119-125).  With torch this is 10 strided slice copies
+// + 2 concatenations forward and 10 zero fills + 10 strided copies + 5 adds backward; here one kernel each way.
+struct FlatLevels { const void* y[8]; void* dy[8]; int hw[8]; int off[8]; int L; };
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void rpn_flatten_kernel(FlatLevels F, int B, int A, int CH, int64_t total_anchors,
+                                                          T* __restrict__ cls_all, T* __restrict__ reg_all, int64_t total) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;        // over (b, level token, channel)
+    if (id >= total) return;
+    const int ch = (int)(id % CH);
+    int64_t tok = id / CH;                                               // b * sum_hw + (level offset + hw)
+    int sum_hw = F.off[F.L - 1] + F.hw[F.L - 1];
+    const int b = (int)(tok / sum_hw);
+    const int g = (int)(tok - (int64_t)b * sum_hw);
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) if (q < F.L && g >= F.off[q]) l = q;
+    const int hw = g - F.off[l];
+    const int64_t src = ((int64_t)b * F.hw[l] + hw) * CH + ch;
+    const int64_t anchor0 = (int64_t)b * total_anchors + ((int64_t)F.off[l] + hw) * A;
+    if (!BWD) {
+        const T v = ((const T*)F.y[l])[src];
+        if (ch < A) cls_all[anchor0 + ch] = v;
+        else if (ch < 5 * A) reg_all[anchor0 * 4 + (ch - A)] = v;
+    } else {
+        T v = (T)0.f;
+        if (ch < A) v = cls_all[anchor0 + ch];
+        else if (ch < 5 * A) v = reg_all[anchor0 * 4 + (ch - A)];
+        ((T*)F.dy[l])[src] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
     if ((dtype) == SWIN_F32) { CALL_F32; } else if ((dtype) == SWIN_BF16) { CALL_BF16; } else return SWIN_ERR_UNSUPPORTED;
@@ -263,4 +298,45 @@ extern "C" int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P
     DISPATCH_T(dtype, (mask_loss_bwd_kernel<float><<<n, 256, 0, s>>>((const float*)pred, n, num_classes, P, target, labels, valid, out2, grad_out, (float*)dpred)),
                (mask_loss_bwd_kernel<bf16><<<n, 256, 0, s>>>((const bf16*)pred, n, num_classes, P, target, labels, valid, out2, grad_out, (bf16*)dpred)))
     return swin_launch_status();
+}
+
+static int rpn_flatten_launch(const void* const* ys, void* const* dys, const int* hw, int L, int B, int A, int CH, void* cls_all,
+                              void* reg_all, int dtype, bool bwd, void* stream) {
+    if (!hw || L <= 0 || L > 8 || B <= 0 || A <= 0 || CH < 5 * A || !cls_all || !reg_all || (!bwd && !ys) || (bwd && !dys))
+        return SWIN_ERR_BAD_ARG;
+    FlatLevels F;
+    int off = 0;
+    for (int l = 0; l < 8; ++l) {
+        F.y[l] = (!bwd && l < L) ? ys[l] : nullptr;
+        F.dy[l] = (bwd && l < L) ? dys[l] : nullptr;
+        F.hw[l] = l < L ? hw[l] : 0;
+        F.off[l] = off;
+        if (l < L) { if (hw[l] <= 0 || (!bwd && !ys[l]) || (bwd && !dys[l])) return SWIN_ERR_BAD_ARG; off += hw[l]; }
+    }
+    F.L = L;
+    const int64_t total = (int64_t)B * off * CH, total_anchors = (int64_t)off * A;
+    const int blocks = (int)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SWIN_F32) {
+        if (bwd) rpn_flatten_kernel<float, true><<<blocks, 256, 0, s>>>(F, B, A, CH, total_anchors, (float*)cls_all, (float*)reg_all, total);
+        else rpn_flatten_kernel<float, false><<<blocks, 256, 0, s>>>(F, B, A, CH, total_anchors, (float*)cls_all, (float*)reg_all, total);
+    } else if (dtype == SWIN_BF16) {
+        if (bwd) rpn_flatten_kernel<bf16, true><<<blocks, 256, 0, s>>>(F, B, A, CH, total_anchors, (bf16*)cls_all, (bf16*)reg_all, total);
+        else rpn_flatten_kernel<bf16, false><<<blocks, 256, 0, s>>>(F, B, A, CH, total_anchors, (bf16*)cls_all, (bf16*)reg_all, total);
+    } else return SWIN_ERR_UNSUPPORTED;
+    return swin_launch_status();
+}
+
+// ys: HOST array of L (<= 8) device pointers to the per-level (B, hw[l], CH) head outputs; cls_all (B, sum hw*A),
+// reg_all (B, sum hw*A, 4) out.
+extern "C" int det_rpn_flatten_fwd(const void* const* ys, const int* hw, int L, int B, int A, int CH, void* cls_all, void* reg_all,
+                                   int dtype, void* stream) {
+    return rpn_flatten_launch(ys, nullptr, hw, L, B, A, CH, cls_all, reg_all, dtype, false, stream);
+}
+
+// dys: HOST array of L device pointers, fully written (padding channels zero); dcls_all / dreg_all in.
+extern "C" int det_rpn_flatten_bwd(void* const* dys, const int* hw, int L, int B, int A, int CH, const void* dcls_all,
+                                   const void* dreg_all, int dtype, void* stream) {
+    return rpn_flatten_launch(nullptr, dys, hw, L, B, A, CH, const_cast<void*>(dcls_all), const_cast<void*>(dreg_all), dtype, true,
+                              stream);
 }

@@ -358,8 +358,11 @@ class RPNHead(nn.Module):
             # the anchor-major flattening that loss() and get_bboxes() need (anchor_head.py:474-486, rpn_head.py:119-125):
             # one strided concatenation per head straight from the token-major GEMM outputs
             N = ys[0].size(0)
-            self._flat = (cls, torch.cat([y[:, :, :A] for y in ys], 1).reshape(N, -1),
-                          torch.cat([y[:, :, A:5 * A] for y in ys], 1).reshape(N, -1, 4))
+            if ys[0].is_cuda:
+                self._flat = (cls,) + tuple(ops.rpn_flatten(ys, A))             # one kernel each way (det_rpn_flatten_*)
+            else:
+                self._flat = (cls, torch.cat([y[:, :, :A] for y in ys], 1).reshape(N, -1),
+                              torch.cat([y[:, :, A:5 * A] for y in ys], 1).reshape(N, -1, 4))
         return cls, reg
 
     def _flattened(self, cls_scores, bbox_preds):

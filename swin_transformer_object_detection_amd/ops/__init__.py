@@ -10,4 +10,4 @@ from .nms import batched_nms, batched_nms_static, batched_nms_static_multi, nms,
 from .roi_align import RoIAlign, roi_align, roi_align_multilevel  # noqa: F401
 from .targets import (bbox_targets, delta2bbox, max_iou_assign, paste_masks, random_sample,  # noqa: F401
                       random_sample_raw)
-from .losses import bbox_loss, mask_loss, rpn_loss  # noqa: F401
+from .losses import bbox_loss, mask_loss, rpn_flatten, rpn_loss  # noqa: F401

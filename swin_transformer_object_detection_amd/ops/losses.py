@@ -3,6 +3,8 @@ launch each, over the fixed-size samples produced by ops.random_sample_raw / ops
 
 Reference arithmetic: AnchorHead.loss_single (anchor_head.py:375-434), BBoxHead.loss (bbox_head.py:188-238),
 FCNMaskHead.loss -> mask_cross_entropy (losses/cross_entropy_loss.py)."""
+import ctypes
+
 import torch
 
 from .._lib import SWIN_BF16, SWIN_F32, SwinHipError, call
@@ -104,3 +106,39 @@ class _MaskLoss(torch.autograd.Function):
 def mask_loss(mask_pred, mask_targets, labels, valid):
     """mean sigmoid-BCE of the labelled class channel over the valid RoIs (mask_cross_entropy, reduction 'mean')."""
     return _MaskLoss.apply(mask_pred, mask_targets.contiguous().float(), labels.contiguous(), valid.to(torch.uint8).contiguous())
+
+
+class _RPNFlatten(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, *ys):
+        ys = [y.contiguous() for y in ys]
+        B, CH = ys[0].shape[0], ys[0].shape[2]
+        L = len(ys)
+        hw = [y.shape[1] for y in ys]
+        tot = sum(hw) * A
+        cls_all = torch.empty((B, tot), device=ys[0].device, dtype=ys[0].dtype)
+        reg_all = torch.empty((B, tot, 4), device=ys[0].device, dtype=ys[0].dtype)
+        ptrs = (ctypes.c_void_p * L)(*[y.data_ptr() for y in ys])
+        hws = (ctypes.c_int * L)(*hw)
+        call("det_rpn_flatten_fwd", ptrs, hws, L, B, A, CH, _p(cls_all), _p(reg_all), _dt(ys[0]), _s())
+        ctx.meta = (A, B, CH, hw, ys[0].dtype, ys[0].device)
+        return cls_all, reg_all
+
+    @staticmethod
+    def backward(ctx, dcls, dreg):
+        A, B, CH, hw, dtype, dev = ctx.meta
+        L = len(hw)
+        tot = sum(hw) * A
+        dcls = torch.zeros((B, tot), device=dev, dtype=dtype) if dcls is None else dcls.contiguous()
+        dreg = torch.zeros((B, tot, 4), device=dev, dtype=dtype) if dreg is None else dreg.contiguous()
+        dys = [torch.empty((B, n, CH), device=dev, dtype=dtype) for n in hw]
+        ptrs = (ctypes.c_void_p * L)(*[d.data_ptr() for d in dys])
+        hws = (ctypes.c_int * L)(*hw)
+        call("det_rpn_flatten_bwd", ptrs, hws, L, B, A, CH, _p(dcls), _p(dreg), SWIN_F32 if dtype == torch.float32 else SWIN_BF16, _s())
+        return (None,) + tuple(dys)
+
+
+def rpn_flatten(ys, num_anchors):
+    """per-level fused RPN head outputs (B, HW_l, CH) -> (cls_all (B, sum HW_l*A), reg_all (B, sum HW_l*A, 4)),
+    anchors ordered (level, h, w, a) as anchor_head.py:474-486 flattens them."""
+    return _RPNFlatten.apply(int(num_anchors), *ys)

@@ -740,3 +740,23 @@ def test_batched_nms_static_multi_equals_per_image(ops):
     for i in range(B):
         d1, v1 = ops.batched_nms_static(boxes[i], scores[i], idxs[i], 0.7, m)
         assert torch.equal(valid[i], v1) and torch.equal(dets[i], d1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rpn_flatten_kernel(ops, dtype):
+    """det_rpn_flatten == slicing + concatenating the per-level head outputs with torch (anchor_head.py:474-486 order),
+    values and gradients (pure data movement: exact)."""
+    g = torch.Generator().manual_seed(9)
+    B, A, CH = 2, 3, 16
+    hws = [40 * 64, 20 * 32, 10 * 16, 5 * 8, 3 * 4]
+    ys = [torch.randn(B, n, CH, generator=g).to(dtype).cuda().requires_grad_(True) for n in hws]
+    ys2 = [y.detach().clone().requires_grad_(True) for y in ys]
+    cls_ref = torch.cat([y[:, :, :A] for y in ys2], 1).reshape(B, -1)
+    reg_ref = torch.cat([y[:, :, A:5 * A] for y in ys2], 1).reshape(B, -1, 4)
+    cls, reg = ops.rpn_flatten(ys, A)
+    assert torch.equal(cls, cls_ref) and torch.equal(reg, reg_ref)
+    wc, wr = torch.randn_like(cls_ref), torch.randn_like(reg_ref)
+    ((cls_ref * wc).sum() + (reg_ref * wr).sum()).backward()
+    ((cls * wc).sum() + (reg * wr).sum()).backward()
+    for a, b in zip(ys, ys2):
+        assert torch.equal(a.grad, b.grad)
