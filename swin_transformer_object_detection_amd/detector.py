@@ -424,9 +424,14 @@ class RPNHead(nn.Module):
             off += na
             an = mlvl_anchors[lvl][None].expand(B, -1, -1)
             if s.shape[1] > nms_pre:
-                ranked, rank_inds = s.sort(dim=1, descending=True, stable=True)
-                topk = rank_inds[:, :nms_pre]
-                s = ranked[:, :nms_pre]
+                if static and s.is_cuda:
+                    # only the SET of the nms_pre best anchors matters here: the NMS below orders all levels' candidates
+                    # by score itself.  A radix select (one kernel) instead of a full segmented sort (~15 kernels).
+                    s, topk = s.topk(nms_pre, dim=1, sorted=False)
+                else:
+                    ranked, rank_inds = s.sort(dim=1, descending=True, stable=True)
+                    topk = rank_inds[:, :nms_pre]
+                    s = ranked[:, :nms_pre]
                 d = torch.gather(d, 1, topk[..., None].expand(-1, -1, 4))
                 an = torch.gather(an, 1, topk[..., None].expand(-1, -1, 4))
             sc_l.append(s); bp_l.append(d); an_l.append(an)
