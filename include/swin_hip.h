@@ -246,9 +246,11 @@ int det_delta2bbox(const float* rois, const float* deltas, int64_t n, const floa
 
 /* det_paste_masks: test-time FCNMaskHead.get_seg_masks / _do_paste_mask (fcn_mask_head.py:169-300, :303-377):
  *   mask_logits (N, num_classes, mh, mw) f32|bf16, labels (N) i64, boxes (N,4) f32 in output-image coordinates ->
- *   out (N, img_h, img_w) u8 = (bilinear resample of sigmoid(logits[n, labels[n]]) into the box) >= thr. */
+ *   out (N, img_h, img_w) u8 = (bilinear resample of sigmoid(logits[n, labels[n]]) into the box) >= thr.  is_prob != 0:
+ *   the input already holds probabilities (CascadeRoIHead averages the stages' sigmoid masks, cascade_roi_head.py:383-396). */
 int det_paste_masks(const void* mask_logits, const int64_t* labels, const float* boxes, int N, int num_classes,
-                    int mh, int mw, int img_h, int img_w, float thr, int in_dtype, uint8_t* out, void* stream);
+                    int mh, int mw, int img_h, int img_w, float thr, int is_prob, int in_dtype, uint8_t* out,
+                    void* stream);
 
 /* swin_adamw_step: AdamW over all parameters in ONE launch (+ the bf16 operand copy of the GEMM/conv weights).
  * Replaces torch.optim.AdamW.step as configured by configs/swin/*_coco.py:64-67 and the master->half copy of apex O1
@@ -269,25 +271,31 @@ int swin_gemm_bf16(const void* a, const void* b, const void* bias, void* c, int6
                    void* workspace, void* stream);
 
 /* ---- loss kernels of the detector heads (csrc/det_losses.hip): value + input gradients, fixed-size samples ----------
- * det_rpn_loss_*:  AnchorHead.loss_single (anchor_head.py:375-434): sigmoid CE over the sampled anchors + L1 on the
- *   positives, divided by the batch's sample count.  cls (B,A), reg (B,A,4) f32|bf16; inds/flags (B*S) from
+ * det_rpn_loss_*:  AnchorHead.loss_single (anchor_head.py:375-434): sigmoid CE over the sampled anchors + L1 (beta 0) or
+ *   SmoothL1(beta) (smooth_l1_loss.py:10-28; the Cascade configs' RPN uses beta 1/9) on the positives, divided by the
+ *   batch's sample count.  cls (B,A), reg (B,A,4) f32|bf16; inds/flags (B*S) from
  *   det_random_sample, targets (B*S,4) from det_bbox_targets; out3 = {loss_cls, loss_bbox, n}.
- * det_bbox_loss_*: BBoxHead.loss (bbox_head.py:188-238): softmax CE, accuracy, class-specific L1; out4 = {loss_cls,
- *   acc %, loss_bbox, n_valid}.
+ * det_bbox_loss_*: BBoxHead.loss (bbox_head.py:188-238): softmax CE, accuracy, regression on the positives; out4 =
+ *   {loss_cls, acc %, loss_bbox, n_valid}.  bbox is (n, 4 nc), or (n, 4) when class_agnostic.  reg_mode 0: L1 (beta 0) /
+ *   SmoothL1(beta) against encoded delta targets; reg_mode 2: reg_decoded_bbox=True with GIoULoss (iou_loss.py:78-101,
+ *   iou2d_calculator.py:108-158): the deltas are decoded against rois (n,4) with means/stds (HOST float[4]) and compared
+ *   with gt boxes in `targets`; eps is GIoULoss.eps.  rois/means/stds may be NULL in mode 0.
  * det_mask_loss_*: FCNMaskHead.loss / mask_cross_entropy (cross_entropy_loss.py): mean BCE of the labelled channel over
  *   the valid RoIs; out2 = {loss, n_valid}.
  * Backward entries take grad_out aligned with the forward's out array; dcls/dreg (rpn) and dpred (mask) must be zeroed
  * by the caller, dcls/dbbox (bbox) are fully written. */
 int det_rpn_loss_fwd(const void* cls, const void* reg, int B, int64_t A, int S, const int64_t* inds, const uint8_t* flags,
-                     const float* targets, float* out3, int dtype, void* stream);
+                     const float* targets, float beta, float* out3, int dtype, void* stream);
 int det_rpn_loss_bwd(const void* cls, const void* reg, int B, int64_t A, int S, const int64_t* inds, const uint8_t* flags,
-                     const float* targets, const float* out3, const float* grad_out, void* dcls, void* dreg, int dtype,
-                     void* stream);
+                     const float* targets, float beta, const float* out3, const float* grad_out, void* dcls, void* dreg,
+                     int dtype, void* stream);
 int det_bbox_loss_fwd(const void* cls, const void* bbox, int n, int num_classes, const int64_t* labels, const float* targets,
-                      const uint8_t* flags, float* out4, float* lse, int dtype, void* stream);
+                      const uint8_t* flags, int reg_mode, int class_agnostic, float beta, float eps, const float* rois,
+                      const float* means, const float* stds, float* out4, float* lse, int dtype, void* stream);
 int det_bbox_loss_bwd(const void* cls, const void* bbox, int n, int num_classes, const int64_t* labels, const float* targets,
-                      const uint8_t* flags, const float* out4, const float* lse, const float* grad_out, void* dcls,
-                      void* dbbox, int dtype, void* stream);
+                      const uint8_t* flags, int reg_mode, int class_agnostic, float beta, float eps, const float* rois,
+                      const float* means, const float* stds, const float* out4, const float* lse, const float* grad_out,
+                      void* dcls, void* dbbox, int dtype, void* stream);
 int det_mask_loss_fwd(const void* pred, int n, int num_classes, int P, const float* target, const int64_t* labels,
                       const uint8_t* valid, float* out2, float* per_roi, int dtype, void* stream);
 int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, const float* target, const int64_t* labels,
@@ -307,6 +315,33 @@ int det_rpn_flatten_fwd(const void* const* ys, const int* hw, int L, int B, int 
                         int dtype, void* stream);
 int det_rpn_flatten_bwd(void* const* dys, const int* hw, int L, int B, int A, int CH, const void* dcls_all,
                         const void* dreg_all, int dtype, void* stream);
+
+/* det_regress_by_class: BBoxHead.regress_by_class (bbox_head.py:409-436) as used between the stages of CascadeRoIHead
+ *   (cascade_roi_head.py:274-284 training, :316-323 testing): rois (n,4) f32; labels (n) i64 or NULL -- NULL, background
+ *   (== num_classes) or negative labels take argmax(cls[:, :num_classes]); cls (n, nc+1), bbox (n, 4 nc | 4) f32|bf16;
+ *   out (n,4) = decode(roi, deltas of the label) clipped to (max_h, max_w) when max_w > 0. */
+int det_regress_by_class(const float* rois, const int64_t* labels, const void* cls, const void* bbox, int64_t n,
+                         int num_classes, int class_agnostic, const float* means, const float* stds, float max_h,
+                         float max_w, float* out, int dtype, void* stream);
+
+/* ---- batch normalisation over channel-last rows (csrc/batchnorm.hip): the SyncBN of the Cascade configs' ConvFCBBoxHead
+ *   (convfc_bbox_head.py:99-107, norm_cfg=dict(type='SyncBN')); x (R, C) f32|bf16, C % (16 / elt size) == 0.
+ *   det_bn_stats: sums (2C+1) = {sum x, sum x^2 per channel, R}; the caller all-reduces sums over ranks for SyncBN.
+ *   det_bn_finalize: mean_invstd (2C) from sums; running_mean/var (C, may be NULL) updated with `momentum` (unbiased var).
+ *   det_bn_apply: y = (x - mean) * invstd * gamma + beta, ReLU when relu != 0.
+ *   det_bn_bwd_reduce: sums (2C) = {sum dy', sum dy' xhat} of this rank (= dbeta, dgamma), dy' = dy masked by the ReLU.
+ *   det_bn_bwd_apply: dx from the (all-reduced) sums and the global row count (DEVICE pointer to one float).
+ *   workspace: det_bn_workspace_bytes(C) bytes. */
+int64_t det_bn_workspace_bytes(int C);
+int det_bn_stats(const void* x, int64_t R, int C, float* sums, void* workspace, int dtype, void* stream);
+int det_bn_finalize(const float* sums, int C, float eps, float momentum, float* mean_invstd, float* running_mean,
+                    float* running_var, void* stream);
+int det_bn_apply(const void* x, void* y, int64_t R, int C, const float* mean_invstd, const float* gamma, const float* beta,
+                 int relu, int dtype, void* stream);
+int det_bn_bwd_reduce(const void* x, const void* dy, int64_t R, int C, const float* mean_invstd, const float* gamma,
+                      const float* beta, int relu, float* sums, void* workspace, int dtype, void* stream);
+int det_bn_bwd_apply(const void* x, const void* dy, void* dx, int64_t R, int C, const float* mean_invstd, const float* gamma,
+                     const float* beta, int relu, const float* sums, const float* count, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,9 @@ and cannot be imported here):
   roi_extract      .../single_level_roi_extractor.py:53-108
   multiclass_nms   mmdet/core/post_processing/bbox_nms.py:7-93
   bbox2roi         mmdet/core/bbox/transforms.py:69-77
+  smooth_l1 / giou_loss / bbox_head_loss   mmdet/models/losses/{smooth_l1_loss,iou_loss}.py, bbox_head.py:188-238
+  regress_by_class mmdet/models/roi_heads/bbox_heads/bbox_head.py:409-436 (+ cascade_roi_head.py:274-281)
+  batch_norm_train torch.nn.SyncBatchNorm arithmetic (norm layer of ConvFCBBoxHead, convfc_bbox_head.py:99-107)
 Pinned by the reference's own known-answer test for delta2bbox
 (tests/test_utils/test_coder.py:26-60, docstring example at
 delta_xywh_bbox_coder.py:172-182); the rest: PARITY UNPINNED (shape-only tests
@@ -200,10 +203,11 @@ def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0,
 
 
 # ---- test-time path (checker for detector.simple_test and csrc/mask_paste.hip) -----------------------------------
-def paste_masks(mask_logits, labels, boxes, img_h, img_w, thr=0.5):
+def paste_masks(mask_logits, labels, boxes, img_h, img_w, thr=0.5, is_prob=False):
     """FCNMaskHead.get_seg_masks + _do_paste_mask (mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:218-300, :303-377;
     GPU branch: whole image, skip_empty=False): sigmoid, class channel, F.grid_sample(bilinear, zeros padding,
-    align_corners=False) on the normalised grid of the box, `>= thr`.  -> (bool (N,img_h,img_w), float32 values)."""
+    align_corners=False) on the normalised grid of the box, `>= thr`.  -> (bool (N,img_h,img_w), float32 values).
+    is_prob: the input holds probabilities already (ndarray input of get_seg_masks, :209-213)."""
     m = np.asarray(mask_logits, np.float32)
     N, nc, mh, mw = m.shape
     boxes = np.asarray(boxes, np.float32).reshape(-1, 4)
@@ -211,7 +215,7 @@ def paste_masks(mask_logits, labels, boxes, img_h, img_w, thr=0.5):
     ys = np.arange(img_h, dtype=np.float32) + np.float32(0.5)
     xs = np.arange(img_w, dtype=np.float32) + np.float32(0.5)
     for n in range(N):
-        p = (np.float32(1) / (np.float32(1) + np.exp(-m[n, int(labels[n])]))).astype(np.float32)
+        p = m[n, int(labels[n])] if is_prob else (np.float32(1) / (np.float32(1) + np.exp(-m[n, int(labels[n])]))).astype(np.float32)
         x0, y0, x1, y1 = boxes[n]
         with np.errstate(divide='ignore', invalid='ignore'):
             gy = (ys - y0) / (y1 - y0) * np.float32(2) - np.float32(1)
@@ -247,6 +251,8 @@ def bbox_head_get_bboxes(rois, cls_score, bbox_pred, img_shape, scale_factor, re
                          means=(0., 0., 0., 0.), stds=(.1, .1, .2, .2)):
     """BBoxHead.get_bboxes (mmdet/models/roi_heads/bbox_heads/bbox_head.py:270-373) for one image, class-specific
     regression: softmax, per-class decode clipped to img_shape, optional division by scale_factor, multiclass_nms."""
+    if isinstance(cls_score, (list, tuple)):                       # bbox_head.py:300-301: per-stage scores are averaged
+        cls_score = sum(np.asarray(c, np.float32) for c in cls_score) / np.float32(len(cls_score))
     cls_score = np.asarray(cls_score, np.float32)
     e = np.exp(cls_score - cls_score.max(1, keepdims=True))
     scores = (e / e.sum(1, keepdims=True)).astype(np.float32)
@@ -258,3 +264,91 @@ def bbox_head_get_bboxes(rois, cls_score, bbox_pred, img_shape, scale_factor, re
     if rescale:
         boxes = (boxes.reshape(n, nc, 4) / np.asarray(scale_factor, np.float32)).reshape(n, nc * 4)
     return multiclass_nms(boxes, scores, score_thr, nms_cfg, max_per_img)
+
+
+# ---- Cascade R-CNN pieces (checkers for csrc/det_losses.hip regression modes, det_regress_by_class, csrc/batchnorm.hip) --
+def smooth_l1(diff, beta):
+    """losses/smooth_l1_loss.py:10-28 element (beta <= 0: plain L1, :31-45)."""
+    d = np.abs(np.asarray(diff, np.float64))
+    if beta <= 0:
+        return d
+    return np.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
+
+
+def giou_loss(pred, target, eps=1e-6):
+    """1 - GIoU per aligned box pair: losses/iou_loss.py:78-101 over bbox_overlaps(mode='giou', is_aligned=True)
+    (core/bbox/iou_calculators/iou2d_calculator.py:108-158).  float64."""
+    p, t = np.asarray(pred, np.float64).reshape(-1, 4), np.asarray(target, np.float64).reshape(-1, 4)
+    area1 = (p[:, 2] - p[:, 0]) * (p[:, 3] - p[:, 1])
+    area2 = (t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1])
+    wh = np.clip(np.minimum(p[:, 2:], t[:, 2:]) - np.maximum(p[:, :2], t[:, :2]), 0, None)
+    overlap = wh[:, 0] * wh[:, 1]
+    union = np.maximum(area1 + area2 - overlap, eps)
+    ious = overlap / union
+    ewh = np.clip(np.maximum(p[:, 2:], t[:, 2:]) - np.minimum(p[:, :2], t[:, :2]), 0, None)
+    earea = np.maximum(ewh[:, 0] * ewh[:, 1], eps)
+    return 1.0 - (ious - (earea - union) / earea)
+
+
+def bbox_head_loss(cls_score, bbox_pred, labels, targets, flags, num_classes, class_agnostic=False, beta=0.0, giou=None):
+    """BBoxHead.loss (bbox_head.py:188-238) over a fixed-size sample (flags bit 0 used, bit 1 positive):
+    -> (loss_cls, acc %, loss_bbox), float64.  giou = (rois (n,4), means, stds, eps) selects reg_decoded_bbox + GIoULoss."""
+    c = np.asarray(cls_score, np.float64)
+    n = c.shape[0]
+    used = (np.asarray(flags) & 1) > 0
+    pos = ((np.asarray(flags) & 2) > 0) & used & (np.asarray(labels) < num_classes)
+    nv = max(int(used.sum()), 1)
+    m = c.max(1, keepdims=True)
+    lse = (m + np.log(np.exp(c - m).sum(1, keepdims=True)))[:, 0]
+    ce = lse - c[np.arange(n), labels]
+    loss_cls = float((ce * used).sum() / nv)
+    acc = float(((c.argmax(1) == labels) & used).sum() / nv * 100.0)
+    b = np.asarray(bbox_pred, np.float64)
+    lab = np.minimum(np.asarray(labels), num_classes - 1)
+    pred = b.reshape(n, 4) if class_agnostic else b.reshape(n, num_classes, 4)[np.arange(n), lab]
+    t = np.asarray(targets, np.float64)
+    if giou is not None:
+        rois, means, stds, eps = giou
+        dec = delta2bbox(np.asarray(rois, np.float64), pred, means, stds, None)
+        per = giou_loss(dec, t, eps)
+    else:
+        per = smooth_l1(pred - t, beta).sum(1)
+    return loss_cls, acc, float((per * pos).sum() / nv)
+
+
+def regress_by_class(rois, labels, cls_score, bbox_pred, num_classes, class_agnostic, means, stds, img_shape):
+    """BBoxHead.regress_by_class (bbox_head.py:409-436) with CascadeRoIHead's label choice (cascade_roi_head.py:274-281
+    in training: background -> argmax of the foreground scores; :316-317 in testing: labels=None -> argmax)."""
+    c = np.asarray(cls_score, np.float32)
+    n = c.shape[0]
+    am = c[:, :num_classes].argmax(1)
+    lab = am if labels is None else np.where((np.asarray(labels) >= num_classes) | (np.asarray(labels) < 0), am, labels)
+    d = np.asarray(bbox_pred, np.float32)
+    if not class_agnostic:
+        d = d.reshape(n, num_classes, 4)[np.arange(n), lab]
+    return delta2bbox(np.asarray(rois, np.float32), d.reshape(n, 4), means, stds, img_shape)
+
+
+def batch_norm_train(x, gamma, beta, eps=1e-5, relu=False):
+    """Training-mode BatchNorm over (R, C) rows (torch.nn.BatchNorm2d / SyncBatchNorm on NHWC data: biased variance for
+    normalisation), float64 -> (y, mean, var_biased)."""
+    x = np.asarray(x, np.float64)
+    mean, var = x.mean(0), x.var(0)
+    y = (x - mean) / np.sqrt(var + eps) * np.asarray(gamma, np.float64) + np.asarray(beta, np.float64)
+    return (np.maximum(y, 0) if relu else y), mean, var
+
+
+def batch_norm_train_bwd(x, gamma, beta, dy, eps=1e-5, relu=False):
+    """Gradients of batch_norm_train (SyncBatchNorm's backward_reduce / backward_elemt arithmetic), float64:
+    -> (dx, dgamma, dbeta)."""
+    x, dy = np.asarray(x, np.float64), np.asarray(dy, np.float64)
+    g = np.asarray(gamma, np.float64)
+    mean, var = x.mean(0), x.var(0)
+    invstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mean) * invstd
+    if relu:
+        dy = dy * ((xhat * g + np.asarray(beta, np.float64)) > 0)
+    sdy, sdyx = dy.sum(0), (dy * xhat).sum(0)
+    n = x.shape[0]
+    dx = g * invstd * (dy - sdy / n - xhat * sdyx / n)
+    return dx, sdyx, sdy

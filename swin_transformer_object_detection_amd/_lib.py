@@ -53,18 +53,25 @@ SIGNATURES = {
     "swin_gemm_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p, _p],
     "swin_adamw_step": [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p],
     "swin_adamw_chunk_elems": [],
-    "det_rpn_loss_fwd": [_p, _p, _i, _i64, _i, _p, _p, _p, _p, _i, _p],
-    "det_rpn_loss_bwd": [_p, _p, _i, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p],
-    "det_bbox_loss_fwd": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _i, _p],
-    "det_bbox_loss_bwd": [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "det_rpn_loss_fwd": [_p, _p, _i, _i64, _i, _p, _p, _p, _f, _p, _i, _p],
+    "det_rpn_loss_bwd": [_p, _p, _i, _i64, _i, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p],
+    "det_bbox_loss_fwd": [_p, _p, _i, _i, _p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _i, _p],
+    "det_bbox_loss_bwd": [_p, _p, _i, _i, _p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "det_regress_by_class": [_p, _p, _p, _p, _i64, _i, _i, _p, _p, _f, _f, _p, _i, _p],
+    "det_bn_workspace_bytes": [_i],
+    "det_bn_stats": [_p, _i64, _i, _p, _p, _i, _p],
+    "det_bn_finalize": [_p, _i, _f, _f, _p, _p, _p, _p],
+    "det_bn_apply": [_p, _p, _i64, _i, _p, _p, _p, _i, _i, _p],
+    "det_bn_bwd_reduce": [_p, _p, _i64, _i, _p, _p, _p, _i, _p, _p, _i, _p],
+    "det_bn_bwd_apply": [_p, _p, _p, _i64, _i, _p, _p, _p, _i, _p, _p, _i, _p],
     "det_mask_loss_fwd": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "det_mask_loss_bwd": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "det_rpn_flatten_fwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
     "det_rpn_flatten_bwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
-    "det_paste_masks": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p],
+    "det_paste_masks": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p],
 }
 _RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_gemm_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
-            "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64}
+            "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64, "det_bn_workspace_bytes": _i64}
 
 _lib = None
 

@@ -1,9 +1,11 @@
 // Loss kernels of the detector heads for gfx950, forward value + input gradients, fixed-size samples.
 // Reference arithmetic:
 //   RPN:   AnchorHead.loss_single (mmdet/models/dense_heads/anchor_head.py:375-434): sigmoid cross entropy over the
-//          sampled anchors + L1 on the positives' deltas, both divided by the number of sampled anchors of the batch;
+//          sampled anchors + L1 / SmoothL1(beta) on the positives' deltas, both divided by the number of sampled
+//          anchors of the batch;
 //   bbox:  BBoxHead.loss (mmdet/models/roi_heads/bbox_heads/bbox_head.py:188-238): softmax cross entropy (avg_factor =
-//          number of sampled RoIs), accuracy, class-specific L1 on the positives divided by the number of samples;
+//          number of sampled RoIs), accuracy, and on the positives -- divided by the number of samples -- class-specific
+//          or class-agnostic L1 / SmoothL1 on the deltas, or GIoU on the decoded boxes (reg_decoded_bbox, Cascade configs);
 //   mask:  FCNMaskHead.loss / mask_cross_entropy (mmdet/models/losses/cross_entropy_loss.py): mean sigmoid BCE over
 //          (positives x 28 x 28) of the labelled class channel.
 // The reference spends 15-40 elementwise launches per loss (gathers, casts, BCE, masks, sums) and as many again in
@@ -26,6 +28,69 @@ __device__ __forceinline__ float bce_logits(float x, float y) {       // max(x,0
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
+// L1Loss / SmoothL1Loss element (losses/smooth_l1_loss.py:10-28, :31-45): beta <= 0 selects plain L1.
+__device__ __forceinline__ float reg_elem_loss(float d, float beta) {
+    const float a = fabsf(d);
+    return a < beta ? 0.5f * a * a / beta : a - 0.5f * beta;
+}
+__device__ __forceinline__ float reg_elem_grad(float d, float beta) {
+    if (fabsf(d) < beta) return d / beta;
+    return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+}
+
+// Regression term of BBoxHead.loss.  mode 0: L1 / SmoothL1(beta) on the encoded deltas; mode 2: GIoULoss on the DECODED
+// boxes (reg_decoded_bbox=True, bbox_head.py:215-216 -> DeltaXYWHBBoxCoder.decode without max_shape; iou_loss.py:78-101 ->
+// bbox_overlaps(mode='giou', is_aligned=True), iou2d_calculator.py:108-158).
+struct RegCfg { int mode; int agnostic; float beta; float eps; float means[4]; float stds[4]; float max_ratio; };
+
+// share of the gradient that max(a,b) / min(a,b) sends to a (torch.maximum / minimum split ties evenly)
+__device__ __forceinline__ float sel_max(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float sel_min(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
+
+// decoded box o[4] of roi r[4] and raw deltas dl[4]; jac[4]: d(center)/d(dl0,dl1) and d(size)/d(dl2,dl3)
+__device__ __forceinline__ void decode_box(const float* r, const float* dl, const RegCfg& c, float* o, float* jac) {
+    const float dx = dl[0] * c.stds[0] + c.means[0], dy = dl[1] * c.stds[1] + c.means[1];
+    const float dw0 = dl[2] * c.stds[2] + c.means[2], dh0 = dl[3] * c.stds[3] + c.means[3];
+    const float dw = fminf(fmaxf(dw0, -c.max_ratio), c.max_ratio), dh = fminf(fmaxf(dh0, -c.max_ratio), c.max_ratio);
+    const float px = (r[0] + r[2]) * 0.5f, py = (r[1] + r[3]) * 0.5f, pw = r[2] - r[0], ph = r[3] - r[1];
+    const float gw = pw * expf(dw), gh = ph * expf(dh);
+    const float gx = px + pw * dx, gy = py + ph * dy;
+    o[0] = gx - gw * 0.5f; o[1] = gy - gh * 0.5f; o[2] = gx + gw * 0.5f; o[3] = gy + gh * 0.5f;
+    if (jac) {
+        jac[0] = pw * c.stds[0]; jac[1] = ph * c.stds[1];
+        jac[2] = (dw0 >= -c.max_ratio && dw0 <= c.max_ratio) ? gw * c.stds[2] : 0.f;     // clamp passes gradient inside [min,max]
+        jac[3] = (dh0 >= -c.max_ratio && dh0 <= c.max_ratio) ? gh * c.stds[3] : 0.f;
+    }
+}
+
+// 1 - GIoU(p, t); g[4] (optional) = d loss / d p
+__device__ __forceinline__ float giou_loss(const float* p, const float* t, float eps, float* g) {
+    const float pw = p[2] - p[0], ph = p[3] - p[1];
+    const float area1 = pw * ph, area2 = (t[2] - t[0]) * (t[3] - t[1]);
+    const float w0 = fminf(p[2], t[2]) - fmaxf(p[0], t[0]), h0 = fminf(p[3], t[3]) - fmaxf(p[1], t[1]);
+    const float w = fmaxf(w0, 0.f), h = fmaxf(h0, 0.f);
+    const float ov = w * h;
+    const float un0 = area1 + area2 - ov, un = fmaxf(un0, eps);
+    const float iou = ov / un;
+    const float ew0 = fmaxf(p[2], t[2]) - fminf(p[0], t[0]), eh0 = fmaxf(p[3], t[3]) - fminf(p[1], t[1]);
+    const float ew = fmaxf(ew0, 0.f), eh = fmaxf(eh0, 0.f);
+    const float ea0 = ew * eh, ea = fmaxf(ea0, eps);
+    const float giou = iou - (ea - un) / ea;
+    if (g) {
+        // loss = 1 - ov/un + (ea - un)/ea
+        const float d_un = (ov / (un * un) - 1.f / ea) * sel_max(un0, eps);
+        const float d_ea = (un / (ea * ea)) * sel_max(ea0, eps);
+        const float d_ov = -1.f / un - d_un;                      // un0 = area1 + area2 - ov
+        const float d_w = (w0 >= 0.f) ? d_ov * h : 0.f, d_h = (h0 >= 0.f) ? d_ov * w : 0.f;
+        const float d_ew = (ew0 >= 0.f) ? d_ea * eh : 0.f, d_eh = (eh0 >= 0.f) ? d_ea * ew : 0.f;
+        g[0] = -d_un * ph - d_w * sel_max(p[0], t[0]) - d_ew * sel_min(p[0], t[0]);
+        g[1] = -d_un * pw - d_h * sel_max(p[1], t[1]) - d_eh * sel_min(p[1], t[1]);
+        g[2] = d_un * ph + d_w * sel_min(p[2], t[2]) + d_ew * sel_max(p[2], t[2]);
+        g[3] = d_un * pw + d_h * sel_min(p[3], t[3]) + d_eh * sel_max(p[3], t[3]);
+    }
+    return 1.f - giou;
+}
+
 // ------------------------------------------------------------------------------------------------ RPN
 // cls (B, A) logits, reg (B, A, 4) deltas; per image S sample slots: inds, flags (bit 0 used, bit 1 positive), tgt (S,4).
 // out[0] = sum BCE / n, out[1] = sum L1 / n, out[2] = n (sampled anchors of the whole batch, >= 1).
@@ -33,7 +98,7 @@ template <typename T>
 __global__ __launch_bounds__(1024) void rpn_loss_fwd_kernel(const T* __restrict__ cls, const T* __restrict__ reg, int B, int64_t A,
                                                             int S, const int64_t* __restrict__ inds,
                                                             const uint8_t* __restrict__ flags, const float* __restrict__ tgt,
-                                                            float* __restrict__ out) {
+                                                            float beta, float* __restrict__ out) {
     __shared__ float red[16];
     float lc = 0.f, lb = 0.f, cnt = 0.f;
     for (int i = threadIdx.x; i < B * S; i += blockDim.x) {
@@ -47,7 +112,7 @@ __global__ __launch_bounds__(1024) void rpn_loss_fwd_kernel(const T* __restrict_
         if (f & 2) {
             const T* r = reg + (b * A + a) * 4;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lb += fabsf(Elt<T>::ld(r + k) - tgt[(int64_t)i * 4 + k]);
+            for (int k = 0; k < 4; ++k) lb += reg_elem_loss(Elt<T>::ld(r + k) - tgt[(int64_t)i * 4 + k], beta);
         }
     }
     lc = block_sum(lc, red); lb = block_sum(lb, red); cnt = block_sum(cnt, red);
@@ -63,7 +128,7 @@ __global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(const T* __restrict__
                                                            int S, const int64_t* __restrict__ inds,
                                                            const uint8_t* __restrict__ flags, const float* __restrict__ tgt,
                                                            const float* __restrict__ out, const float* __restrict__ gout,
-                                                           T* __restrict__ dcls, T* __restrict__ dreg) {
+                                                           float beta, T* __restrict__ dcls, T* __restrict__ dreg) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * S) return;
     const uint8_t f = flags[i];
@@ -77,19 +142,20 @@ __global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(const T* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float d = Elt<T>::ld(reg + (b * A + a) * 4 + k) - tgt[(int64_t)i * 4 + k];
-            Elt<T>::st(dreg + (b * A + a) * 4 + k, (d > 0.f ? g1 : (d < 0.f ? -g1 : 0.f)));
+            Elt<T>::st(dreg + (b * A + a) * 4 + k, reg_elem_grad(d, beta) * g1);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ bbox head
-// cls (n, nc+1) logits, bbox (n, 4 nc) class-specific deltas, labels (n) in [0, nc] (nc = background), tgt (n,4),
-// flags (n) (bit 0 used, bit 1 positive).  out[0] = CE sum / nv, out[1] = accuracy (%), out[2] = L1 sum / nv, out[3] = nv.
+// cls (n, nc+1) logits, bbox (n, 4 nc) class-specific or (n, 4) class-agnostic deltas, labels (n) in [0, nc] (nc =
+// background), tgt (n,4) (encoded deltas, or gt boxes in GIoU mode), rois (n,4) (GIoU mode only), flags (n) (bit 0 used,
+// bit 1 positive).  out[0] = CE sum / nv, out[1] = accuracy (%), out[2] = regression sum / nv, out[3] = nv.
 template <typename T>
 __global__ __launch_bounds__(1024) void bbox_loss_fwd_kernel(const T* __restrict__ cls, const T* __restrict__ bbox, int n, int nc,
                                                              const int64_t* __restrict__ labels, const float* __restrict__ tgt,
-                                                             const uint8_t* __restrict__ flags, float* __restrict__ out,
-                                                             float* __restrict__ lse) {
+                                                             const uint8_t* __restrict__ flags, const float* __restrict__ rois,
+                                                             RegCfg rc, float* __restrict__ out, float* __restrict__ lse) {
     __shared__ float red[16];
     float ce = 0.f, hit = 0.f, l1 = 0.f, cnt = 0.f;
     const int C = nc + 1;
@@ -108,9 +174,20 @@ __global__ __launch_bounds__(1024) void bbox_loss_fwd_kernel(const T* __restrict
         hit += (am == lab) ? 1.f : 0.f;
         cnt += 1.f;
         if ((f & 2) && lab < nc) {
-            const T* p = bbox + ((int64_t)i * nc + lab) * 4;
+            const T* p = rc.agnostic ? bbox + (int64_t)i * 4 : bbox + ((int64_t)i * nc + lab) * 4;
+            float dl[4], t4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) l1 += fabsf(Elt<T>::ld(p + k) - tgt[(int64_t)i * 4 + k]);
+            for (int k = 0; k < 4; ++k) { dl[k] = Elt<T>::ld(p + k); t4[k] = tgt[(int64_t)i * 4 + k]; }
+            if (rc.mode == 2) {
+                float r4[4], o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r4[k] = rois[(int64_t)i * 4 + k];
+                decode_box(r4, dl, rc, o, nullptr);
+                l1 += giou_loss(o, t4, rc.eps, nullptr);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) l1 += reg_elem_loss(dl[k] - t4[k], rc.beta);
+            }
         }
     }
     ce = block_sum(ce, red); hit = block_sum(hit, red); l1 = block_sum(l1, red); cnt = block_sum(cnt, red);
@@ -124,10 +201,11 @@ __global__ __launch_bounds__(1024) void bbox_loss_fwd_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void bbox_loss_bwd_kernel(const T* __restrict__ cls, const T* __restrict__ bbox, int n, int nc,
                                                             const int64_t* __restrict__ labels, const float* __restrict__ tgt,
-                                                            const uint8_t* __restrict__ flags, const float* __restrict__ out,
+                                                            const uint8_t* __restrict__ flags, const float* __restrict__ rois,
+                                                            RegCfg rc, const float* __restrict__ out,
                                                             const float* __restrict__ lse, const float* __restrict__ gout,
                                                             T* __restrict__ dcls, T* __restrict__ dbbox) {
-    const int C = nc + 1, W = C + 4 * nc;
+    const int C = nc + 1, RW = rc.agnostic ? 4 : 4 * nc, W = C + RW;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= (int64_t)n * W) return;
     const int i = (int)(id / W), col = (int)(id - (int64_t)i * W);
@@ -141,11 +219,23 @@ __global__ __launch_bounds__(256) void bbox_loss_bwd_kernel(const T* __restrict_
     } else {
         const int q = col - C, c = q >> 2, k = q & 3;
         float g = 0.f;
-        if ((f & 2) && c == lab) {
-            const float d = Elt<T>::ld(bbox + (int64_t)i * 4 * nc + q) - tgt[(int64_t)i * 4 + k];
-            g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * gout[2] * inv;
+        if ((f & 2) && lab < nc && (rc.agnostic || c == lab)) {
+            const T* p = bbox + (int64_t)i * RW + (q - k);
+            if (rc.mode == 2) {
+                float dl[4], t4[4], r4[4], o[4], jac[4], gb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dl[j] = Elt<T>::ld(p + j); t4[j] = tgt[(int64_t)i * 4 + j]; r4[j] = rois[(int64_t)i * 4 + j]; }
+                decode_box(r4, dl, rc, o, jac);
+                giou_loss(o, t4, rc.eps, gb);
+                // o = (gx - gw/2, gy - gh/2, gx + gw/2, gy + gh/2)
+                const float gk = k == 0 ? (gb[0] + gb[2]) * jac[0] : k == 1 ? (gb[1] + gb[3]) * jac[1]
+                               : k == 2 ? 0.5f * (gb[2] - gb[0]) * jac[2] : 0.5f * (gb[3] - gb[1]) * jac[3];
+                g = gk * gout[2] * inv;
+            } else {
+                g = reg_elem_grad(Elt<T>::ld(p + k) - tgt[(int64_t)i * 4 + k], rc.beta) * gout[2] * inv;
+            }
         }
-        Elt<T>::st(dbbox + (int64_t)i * 4 * nc + q, g);
+        Elt<T>::st(dbbox + (int64_t)i * RW + q, g);
     }
 }
 
@@ -233,48 +323,72 @@ __global__ __launch_bounds__(256) void rpn_flatten_kernel(FlatLevels F, int B, i
     if ((dtype) == SWIN_F32) { CALL_F32; } else if ((dtype) == SWIN_BF16) { CALL_BF16; } else return SWIN_ERR_UNSUPPORTED;
 
 extern "C" int det_rpn_loss_fwd(const void* cls, const void* reg, int B, int64_t A, int S, const int64_t* inds, const uint8_t* flags,
-                                const float* targets, float* out3, int dtype, void* stream) {
-    if (!cls || !reg || !inds || !flags || !targets || !out3 || B <= 0 || A <= 0 || S <= 0) return SWIN_ERR_BAD_ARG;
+                                const float* targets, float beta, float* out3, int dtype, void* stream) {
+    if (!cls || !reg || !inds || !flags || !targets || !out3 || B <= 0 || A <= 0 || S <= 0 || !(beta >= 0.f)) return SWIN_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_T(dtype, (rpn_loss_fwd_kernel<float><<<1, 1024, 0, s>>>((const float*)cls, (const float*)reg, B, A, S, inds, flags, targets, out3)),
-               (rpn_loss_fwd_kernel<bf16><<<1, 1024, 0, s>>>((const bf16*)cls, (const bf16*)reg, B, A, S, inds, flags, targets, out3)))
+    DISPATCH_T(dtype, (rpn_loss_fwd_kernel<float><<<1, 1024, 0, s>>>((const float*)cls, (const float*)reg, B, A, S, inds, flags, targets, beta, out3)),
+               (rpn_loss_fwd_kernel<bf16><<<1, 1024, 0, s>>>((const bf16*)cls, (const bf16*)reg, B, A, S, inds, flags, targets, beta, out3)))
     return swin_launch_status();
 }
 
 // dcls (B,A) / dreg (B,A,4): zeroed by the caller; grad_out: 2 floats (d loss_cls, d loss_bbox); out3 from the forward.
 extern "C" int det_rpn_loss_bwd(const void* cls, const void* reg, int B, int64_t A, int S, const int64_t* inds, const uint8_t* flags,
-                                const float* targets, const float* out3, const float* grad_out, void* dcls, void* dreg, int dtype,
-                                void* stream) {
-    if (!cls || !reg || !inds || !flags || !targets || !out3 || !grad_out || !dcls || !dreg || B <= 0 || A <= 0 || S <= 0)
+                                const float* targets, float beta, const float* out3, const float* grad_out, void* dcls, void* dreg,
+                                int dtype, void* stream) {
+    if (!cls || !reg || !inds || !flags || !targets || !out3 || !grad_out || !dcls || !dreg || B <= 0 || A <= 0 || S <= 0 ||
+        !(beta >= 0.f))
         return SWIN_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (B * S + 255) / 256;
-    DISPATCH_T(dtype, (rpn_loss_bwd_kernel<float><<<blocks, 256, 0, s>>>((const float*)cls, (const float*)reg, B, A, S, inds, flags, targets, out3, grad_out, (float*)dcls, (float*)dreg)),
-               (rpn_loss_bwd_kernel<bf16><<<blocks, 256, 0, s>>>((const bf16*)cls, (const bf16*)reg, B, A, S, inds, flags, targets, out3, grad_out, (bf16*)dcls, (bf16*)dreg)))
+    DISPATCH_T(dtype, (rpn_loss_bwd_kernel<float><<<blocks, 256, 0, s>>>((const float*)cls, (const float*)reg, B, A, S, inds, flags, targets, out3, grad_out, beta, (float*)dcls, (float*)dreg)),
+               (rpn_loss_bwd_kernel<bf16><<<blocks, 256, 0, s>>>((const bf16*)cls, (const bf16*)reg, B, A, S, inds, flags, targets, out3, grad_out, beta, (bf16*)dcls, (bf16*)dreg)))
     return swin_launch_status();
+}
+
+// reg_mode 0: L1 (beta 0) / SmoothL1 (beta > 0) on encoded deltas; 2: GIoU on decoded boxes (rois, means, stds, eps used).
+static int reg_cfg(RegCfg& rc, int reg_mode, int class_agnostic, float beta, float eps, const float* rois, const float* means,
+                   const float* stds) {
+    if (reg_mode != 0 && reg_mode != 2) return SWIN_ERR_UNSUPPORTED;
+    if (!(beta >= 0.f)) return SWIN_ERR_BAD_ARG;
+    rc.mode = reg_mode; rc.agnostic = class_agnostic ? 1 : 0; rc.beta = beta; rc.eps = eps;
+    rc.max_ratio = fabsf(logf(16.f / 1000.f));                     // DeltaXYWHBBoxCoder default wh_ratio_clip
+    for (int q = 0; q < 4; ++q) { rc.means[q] = 0.f; rc.stds[q] = 1.f; }
+    if (reg_mode == 2) {
+        if (!rois || !means || !stds || !(eps > 0.f)) return SWIN_ERR_BAD_ARG;
+        for (int q = 0; q < 4; ++q) { rc.means[q] = means[q]; rc.stds[q] = stds[q]; }
+    }
+    return SWIN_OK;
 }
 
 // out4: loss_cls, accuracy (%), loss_bbox, n_valid; lse (n) f32 scratch kept for the backward.
 extern "C" int det_bbox_loss_fwd(const void* cls, const void* bbox, int n, int num_classes, const int64_t* labels, const float* targets,
-                                 const uint8_t* flags, float* out4, float* lse, int dtype, void* stream) {
+                                 const uint8_t* flags, int reg_mode, int class_agnostic, float beta, float eps, const float* rois,
+                                 const float* means, const float* stds, float* out4, float* lse, int dtype, void* stream) {
     if (!cls || !bbox || !labels || !targets || !flags || !out4 || !lse || n <= 0 || num_classes <= 0) return SWIN_ERR_BAD_ARG;
+    RegCfg rc;
+    const int st = reg_cfg(rc, reg_mode, class_agnostic, beta, eps, rois, means, stds);
+    if (st != SWIN_OK) return st;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_T(dtype, (bbox_loss_fwd_kernel<float><<<1, 1024, 0, s>>>((const float*)cls, (const float*)bbox, n, num_classes, labels, targets, flags, out4, lse)),
-               (bbox_loss_fwd_kernel<bf16><<<1, 1024, 0, s>>>((const bf16*)cls, (const bf16*)bbox, n, num_classes, labels, targets, flags, out4, lse)))
+    DISPATCH_T(dtype, (bbox_loss_fwd_kernel<float><<<1, 1024, 0, s>>>((const float*)cls, (const float*)bbox, n, num_classes, labels, targets, flags, rois, rc, out4, lse)),
+               (bbox_loss_fwd_kernel<bf16><<<1, 1024, 0, s>>>((const bf16*)cls, (const bf16*)bbox, n, num_classes, labels, targets, flags, rois, rc, out4, lse)))
     return swin_launch_status();
 }
 
-// grad_out: 4 floats aligned with out4 (entries 0 and 2 are used); dcls (n, nc+1), dbbox (n, 4 nc): fully written.
+// grad_out: 4 floats aligned with out4 (entries 0 and 2 are used); dcls (n, nc+1), dbbox (n, 4 nc | 4): fully written.
 extern "C" int det_bbox_loss_bwd(const void* cls, const void* bbox, int n, int num_classes, const int64_t* labels, const float* targets,
-                                 const uint8_t* flags, const float* out4, const float* lse, const float* grad_out, void* dcls,
-                                 void* dbbox, int dtype, void* stream) {
+                                 const uint8_t* flags, int reg_mode, int class_agnostic, float beta, float eps, const float* rois,
+                                 const float* means, const float* stds, const float* out4, const float* lse, const float* grad_out,
+                                 void* dcls, void* dbbox, int dtype, void* stream) {
     if (!cls || !bbox || !labels || !targets || !flags || !out4 || !lse || !grad_out || !dcls || !dbbox || n <= 0 || num_classes <= 0)
         return SWIN_ERR_BAD_ARG;
+    RegCfg rc;
+    const int st = reg_cfg(rc, reg_mode, class_agnostic, beta, eps, rois, means, stds);
+    if (st != SWIN_OK) return st;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = (int64_t)n * (5 * num_classes + 1);
+    const int64_t total = (int64_t)n * (num_classes + 1 + (class_agnostic ? 4 : 4 * num_classes));
     const int blocks = (int)((total + 255) / 256);
-    DISPATCH_T(dtype, (bbox_loss_bwd_kernel<float><<<blocks, 256, 0, s>>>((const float*)cls, (const float*)bbox, n, num_classes, labels, targets, flags, out4, lse, grad_out, (float*)dcls, (float*)dbbox)),
-               (bbox_loss_bwd_kernel<bf16><<<blocks, 256, 0, s>>>((const bf16*)cls, (const bf16*)bbox, n, num_classes, labels, targets, flags, out4, lse, grad_out, (bf16*)dcls, (bf16*)dbbox)))
+    DISPATCH_T(dtype, (bbox_loss_bwd_kernel<float><<<blocks, 256, 0, s>>>((const float*)cls, (const float*)bbox, n, num_classes, labels, targets, flags, rois, rc, out4, lse, grad_out, (float*)dcls, (float*)dbbox)),
+               (bbox_loss_bwd_kernel<bf16><<<blocks, 256, 0, s>>>((const bf16*)cls, (const bf16*)bbox, n, num_classes, labels, targets, flags, rois, rc, out4, lse, grad_out, (bf16*)dcls, (bf16*)dbbox)))
     return swin_launch_status();
 }
 

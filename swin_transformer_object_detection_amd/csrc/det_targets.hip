@@ -28,14 +28,19 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
 
 // ---- pass 1: per box max / argmax over the gts, per gt max over the boxes (IoU >= 0: uint order == float order)
 __global__ __launch_bounds__(256) void assign_max_kernel(const float4* __restrict__ boxes, int n, const float4* __restrict__ gts,
-                                                         int G, int n_self, float* __restrict__ max_ov,
-                                                         int* __restrict__ argmax, unsigned* __restrict__ gt_max) {
+                                                         int G, int n_self, const uint8_t* __restrict__ valid_mask,
+                                                         float* __restrict__ max_ov, int* __restrict__ argmax,
+                                                         unsigned* __restrict__ gt_max) {
     __shared__ float4 sg[256];
     __shared__ unsigned smax[256];
     const int t = threadIdx.x, lane = t & 63;
     const int idx = blockIdx.x * 256 + t;
     const bool valid = idx < n;
     const float4 box = valid ? boxes[idx] : float4{0.f, 0.f, 0.f, 0.f};
+    // masked-out boxes (padding of fixed-size lists; anchors outside `allowed_border`, which the reference removes before
+    // assigning: anchor_head.py:200-207) and the leading gt rows (appended AFTER the assignment in the reference) do not
+    // feed the per-gt maximum
+    const bool feeds = valid && idx >= n_self && (!valid_mask || valid_mask[idx]);
     float best = -1.f;
     int arg = 0;
     for (int g0 = 0; g0 < G; g0 += 256) {
@@ -45,8 +50,7 @@ __global__ __launch_bounds__(256) void assign_max_kernel(const float4* __restric
         for (int q = 0; q < cnt; ++q) {
             const float iou = valid ? iou_gt_box(sg[q], box) : 0.f;
             if (iou > best) { best = iou; arg = g0 + q; }                // strict: first maximum, as argmax does
-            // leading gt rows are appended AFTER the assignment in the reference: they do not feed the per-gt maximum
-            const unsigned m = wave_max_u32(idx >= n_self ? __float_as_uint(iou) : 0u);
+            const unsigned m = wave_max_u32(feeds ? __float_as_uint(iou) : 0u);
             if (lane == 0 && m) atomicMax(&smax[q], m);
         }
         __syncthreads();
@@ -292,6 +296,39 @@ __global__ __launch_bounds__(256) void delta2bbox_kernel(const float4* __restric
     out[i] = o;
 }
 
+// BBoxHead.regress_by_class (bbox_head.py:409-436) with the label choice of CascadeRoIHead folded in
+// (cascade_roi_head.py:274-281 training: background labels -> argmax over the foreground scores; :316-317 testing:
+// always the argmax): select the label's 4 deltas and decode against the roi, clipped to the image.
+template <typename T>
+__global__ __launch_bounds__(256) void regress_by_class_kernel(const float4* __restrict__ rois, const int64_t* __restrict__ labels,
+                                                               const T* __restrict__ cls, const T* __restrict__ bbox, int64_t n, int nc,
+                                                               int agnostic, F4 means, F4 stds, float max_h, float max_w,
+                                                               float max_ratio, float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int lab = labels ? (int)labels[i] : nc;
+    if (lab < 0 || lab >= nc) {
+        const T* row = cls + i * (nc + 1);
+        float m = Elt<T>::ld(row); lab = 0;
+        for (int c = 1; c < nc; ++c) { const float v = Elt<T>::ld(row + c); if (v > m) { m = v; lab = c; } }
+    }
+    const T* d = agnostic ? bbox + i * 4 : bbox + (i * nc + lab) * 4;
+    const float4 r = rois[i];
+    const float dx = Elt<T>::ld(d) * stds.v[0] + means.v[0], dy = Elt<T>::ld(d + 1) * stds.v[1] + means.v[1];
+    float dw = Elt<T>::ld(d + 2) * stds.v[2] + means.v[2], dh = Elt<T>::ld(d + 3) * stds.v[3] + means.v[3];
+    dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+    dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+    const float px = (r.x + r.z) * 0.5f, py = (r.y + r.w) * 0.5f, pw = r.z - r.x, ph = r.w - r.y;
+    const float gw = pw * expf(dw), gh = ph * expf(dh);
+    const float gx = px + pw * dx, gy = py + ph * dy;
+    float4 o = {gx - gw * 0.5f, gy - gh * 0.5f, gx + gw * 0.5f, gy + gh * 0.5f};
+    if (max_w > 0.f) {
+        o.x = fminf(fmaxf(o.x, 0.f), max_w); o.z = fminf(fmaxf(o.z, 0.f), max_w);
+        o.y = fminf(fmaxf(o.y, 0.f), max_h); o.w = fminf(fmaxf(o.w, 0.f), max_h);
+    }
+    out[i] = o;
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int64_t det_assign_workspace_bytes(int64_t n, int num_gts) {
     if (n < 0) n = 0;
@@ -318,7 +355,7 @@ extern "C" int det_max_iou_assign(const float* bboxes, int64_t n, const float* g
     if (num_gts > 0) {
         if (hipMemsetAsync(gt_max, 0, (size_t)num_gts * 4, s) != hipSuccess) return SWIN_ERR_LAUNCH;
         assign_max_kernel<<<blocks, 256, 0, s>>>((const float4*)bboxes, (int)n, (const float4*)gt_bboxes, num_gts, num_leading_gt,
-                                                 max_overlaps, argmax, gt_max);
+                                                 valid, max_overlaps, argmax, gt_max);
     }
     assign_final_kernel<<<blocks, 256, 0, s>>>((const float4*)bboxes, (int)n, (const float4*)gt_bboxes, num_gts, gt_labels,
                                                pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality, num_leading_gt, valid,
@@ -379,5 +416,27 @@ extern "C" int det_delta2bbox(const float* rois, const float* deltas, int64_t n,
     const float mr = fabsf(logf(wh_ratio_clip));
     delta2bbox_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>((const float4*)rois, (const float4*)deltas, n, m, sd,
                                                                                    max_h, max_w, mr, (float4*)out);
+    return swin_launch_status();
+}
+
+// rois (n,4) f32; labels (n) i64 or NULL (NULL / background / negative -> argmax of cls[:, :num_classes]); cls (n, nc+1),
+// bbox (n, 4 nc) or (n, 4) when class_agnostic, f32|bf16; out (n,4) f32 refined boxes clipped to (max_h, max_w) when > 0.
+extern "C" int det_regress_by_class(const float* rois, const int64_t* labels, const void* cls, const void* bbox, int64_t n,
+                                    int num_classes, int class_agnostic, const float* means, const float* stds, float max_h,
+                                    float max_w, float* out, int dtype, void* stream) {
+    if (n == 0) return SWIN_OK;
+    if (!rois || !cls || !bbox || !means || !stds || !out || n < 0 || num_classes <= 0) return SWIN_ERR_BAD_ARG;
+    F4 m, sd;
+    for (int q = 0; q < 4; ++q) { m.v[q] = means[q]; sd.v[q] = stds[q]; }
+    const float mr = fabsf(logf(16.f / 1000.f));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SWIN_F32)
+        regress_by_class_kernel<float><<<blocks, 256, 0, s>>>((const float4*)rois, labels, (const float*)cls, (const float*)bbox, n,
+                                                              num_classes, class_agnostic, m, sd, max_h, max_w, mr, (float4*)out);
+    else if (dtype == SWIN_BF16)
+        regress_by_class_kernel<bf16><<<blocks, 256, 0, s>>>((const float4*)rois, labels, (const bf16*)cls, (const bf16*)bbox, n,
+                                                             num_classes, class_agnostic, m, sd, max_h, max_w, mr, (float4*)out);
+    else return SWIN_ERR_UNSUPPORTED;
     return swin_launch_status();
 }

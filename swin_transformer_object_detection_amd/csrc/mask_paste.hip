@@ -10,7 +10,7 @@
 template <typename T>
 __global__ __launch_bounds__(256) void paste_masks_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
                                                           const float4* __restrict__ boxes, int N, int num_classes, int mh,
-                                                          int mw, int img_h, int img_w, float thr,
+                                                          int mw, int img_h, int img_w, float thr, int is_prob,
                                                           uint8_t* __restrict__ out) {
     const int n = blockIdx.z;
     const int y = blockIdx.y;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const T* __restrict__ 
         auto tap = [&](int yy, int xx) -> float {
             if (yy < 0 || yy >= mh || xx < 0 || xx >= mw) return 0.f;
             const float l = Elt<T>::ld(m + yy * mw + xx);
-            return 1.f / (1.f + expf(-l));
+            return is_prob ? l : 1.f / (1.f + expf(-l));
         };
         // accumulation order of grid_sample's bilinear kernel: nw, ne, sw, se
         v = tap(y0, x0) * (wx0 * wy0);
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const T* __restrict__ 
 // mask_logits (N, num_classes, mh, mw) f32 or bf16; labels (N) i64; boxes (N,4) f32 in output-image coordinates;
 // out (N, img_h, img_w) u8 = sigmoid-mask resampled into the box >= thr.
 extern "C" int det_paste_masks(const void* mask_logits, const int64_t* labels, const float* boxes, int N, int num_classes,
-                               int mh, int mw, int img_h, int img_w, float thr, int in_dtype, uint8_t* out, void* stream) {
+                               int mh, int mw, int img_h, int img_w, float thr, int is_prob, int in_dtype, uint8_t* out, void* stream) {
     if (N == 0) return SWIN_OK;
     if (!mask_logits || !labels || !boxes || !out || N < 0 || num_classes <= 0 || mh <= 0 || mw <= 0 || img_h <= 0 || img_w <= 0)
         return SWIN_ERR_BAD_ARG;
@@ -58,10 +58,10 @@ extern "C" int det_paste_masks(const void* mask_logits, const int64_t* labels, c
     hipStream_t s = (hipStream_t)stream;
     if (in_dtype == SWIN_F32)
         paste_masks_kernel<float><<<grid, 256, 0, s>>>((const float*)mask_logits, labels, (const float4*)boxes, N, num_classes, mh,
-                                                       mw, img_h, img_w, thr, out);
+                                                       mw, img_h, img_w, thr, is_prob, out);
     else if (in_dtype == SWIN_BF16)
         paste_masks_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)mask_logits, labels, (const float4*)boxes, N, num_classes, mh, mw,
-                                                      img_h, img_w, thr, out);
+                                                      img_h, img_w, thr, is_prob, out);
     else return SWIN_ERR_UNSUPPORTED;
     return swin_launch_status();
 }

@@ -134,8 +134,10 @@ class AnchorGenerator:
         return self._cache[key]
 
 
-def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality=True, gt_labels=None):
-    """MaxIoUAssigner.assign_wrt_overlaps (max_iou_assigner.py:130-212), ignore_iof_thr=-1."""
+def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality=True, gt_labels=None, feeds=None):
+    """MaxIoUAssigner.assign_wrt_overlaps (max_iou_assigner.py:130-212), ignore_iof_thr=-1.  ``feeds`` (n,) bool: boxes
+    that take part in the per-gt maximum (the reference never sees the others: padding slots, anchors outside
+    ``allowed_border``)."""
     n = bboxes.size(0)
     assigned = bboxes.new_full((n,), -1, dtype=torch.long)
     if gt_bboxes.size(0) == 0 or n == 0:
@@ -144,7 +146,7 @@ def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou, mat
         return assigned, bboxes.new_zeros((n,)), labels
     overlaps = bbox_overlaps(gt_bboxes, bboxes)
     max_ov, argmax = overlaps.max(dim=0)
-    gt_max, _ = overlaps.max(dim=1)
+    gt_max, _ = (overlaps if feeds is None else torch.where(feeds[None, :], overlaps, overlaps.new_full((), -1.0))).max(dim=1)
     # masked writes as torch.where: boolean-mask assignment would cost a device->host sync each
     zero = torch.zeros_like(assigned)
     assigned = torch.where((max_ov >= 0) & (max_ov < neg_iou_thr), zero, assigned)
@@ -213,7 +215,7 @@ def assign_and_sample(bboxes, gt_bboxes, a_cfg, s_cfg, means, stds, gt_labels=No
         return boxes, deltas, labels, gt_inds, flags >= 2, flags >= 1, inds, flags
     g = num_leading_gt
     assigned, _, lab = max_iou_assign(bboxes[g:], gt_bboxes, a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'], a_cfg['min_pos_iou'],
-                                      a_cfg.get('match_low_quality', True), gt_labels)
+                                      a_cfg.get('match_low_quality', True), gt_labels, None if valid is None else valid[g:])
     if g > 0:
         assigned = torch.cat([torch.arange(1, g + 1, device=assigned.device), assigned], 0)
         if lab is not None:
@@ -257,8 +259,77 @@ def _conv(x, conv, dtype, padding=0, relu=False):
     else:
         x = x.contiguous(memory_format=torch.channels_last)
         w = _cast(conv.weight, dtype).contiguous(memory_format=torch.channels_last)
-        y = F.conv2d(x, w, _cast(conv.bias, dtype), padding=padding)
+        y = F.conv2d(x, w, None if conv.bias is None else _cast(conv.bias, dtype), padding=padding)
     return F.relu(y, inplace=True) if relu else y
+
+
+class _SyncBNHost(torch.autograd.Function):
+    """torch restatement of ops.batch_norm's synchronised training pass for CPU tensors (gloo rehearsals and CPU tests):
+    the same two collectives as torch.nn.SyncBatchNorm -- per-channel {sum, sum of squares, count} forward,
+    {sum dy, sum dy*xhat} backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, rm, rv, eps, momentum):
+        import torch.distributed as dist
+        C = x.shape[1]
+        xf = x.float()
+        s_ = torch.cat([xf.sum((0, 2, 3)), (xf * xf).sum((0, 2, 3)), xf.new_tensor([xf.numel() / C])])
+        dist.all_reduce(s_)
+        n = s_[-1]
+        mean = s_[:C] / n
+        var = (s_[C:2 * C] / n - mean * mean).clamp(min=0)
+        invstd = torch.rsqrt(var + eps)
+        if rm is not None:
+            rm.mul_(1 - momentum).add_(mean * momentum)
+            rv.mul_(1 - momentum).add_(var * (n / (n - 1).clamp(min=1)) * momentum)
+        xhat = (xf - mean[None, :, None, None]) * invstd[None, :, None, None]
+        ctx.save_for_backward(xhat, invstd, w.float(), n)
+        return (xhat * w.float()[None, :, None, None] + b.float()[None, :, None, None]).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        xhat, invstd, w, n = ctx.saved_tensors
+        dyf = dy.float()
+        sdy, sdyx = dyf.sum((0, 2, 3)), (dyf * xhat).sum((0, 2, 3))
+        tot = torch.cat([sdy, sdyx])
+        dist.all_reduce(tot)
+        C = sdy.numel()
+        m1, m2 = tot[:C] / n, tot[C:] / n
+        dx = (w * invstd)[None, :, None, None] * (dyf - m1[None, :, None, None] - xhat * m2[None, :, None, None])
+        return dx.to(dy.dtype), sdyx, sdy, None, None, None, None
+
+
+def _bn_act(x, cm, training, relu=True):
+    """norm (+ ReLU) of a ConvModule built with norm_cfg: HIP kernels on the GPU (ops.batch_norm: statistics exchanged
+    over the ranks for SyncBN), torch on the CPU."""
+    import torch.distributed as dist
+    bn = cm.bn
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    multi = cm.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if x.is_cuda:
+        return ops.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, bn.momentum, relu, sync=multi)
+    if training and multi:
+        y = _SyncBNHost.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+    else:
+        y = F.batch_norm(x.float(), bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps).to(x.dtype)
+    return F.relu(y) if relu else y
+
+
+def giou_loss_elem(pred, target, eps=1e-6):
+    """1 - GIoU of aligned (n,4) boxes: iou_loss.py:78-101 over bbox_overlaps(mode='giou', is_aligned=True)
+    (iou2d_calculator.py:108-158).  Host restatement (differentiable) of csrc/det_losses.hip's giou_loss."""
+    area1 = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    area2 = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    wh = (torch.min(pred[:, 2:], target[:, 2:]) - torch.max(pred[:, :2], target[:, :2])).clamp(min=0)
+    overlap = wh[:, 0] * wh[:, 1]
+    e = pred.new_tensor([eps])
+    union = torch.max(area1 + area2 - overlap, e)
+    ious = overlap / union
+    ewh = (torch.max(pred[:, 2:], target[:, 2:]) - torch.min(pred[:, :2], target[:, :2])).clamp(min=0)
+    earea = torch.max(ewh[:, 0] * ewh[:, 1], e)
+    return 1 - (ious - (earea - union) / earea)
 
 
 def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1):
@@ -317,8 +388,10 @@ class RPNHead(nn.Module):
         self.stds = tuple(bc.get('target_stds', (1., 1., 1., 1.)))
         self.loss_cls_weight = _cfg_get(loss_cls, 'loss_weight', 1.0)
         self.loss_bbox_weight = _cfg_get(loss_bbox, 'loss_weight', 1.0)
-        if _cfg_get(loss_bbox, 'type', 'L1Loss') != 'L1Loss' or not _cfg_get(loss_cls, 'use_sigmoid', True):
-            raise NotImplementedError("RPN: sigmoid CE + L1 (the swin configs)")
+        lb_type = _cfg_get(loss_bbox, 'type', 'L1Loss')
+        if lb_type not in ('L1Loss', 'SmoothL1Loss') or not _cfg_get(loss_cls, 'use_sigmoid', True):
+            raise NotImplementedError("RPN: sigmoid CE + L1 / SmoothL1 (the swin configs)")
+        self.loss_bbox_beta = float(_cfg_get(loss_bbox, 'beta', 1.0)) if lb_type == 'SmoothL1Loss' else 0.0
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.compute_dtype = compute_dtype
         self.rpn_conv = nn.Conv2d(in_channels, feat_channels, 3, padding=1)
@@ -390,11 +463,18 @@ class RPNHead(nn.Module):
         anchors = self.anchor_generator.grid_anchors_cat(sizes, cls_scores[0].device)
         B = cls_scores[0].size(0)
         cls, reg = self._flattened(cls_scores, bbox_preds)
-        samples = [assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg, self.means, self.stds) for i in range(B)]
+        ab = cfg.get('allowed_border', -1)
+        inside = [None] * B
+        if ab >= 0:                                 # anchor_inside_flags (core/anchor/utils.py:28-50), anchor_head.py:200-207
+            for i in range(B):
+                h, w = img_shapes[i][:2]
+                inside[i] = ((anchors[:, 0] >= -ab) & (anchors[:, 1] >= -ab) & (anchors[:, 2] < w + ab) & (anchors[:, 3] < h + ab))
+        samples = [assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg, self.means, self.stds, valid=inside[i]) for i in range(B)]
+        beta = self.loss_bbox_beta
         if cls.is_cuda:
             # both losses, over all images, in one forward and one backward launch (csrc/det_losses.hip)
             lc, lb = ops.rpn_loss(cls, reg, torch.stack([s_[6] for s_ in samples]), torch.stack([s_[7] for s_ in samples]),
-                                  torch.stack([s_[1] for s_ in samples]))
+                                  torch.stack([s_[1] for s_ in samples]), beta)
             return dict(loss_rpn_cls=lc * self.loss_cls_weight, loss_rpn_bbox=lb * self.loss_bbox_weight)
         loss_cls = loss_bbox = total = 0.
         for i in range(B):
@@ -402,7 +482,10 @@ class RPNHead(nn.Module):
             c_i, r_i = cls[i][idx].float(), reg[i][idx].float()
             lc = F.binary_cross_entropy_with_logits(c_i, is_pos.float(), reduction='none')     # fg -> 1, bg -> 0
             loss_cls = loss_cls + (lc * valid).sum()
-            loss_bbox = loss_bbox + ((r_i - tgt).abs() * is_pos[:, None]).sum()
+            d = (r_i - tgt).abs()
+            if beta > 0:
+                d = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
+            loss_bbox = loss_bbox + (d * is_pos[:, None]).sum()
             total = total + valid.sum()
         avg = total.clamp(min=1).float()                                                   # num_total_samples
         return dict(loss_rpn_cls=loss_cls / avg * self.loss_cls_weight, loss_rpn_bbox=loss_bbox / avg * self.loss_bbox_weight)
@@ -538,35 +621,63 @@ class SingleRoIExtractor(nn.Module):
 
 
 @HEADS.register_module()
-class Shared2FCBBoxHead(nn.Module):
-    """convfc_bbox_head.py:135 (2 shared fcs) + bbox_head.py loss/targets."""
+class ConvFCBBoxHead(nn.Module):
+    """convfc_bbox_head.py:9-178 (shared convs -> shared fcs -> fc_cls / fc_reg) + bbox_head.py loss / targets / decoding.
+    The swin configs use two instances: Shared2FCBBoxHead (Mask R-CNN) and 4 shared convs with SyncBN + 1 shared fc,
+    ``reg_decoded_bbox=True`` with GIoULoss (Cascade Mask R-CNN).  Separate cls / reg branches are not on this path."""
 
-    def __init__(self, in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=80, bbox_coder=None,
-                 reg_class_agnostic=False, loss_cls=None, loss_bbox=None, compute_dtype=torch.float32, **kwargs):
+    def __init__(self, num_shared_convs=0, num_shared_fcs=0, num_cls_convs=0, num_cls_fcs=0, num_reg_convs=0, num_reg_fcs=0,
+                 conv_out_channels=256, fc_out_channels=1024, conv_cfg=None, norm_cfg=None, with_avg_pool=False,
+                 in_channels=256, roi_feat_size=7, num_classes=80, bbox_coder=None, reg_class_agnostic=False,
+                 reg_decoded_bbox=False, loss_cls=None, loss_bbox=None, compute_dtype=torch.float32, **kwargs):
         super().__init__()
+        if num_cls_convs or num_cls_fcs or num_reg_convs or num_reg_fcs or with_avg_pool or conv_cfg is not None:
+            raise NotImplementedError("ConvFCBBoxHead: shared convs + shared fcs only (the swin configs)")
+        if num_shared_fcs < 1:
+            raise NotImplementedError("ConvFCBBoxHead: at least one shared fc (the swin configs use 1 or 2)")
         bc = dict(bbox_coder or {})
         self.means = tuple(bc.get('target_means', (0., 0., 0., 0.)))
         self.stds = tuple(bc.get('target_stds', (0.1, 0.1, 0.2, 0.2)))
-        if reg_class_agnostic or _cfg_get(loss_bbox, 'type', 'L1Loss') != 'L1Loss':
-            raise NotImplementedError("Shared2FCBBoxHead: class-specific L1 regression (mask_rcnn swin configs)")
+        lb_type = _cfg_get(loss_bbox, 'type', 'L1Loss')
+        if lb_type not in ('L1Loss', 'SmoothL1Loss', 'GIoULoss') or (lb_type == 'GIoULoss') != bool(reg_decoded_bbox):
+            raise NotImplementedError("bbox head: L1 / SmoothL1 on deltas, or GIoU with reg_decoded_bbox=True")
+        if _cfg_get(loss_cls, 'use_sigmoid', False):
+            raise NotImplementedError("bbox head: softmax cross entropy")
+        self.reg_beta = float(_cfg_get(loss_bbox, 'beta', 1.0)) if lb_type == 'SmoothL1Loss' else 0.0
+        self.giou_eps = float(_cfg_get(loss_bbox, 'eps', 1e-6))
+        self.reg_class_agnostic, self.reg_decoded_bbox = bool(reg_class_agnostic), bool(reg_decoded_bbox)
         self.num_classes = num_classes
         self.loss_cls_weight = _cfg_get(loss_cls, 'loss_weight', 1.0)
         self.loss_bbox_weight = _cfg_get(loss_bbox, 'loss_weight', 1.0)
         self.compute_dtype = compute_dtype
-        area = roi_feat_size * roi_feat_size
-        self.shared_fcs = nn.ModuleList([nn.Linear(in_channels * area, fc_out_channels),
-                                         nn.Linear(fc_out_channels, fc_out_channels)])
+        from .fpn import ConvModule
+        self.shared_convs = nn.ModuleList([ConvModule(in_channels if i == 0 else conv_out_channels, conv_out_channels, 3, padding=1,
+                                                      norm_cfg=norm_cfg) for i in range(num_shared_convs)])
+        last = (conv_out_channels if num_shared_convs else in_channels) * roi_feat_size * roi_feat_size
+        self.shared_fcs = nn.ModuleList([nn.Linear(last if i == 0 else fc_out_channels, fc_out_channels) for i in range(num_shared_fcs)])
         self.fc_cls = nn.Linear(fc_out_channels, num_classes + 1)
-        self.fc_reg = nn.Linear(fc_out_channels, 4 * num_classes)
+        self.fc_reg = nn.Linear(fc_out_channels, 4 if reg_class_agnostic else 4 * num_classes)
 
     def init_weights(self):
-        for m in self.shared_fcs:
+        for cm in self.shared_convs:                        # mmcv ConvModule.init_weights: kaiming (fan_out, relu), norm 1/0
+            nn.init.kaiming_normal_(cm.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+            if cm.conv.bias is not None:
+                nn.init.constant_(cm.conv.bias, 0)
+            if cm.with_norm:
+                nn.init.constant_(cm.bn.weight, 1); nn.init.constant_(cm.bn.bias, 0)
+        for m in self.shared_fcs:                           # convfc_bbox_head.py:116-122
             nn.init.xavier_uniform_(m.weight); nn.init.constant_(m.bias, 0)
-        nn.init.normal_(self.fc_cls.weight, 0, 0.01); nn.init.constant_(self.fc_cls.bias, 0)
+        nn.init.normal_(self.fc_cls.weight, 0, 0.01); nn.init.constant_(self.fc_cls.bias, 0)       # bbox_head.py:61-68
         nn.init.normal_(self.fc_reg.weight, 0, 0.001); nn.init.constant_(self.fc_reg.bias, 0)
 
     def forward(self, x):
         dt = self.compute_dtype
+        if len(self.shared_convs):
+            x = _cast(x, dt).contiguous(memory_format=torch.channels_last)
+            for cm in self.shared_convs:                    # ConvModule: conv -> norm -> ReLU
+                x = _conv(x, cm.conv, dt, padding=1, relu=not cm.with_norm)
+                if cm.with_norm:
+                    x = _bn_act(x, cm, self.training, relu=True)
         x = _cast(x.flatten(1), dt)                 # (K, C*7*7) in the reference's (C,7,7) order
         for fc in self.shared_fcs:
             x = F.relu(F.linear(x, _cast(fc.weight, dt), _cast(fc.bias, dt)), inplace=True)
@@ -574,31 +685,67 @@ class Shared2FCBBoxHead(nn.Module):
         reg = F.linear(x, _cast(self.fc_reg.weight, dt), _cast(self.fc_reg.bias, dt))
         return cls, reg
 
-    def loss(self, cls_score, bbox_pred, labels, bbox_targets, pos_mask, valid=None):
-        """bbox_head.py loss: CE over the sampled RoIs (avg_factor = their count), class-specific L1 over the
-        positives divided by the number of samples.  ``valid`` masks the unused slots of a fixed-size sample."""
+    def loss(self, cls_score, bbox_pred, labels, bbox_targets, pos_mask, valid=None, rois=None):
+        """bbox_head.py:188-238: CE over the sampled RoIs (avg_factor = their count); on the positives -- divided by the
+        number of samples -- L1 / SmoothL1 between the labelled (or class-agnostic) deltas and the encoded targets, or
+        (reg_decoded_bbox) GIoU between the boxes decoded against ``rois`` (n,4) and the gt boxes in ``bbox_targets``.
+        ``valid`` masks the unused slots of a fixed-size sample."""
         n = cls_score.size(0)
         if valid is None:
             valid = torch.ones(n, dtype=torch.bool, device=cls_score.device)
+        if self.reg_decoded_bbox and rois is None:
+            raise ValueError("reg_decoded_bbox=True: loss() needs the sampled rois")
         if cls_score.is_cuda and n > 0:
             flags = valid.to(torch.uint8) + 2 * (pos_mask & valid).to(torch.uint8)
-            lc, acc, lb = ops.bbox_loss(cls_score, bbox_pred, labels, bbox_targets, flags, self.num_classes)
+            giou = (rois[:, -4:], self.means, self.stds, self.giou_eps) if self.reg_decoded_bbox else None
+            lc, acc, lb = ops.bbox_loss(cls_score, bbox_pred, labels, bbox_targets, flags, self.num_classes,
+                                        self.reg_class_agnostic, self.reg_beta, giou)
             return dict(loss_cls=lc * self.loss_cls_weight, acc=acc, loss_bbox=lb * self.loss_bbox_weight)
         cls_score, bbox_pred = cls_score.float(), bbox_pred.float()
         nv = valid.sum().clamp(min=1).float()
         ce = F.cross_entropy(cls_score, labels, reduction='none')
         loss_cls = (ce * valid).sum() / nv
         acc = (((cls_score.argmax(1) == labels) & valid).sum() / nv) * 100
-        pred = bbox_pred.view(n, -1, 4)[torch.arange(n, device=labels.device), labels.clamp(max=self.num_classes - 1)]
-        loss_bbox = ((pred - bbox_targets).abs() * pos_mask[:, None]).sum() / nv
+        if self.reg_class_agnostic:
+            pred = bbox_pred.view(n, 4)
+        else:
+            pred = bbox_pred.view(n, -1, 4)[torch.arange(n, device=labels.device), labels.clamp(max=self.num_classes - 1)]
+        pos = (pos_mask & valid).float()
+        if self.reg_decoded_bbox:
+            dec = delta2bbox(rois[:, -4:].float(), pred, self.means, self.stds)                  # bbox_head.py:215-216
+            per = giou_loss_elem(dec, bbox_targets.float(), self.giou_eps)
+            loss_bbox = (per * pos).sum() / nv
+        else:
+            d = (pred - bbox_targets).abs()
+            if self.reg_beta > 0:
+                d = torch.where(d < self.reg_beta, 0.5 * d * d / self.reg_beta, d - 0.5 * self.reg_beta)
+            loss_bbox = (d * pos[:, None]).sum() / nv
         return dict(loss_cls=loss_cls * self.loss_cls_weight, acc=acc, loss_bbox=loss_bbox * self.loss_bbox_weight)
 
+    @torch.no_grad()
+    def regress_by_class(self, rois, labels, cls_score, bbox_pred, img_shape):
+        """bbox_head.py:409-436 with CascadeRoIHead's label choice: ``labels`` None (testing) or background entries take
+        argmax(cls_score[:, :-1]) (cascade_roi_head.py:274-281, :316-317).  rois (n,4) -> refined (n,4)."""
+        nc = self.num_classes
+        if rois.is_cuda:
+            return ops.regress_by_class(rois, labels, cls_score, bbox_pred, nc, self.reg_class_agnostic, self.means, self.stds,
+                                        img_shape)
+        am = cls_score[:, :nc].float().argmax(1)
+        lab = am if labels is None else torch.where((labels >= nc) | (labels < 0), am, labels)
+        d = bbox_pred.float()
+        if not self.reg_class_agnostic:
+            d = d.view(d.size(0), nc, 4)[torch.arange(d.size(0), device=d.device), lab]
+        return delta2bbox(rois.float(), d, self.means, self.stds, max_shape=img_shape)
 
     @torch.no_grad()
     def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
-        """bbox_head.py:270-373 for one image: rois (n,5), class-specific deltas (n, 4*num_classes)."""
+        """bbox_head.py:270-373 for one image: rois (n,5), deltas (n, 4*num_classes) or class-agnostic (n,4);
+        ``cls_score`` may be a list of per-stage scores, which are averaged (:300-301)."""
+        if isinstance(cls_score, (list, tuple)):
+            cls_score = sum(c.float() for c in cls_score) / float(len(cls_score))
         scores = F.softmax(cls_score.float(), dim=-1)
-        n, nc = scores.size(0), self.num_classes
+        n = scores.size(0)
+        nc = 1 if self.reg_class_agnostic else self.num_classes
         deltas = bbox_pred.float().reshape(n * nc, 4)
         boxes = rois[:, 1:5].float()[:, None, :].expand(n, nc, 4).reshape(n * nc, 4)
         dec = ops.delta2bbox if boxes.is_cuda else delta2bbox
@@ -608,6 +755,22 @@ class Shared2FCBBoxHead(nn.Module):
         if cfg is None:
             return bboxes, scores
         return multiclass_nms(bboxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+
+
+@HEADS.register_module()
+class Shared2FCBBoxHead(ConvFCBBoxHead):
+    """convfc_bbox_head.py:181-192."""
+
+    def __init__(self, fc_out_channels=1024, *args, **kwargs):
+        super().__init__(*args, num_shared_convs=0, num_shared_fcs=2, fc_out_channels=fc_out_channels, **kwargs)
+
+
+@HEADS.register_module()
+class Shared4Conv1FCBBoxHead(ConvFCBBoxHead):
+    """convfc_bbox_head.py:195-205."""
+
+    def __init__(self, fc_out_channels=1024, *args, **kwargs):
+        super().__init__(*args, num_shared_convs=4, num_shared_fcs=1, fc_out_channels=fc_out_channels, **kwargs)
 
 
 @HEADS.register_module()
@@ -670,9 +833,10 @@ class FCNMaskHead(nn.Module):
 
 
     @torch.no_grad()
-    def get_seg_masks(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale):
+    def get_seg_masks(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale, is_prob=False):
         """fcn_mask_head.py:169-300: per-class lists of (img_h, img_w) bool numpy masks.  Sigmoid, class select,
-        bilinear paste into the box and the `mask_thr_binary` test run as one HIP kernel (ops.paste_masks)."""
+        bilinear paste into the box and the `mask_thr_binary` test run as one HIP kernel (ops.paste_masks).
+        ``is_prob``: mask_pred already holds probabilities (the reference's ndarray input, :209-213)."""
         import numpy as np
         cls_segms = [[] for _ in range(self.num_classes)]
         bboxes = det_bboxes[:, :4].float()
@@ -688,11 +852,84 @@ class FCNMaskHead(nn.Module):
         n = mask_pred.size(0)
         if n == 0:
             return cls_segms
-        im_mask = ops.paste_masks(mask_pred, det_labels, bboxes, img_h, img_w, thr).cpu().numpy()
+        im_mask = ops.paste_masks(mask_pred, det_labels, bboxes, img_h, img_w, thr, is_prob).cpu().numpy()
         labels = det_labels.cpu().numpy()
         for i in range(n):
             cls_segms[labels[i]].append(im_mask[i])
         return cls_segms
+
+
+def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox_roi_extractor, bbox_head, mask_roi_extractor,
+                     mask_head):
+    """One R-CNN stage of training (standard_roi_head.py:70-131; cascade_roi_head.py:228-270 runs it per stage) with
+    fixed-size samples.  ``proposal_list[i]`` is ``dets (n,4|5)`` (the reference's form) or ``(dets (max,4|5), valid (max,))``
+    from the static RPN / refinement path.  Every tensor below has a shape known on the host (512 RoIs and 128 mask slots per
+    image); unused slots are masked out of the losses and skipped by RoIAlign, so the step needs no device->host
+    synchronisation.  gt_masks: list of (G_i, H, W) uint8/bool tensors on the device.
+    Returns (losses, state) -- state carries what CascadeRoIHead's refinement needs."""
+    a, s = cfg['assigner'], cfg['sampler']
+    nimg = len(proposal_list)
+    nc = bbox_head.num_classes
+    num, npos_max = s['num'], int(s['num'] * s['pos_fraction'])
+    roi_l, lab_l, tgt_l, pos_l, val_l, isgt_l = [], [], [], [], [], []
+    m_roi, m_gt, m_lab, m_val = [], [], [], []
+    for i in range(nimg):
+        p = proposal_list[i]
+        dets, pvalid = (p if isinstance(p, tuple) else (p, torch.ones(p.size(0), dtype=torch.bool, device=p.device)))
+        props = dets[:, :4]
+        g = gt_bboxes[i].size(0)
+        if s.get('add_gt_as_proposals', True):
+            props = torch.cat([gt_bboxes[i], props], 0)
+            pvalid = torch.cat([torch.ones(g, dtype=torch.bool, device=props.device), pvalid], 0)
+        lead = g if s.get('add_gt_as_proposals', True) else 0
+        boxes, t_i, l_i, gt_ind, is_pos, valid, inds, _ = assign_and_sample(
+            props, gt_bboxes[i], a, s, bbox_head.means, bbox_head.stds, gt_labels[i], lead, pvalid, bg_label=nc)
+        if bbox_head.reg_decoded_bbox:                 # bbox_head.py:174-175: the targets are the matched gt boxes themselves
+            t_i = gt_bboxes[i][gt_ind] if g > 0 else torch.zeros_like(boxes)
+        roi_l.append(boxes); lab_l.append(l_i); tgt_l.append(t_i); pos_l.append(is_pos); val_l.append(valid)
+        isgt_l.append(is_pos & (inds < lead))         # SamplingResult.pos_is_gt
+        k = min(npos_max, num)                                    # positives come first in the sample
+        m_roi.append(boxes[:k]); m_gt.append(gt_ind[:k]); m_lab.append(l_i[:k].clamp(max=nc - 1)); m_val.append(is_pos[:k])
+    losses = {}
+    rois = bbox2roi(roi_l)
+    valid = torch.cat(val_l)
+    labels = torch.cat(lab_l)
+    feats = x[:bbox_roi_extractor.num_inputs]
+    bbox_feats = bbox_roi_extractor(feats, rois, valid=valid)                      # HIP RoIAlign, all levels at once
+    cls_score, bbox_pred = bbox_head(bbox_feats)
+    losses.update(bbox_head.loss(cls_score, bbox_pred, labels, torch.cat(tgt_l), torch.cat(pos_l), valid, rois=rois))
+    state = dict(rois=roi_l, labels=labels, cls_score=cls_score, bbox_pred=bbox_pred, valid=val_l, pos_is_gt=isgt_l)
+    if mask_head is not None:
+        pos_rois = bbox2roi(m_roi)
+        mvalid = torch.cat(m_val)
+        mask_feats = mask_roi_extractor(x[:mask_roi_extractor.num_inputs], pos_rois, valid=mvalid)
+        mask_pred = mask_head(mask_feats)
+        size = cfg.get('mask_size', 28)
+        # mask_target.py:66-122 on the device.  When every image has gt masks of one size, all images go through ONE
+        # RoIAlign launch (the gt masks stacked along the batch axis, the RoI's batch index offset by its image's
+        # first mask): the per-image launches are latency-bound and would run back to back.
+        same = (all(g_.size(0) > 0 for g_ in gt_masks) and all(r_.size(0) > 0 for r_ in m_roi)
+                and all(g_.shape[1:] == gt_masks[0].shape[1:] for g_ in gt_masks))
+        if same:
+            m = torch.cat(list(gt_masks), 0).to(torch.bfloat16)[:, None]      # 0/1 exact in bf16
+            offs, o_ = [], 0
+            for g_ in gt_masks:
+                offs.append(o_); o_ += g_.size(0)
+            r = torch.cat([torch.cat([(m_gt[i] + offs[i]).to(m_roi[i].dtype)[:, None], m_roi[i]], 1) for i in range(nimg)], 0)
+            t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)        # structures.py:353-354
+            tg = [(t[:, 0] >= 0.5).float()]
+        else:
+            tg = []
+            for i in range(nimg):
+                if m_roi[i].size(0) == 0 or gt_masks[i].size(0) == 0:
+                    tg.append(m_roi[i].new_zeros((m_roi[i].size(0), size, size)))
+                    continue
+                m = gt_masks[i].to(torch.bfloat16)[:, None].contiguous()
+                r = torch.cat([m_gt[i].to(m_roi[i].dtype)[:, None], m_roi[i]], 1)
+                t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)
+                tg.append((t[:, 0] >= 0.5).float())
+        losses.update(mask_head.loss(mask_pred, torch.cat(tg), torch.cat(m_lab), mvalid))
+    return losses, state
 
 
 @HEADS.register_module()
@@ -712,69 +949,9 @@ class StandardRoIHead(nn.Module):
             self.mask_head.init_weights()
 
     def forward_train(self, x, proposal_list, gt_bboxes, gt_labels, gt_masks):
-        """standard_roi_head.py:70-131 with fixed-size samples.  ``proposal_list[i]`` is either ``dets (n,5)`` (the
-        reference's form) or ``(dets (max,5), valid (max,))`` from the static RPN path.  Every tensor below has a
-        shape known on the host (512 RoIs and 128 mask slots per image); unused slots are masked out of the losses
-        and skipped by RoIAlign, so the step needs no device->host synchronisation.
-        gt_masks: list of (G_i, H, W) uint8/bool tensors on the device."""
-        cfg = self.train_cfg
-        a, s = cfg['assigner'], cfg['sampler']
-        nimg = len(proposal_list)
-        nc = self.bbox_head.num_classes
-        num, npos_max = s['num'], int(s['num'] * s['pos_fraction'])
-        roi_l, lab_l, tgt_l, pos_l, val_l = [], [], [], [], []
-        m_roi, m_gt, m_lab, m_val = [], [], [], []
-        for i in range(nimg):
-            p = proposal_list[i]
-            dets, pvalid = (p if isinstance(p, tuple) else (p, torch.ones(p.size(0), dtype=torch.bool, device=p.device)))
-            props = dets[:, :4]
-            g = gt_bboxes[i].size(0)
-            if s.get('add_gt_as_proposals', True):
-                props = torch.cat([gt_bboxes[i], props], 0)
-                pvalid = torch.cat([torch.ones(g, dtype=torch.bool, device=props.device), pvalid], 0)
-            lead = g if s.get('add_gt_as_proposals', True) else 0
-            boxes, t_i, l_i, gt_ind, is_pos, valid, _, _ = assign_and_sample(
-                props, gt_bboxes[i], a, s, self.bbox_head.means, self.bbox_head.stds, gt_labels[i], lead, pvalid, bg_label=nc)
-            roi_l.append(boxes); lab_l.append(l_i); tgt_l.append(t_i); pos_l.append(is_pos); val_l.append(valid)
-            k = min(npos_max, num)                                    # positives come first in the sample
-            m_roi.append(boxes[:k]); m_gt.append(gt_ind[:k]); m_lab.append(l_i[:k].clamp(max=nc - 1)); m_val.append(is_pos[:k])
-        losses = {}
-        rois = bbox2roi(roi_l)
-        valid = torch.cat(val_l)
-        feats = x[:self.bbox_roi_extractor.num_inputs]
-        bbox_feats = self.bbox_roi_extractor(feats, rois, valid=valid)                      # HIP RoIAlign, all levels at once
-        cls_score, bbox_pred = self.bbox_head(bbox_feats)
-        losses.update(self.bbox_head.loss(cls_score, bbox_pred, torch.cat(lab_l), torch.cat(tgt_l), torch.cat(pos_l), valid))
-        if self.mask_head is not None:
-            pos_rois = bbox2roi(m_roi)
-            mvalid = torch.cat(m_val)
-            mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois, valid=mvalid)
-            mask_pred = self.mask_head(mask_feats)
-            size = cfg.get('mask_size', 28)
-            # mask_target.py:66-122 on the device.  When every image has gt masks of one size, all images go through ONE
-            # RoIAlign launch (the gt masks stacked along the batch axis, the RoI's batch index offset by its image's
-            # first mask): the per-image launches are latency-bound and would run back to back.
-            same = (all(g_.size(0) > 0 for g_ in gt_masks) and all(r_.size(0) > 0 for r_ in m_roi)
-                    and all(g_.shape[1:] == gt_masks[0].shape[1:] for g_ in gt_masks))
-            if same:
-                m = torch.cat(list(gt_masks), 0).to(torch.bfloat16)[:, None]      # 0/1 exact in bf16
-                offs, o_ = [], 0
-                for g_ in gt_masks:
-                    offs.append(o_); o_ += g_.size(0)
-                r = torch.cat([torch.cat([(m_gt[i] + offs[i]).to(m_roi[i].dtype)[:, None], m_roi[i]], 1) for i in range(nimg)], 0)
-                t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)        # structures.py:353-354
-                tg = [(t[:, 0] >= 0.5).float()]
-            else:
-                tg = []
-                for i in range(nimg):
-                    if m_roi[i].size(0) == 0 or gt_masks[i].size(0) == 0:
-                        tg.append(m_roi[i].new_zeros((m_roi[i].size(0), size, size)))
-                        continue
-                    m = gt_masks[i].to(torch.bfloat16)[:, None].contiguous()
-                    r = torch.cat([m_gt[i].to(m_roi[i].dtype)[:, None], m_roi[i]], 1)
-                    t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)
-                    tg.append((t[:, 0] >= 0.5).float())
-            losses.update(self.mask_head.loss(mask_pred, torch.cat(tg), torch.cat(m_lab), mvalid))
+        """standard_roi_head.py:70-131 with fixed-size samples (see _roi_stage_train)."""
+        losses, _ = _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, self.train_cfg, self.bbox_roi_extractor,
+                                     self.bbox_head, self.mask_roi_extractor, self.mask_head)
         return losses
 
 
@@ -810,6 +987,120 @@ class StandardRoIHead(nn.Module):
             segm_results.append(self.mask_head.get_seg_masks(mask_pred, mb, det_labels, cfg, meta['ori_shape'],
                                                              meta['scale_factor'], rescale))
         if self.mask_head is None:
+            return bbox_results
+        return list(zip(bbox_results, segm_results))
+
+
+@HEADS.register_module()
+class CascadeRoIHead(nn.Module):
+    """cascade_roi_head.py:13-420: ``num_stages`` bbox heads (and mask heads) applied in sequence, each trained on the
+    boxes refined by the previous one, with per-stage assigner thresholds (train_cfg is a list) and loss weights."""
+
+    def __init__(self, num_stages, stage_loss_weights, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None,
+                 mask_head=None, shared_head=None, train_cfg=None, test_cfg=None, compute_dtype=torch.float32):
+        super().__init__()
+        assert bbox_roi_extractor is not None and bbox_head is not None
+        assert shared_head is None, 'Shared head is not supported in Cascade RCNN anymore'
+        self.num_stages, self.stage_loss_weights = num_stages, list(stage_loss_weights)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+        def per_stage(c):
+            c = c if isinstance(c, (list, tuple)) else [c for _ in range(num_stages)]
+            assert len(c) == num_stages
+            return c
+        self.bbox_roi_extractor = nn.ModuleList([build_roi_extractor(c) for c in per_stage(bbox_roi_extractor)])
+        self.bbox_head = nn.ModuleList([build_from_cfg(c, HEADS, dict(compute_dtype=compute_dtype)) for c in per_stage(bbox_head)])
+        self.mask_head = self.mask_roi_extractor = None
+        self.share_roi_extractor = False
+        if mask_head is not None:
+            self.mask_head = nn.ModuleList([build_from_cfg(c, HEADS, dict(compute_dtype=compute_dtype)) for c in per_stage(mask_head)])
+            if mask_roi_extractor is not None:
+                self.mask_roi_extractor = nn.ModuleList([build_roi_extractor(c) for c in per_stage(mask_roi_extractor)])
+            else:                                                    # cascade_roi_head.py:87-89
+                self.share_roi_extractor = True
+                self.mask_roi_extractor = self.bbox_roi_extractor
+        if train_cfg is not None:
+            assert len(train_cfg) == num_stages
+
+    @property
+    def with_mask(self):
+        return self.mask_head is not None
+
+    def init_weights(self, pretrained=None):
+        for i in range(self.num_stages):
+            self.bbox_head[i].init_weights()
+            if self.with_mask:
+                self.mask_head[i].init_weights()
+
+    def forward_train(self, x, proposal_list, gt_bboxes, gt_labels, gt_masks, img_shapes=None):
+        """cascade_roi_head.py:200-284.  Each stage is _roi_stage_train (fixed-size samples, no host sync); between
+        stages the sampled RoIs are regressed by their (gt or predicted) class on the device and the ones that were gt
+        boxes are dropped through the validity mask (bbox_head.py:376-407)."""
+        losses = {}
+        for i in range(self.num_stages):
+            lw = self.stage_loss_weights[i]
+            head = self.bbox_head[i]
+            st_losses, st = _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, self.train_cfg[i],
+                                             self.bbox_roi_extractor[i], head,
+                                             self.mask_roi_extractor[i] if self.with_mask else None,
+                                             self.mask_head[i] if self.with_mask else None)
+            for name, value in st_losses.items():
+                losses[f's{i}.{name}'] = value * lw if 'loss' in name else value
+            if i < self.num_stages - 1:
+                with torch.no_grad():
+                    nimg = len(st['rois'])
+                    per = st['rois'][0].size(0)
+                    shapes = img_shapes if img_shapes is not None else [None] * nimg
+                    if all(tuple(sh[:2]) == tuple(shapes[0][:2]) for sh in shapes) if shapes[0] is not None else True:
+                        new = head.regress_by_class(torch.cat(st['rois']), st['labels'], st['cls_score'], st['bbox_pred'], shapes[0])
+                        new = list(new.split(per))
+                    else:
+                        new = [head.regress_by_class(st['rois'][j], st['labels'][j * per:(j + 1) * per],
+                                                     st['cls_score'][j * per:(j + 1) * per], st['bbox_pred'][j * per:(j + 1) * per],
+                                                     shapes[j]) for j in range(nimg)]
+                    proposal_list = [(new[j], st['valid'][j] & ~st['pos_is_gt'][j]) for j in range(nimg)]
+        return losses
+
+    # ---- test time (cascade_roi_head.py:286-411) ----
+    @torch.no_grad()
+    def simple_test(self, x, proposal_list, img_metas, rescale=False):
+        cfg = self.test_cfg
+        nc = self.bbox_head[-1].num_classes
+        bbox_results, segm_results = [], []
+        for i, (props, meta) in enumerate(zip(proposal_list, img_metas)):
+            rois = bbox2roi([props[:, :4]])
+            rois[:, 0] = i
+            if rois.size(0) == 0:
+                det_bboxes, det_labels = rois.new_zeros((0, 5)), rois.new_zeros((0,), dtype=torch.long)
+            else:
+                ms_scores = []
+                for st in range(self.num_stages):
+                    ext = self.bbox_roi_extractor[st]
+                    cls_score, bbox_pred = self.bbox_head[st](ext(x[:ext.num_inputs], rois))
+                    ms_scores.append(cls_score)
+                    if st < self.num_stages - 1:                          # :315-323
+                        ref = self.bbox_head[st].regress_by_class(rois[:, 1:], None, cls_score, bbox_pred, meta['img_shape'])
+                        rois = torch.cat([rois[:, :1], ref], 1)
+                det_bboxes, det_labels = self.bbox_head[-1].get_bboxes(rois, ms_scores, bbox_pred, meta['img_shape'],
+                                                                       meta['scale_factor'], rescale, cfg)
+            bbox_results.append(bbox2result(det_bboxes, det_labels, nc))
+            if not self.with_mask:
+                continue
+            if det_bboxes.size(0) == 0:
+                segm_results.append([[] for _ in range(self.mask_head[-1].num_classes)])
+                continue
+            mb = det_bboxes[:, :4]
+            if rescale:
+                mb = mb * mb.new_tensor(_sf4(meta['scale_factor']))
+            mask_rois = torch.cat([mb.new_full((mb.size(0), 1), i), mb], 1)
+            prob = 0.
+            for st in range(self.num_stages):                               # merge_aug_masks without flips: the mean
+                ext = self.mask_roi_extractor[st]
+                prob = prob + self.mask_head[st](ext(x[:ext.num_inputs], mask_rois)).float().sigmoid()
+            prob = prob / float(self.num_stages)
+            segm_results.append(self.mask_head[-1].get_seg_masks(prob, mb, det_labels, cfg, meta['ori_shape'],
+                                                                 meta['scale_factor'], rescale, is_prob=True))
+        if not self.with_mask:
             return bbox_results
         return list(zip(bbox_results, segm_results))
 
@@ -852,7 +1143,10 @@ class MaskRCNN(nn.Module):
         losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_shapes))
         proposal_cfg = _cfg_get(self.train_cfg, 'rpn_proposal', _cfg_get(self.test_cfg, 'rpn'))
         proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_shapes, proposal_cfg, static=True)
-        losses.update(self.roi_head.forward_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks))
+        if isinstance(self.roi_head, CascadeRoIHead):
+            losses.update(self.roi_head.forward_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, img_shapes))
+        else:
+            losses.update(self.roi_head.forward_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks))
         return losses
 
     @torch.no_grad()
@@ -867,6 +1161,11 @@ class MaskRCNN(nn.Module):
         """base.py:185-218 without the per-scalar all-reduce/.item(): returns (loss tensor, dict of tensors)."""
         total = sum(v for k, v in losses.items() if 'loss' in k)
         return total, losses
+
+
+@DETECTORS.register_module()
+class CascadeRCNN(MaskRCNN):
+    """cascade_rcnn.py: TwoStageDetector with a CascadeRoIHead (configs/_base_/models/cascade_mask_rcnn_swin_fpn.py)."""
 
 
 def build_detector(cfg, train_cfg=None, test_cfg=None, compute_dtype=torch.float32):

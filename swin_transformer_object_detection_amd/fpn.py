@@ -17,17 +17,32 @@ from .registry import NECKS
 
 
 class ConvModule(nn.Module):
-    """mmcv.cnn.ConvModule with norm_cfg=None and act_cfg=None: a biased Conv2d stored as ``.conv``."""
+    """mmcv.cnn.ConvModule as the swin configs use it: a Conv2d stored as ``.conv`` and, with
+    ``norm_cfg=dict(type='BN'|'SyncBN')``, a bias-free conv followed by a BatchNorm stored as ``.bn`` (mmcv names the norm
+    layer 'bn' for both types; bias='auto' drops the conv bias when a norm follows).  This module only HOLDS the parameters
+    (state_dict keys ``conv.weight``, ``conv.bias`` / ``bn.weight``, ``bn.bias``, ``bn.running_mean``, ...): the callers
+    run conv / norm / activation on the HIP kernels.  ``sync`` records whether statistics span the ranks (SyncBN)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, conv_cfg=None, norm_cfg=None,
                  act_cfg=None, inplace=False):
         super().__init__()
-        if norm_cfg is not None or act_cfg is not None or conv_cfg is not None:
-            raise NotImplementedError("swin configs build FPN convs without norm/activation/conv_cfg")
-        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=True)
+        if act_cfg is not None or conv_cfg is not None:
+            raise NotImplementedError("ConvModule: plain Conv2d; the activation is applied by the caller")
+        self.with_norm = norm_cfg is not None
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=not self.with_norm)
+        self.sync = False
+        if self.with_norm:
+            ntype = norm_cfg.get('type')
+            if ntype not in ('BN', 'SyncBN'):
+                raise NotImplementedError(f"ConvModule: norm type {ntype!r} (swin configs: SyncBN)")
+            self.sync = ntype == 'SyncBN'
+            self.bn = nn.BatchNorm2d(out_channels, eps=norm_cfg.get('eps', 1e-5), momentum=norm_cfg.get('momentum', 0.1))
+            for p_ in self.bn.parameters():
+                p_.requires_grad = norm_cfg.get('requires_grad', True)
 
     def forward(self, x):
-        return self.conv(x)
+        x = self.conv(x)
+        return self.bn(x) if self.with_norm else x
 
 
 def _to_cl(x, dtype):
@@ -47,6 +62,8 @@ class FPN(nn.Module):
             raise NotImplementedError("only the Mask R-CNN form (extra levels by max-pool) is on the Swin path")
         if upsample_cfg.get('mode', 'nearest') != 'nearest' or 'scale_factor' in upsample_cfg:
             raise NotImplementedError("upsample_cfg must be dict(mode='nearest')")
+        if norm_cfg is not None or act_cfg is not None or conv_cfg is not None:
+            raise NotImplementedError("swin configs build FPN convs without norm/activation/conv_cfg")
         self.in_channels, self.out_channels = in_channels, out_channels
         self.num_ins, self.num_outs = len(in_channels), num_outs
         assert num_outs >= self.num_ins

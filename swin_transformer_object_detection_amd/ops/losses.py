@@ -21,13 +21,14 @@ def _dt(t):
 
 class _RPNLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cls, reg, inds, flags, targets):
+    def forward(ctx, cls, reg, inds, flags, targets, beta):
         cls, reg = cls.contiguous(), reg.contiguous()
         B, A = cls.shape
         S = inds.numel() // B
         out = torch.empty(3, device=cls.device, dtype=torch.float32)
-        call("det_rpn_loss_fwd", _p(cls), _p(reg), B, A, S, _p(inds), _p(flags), _p(targets), _p(out), _dt(cls), _s())
+        call("det_rpn_loss_fwd", _p(cls), _p(reg), B, A, S, _p(inds), _p(flags), _p(targets), beta, _p(out), _dt(cls), _s())
         ctx.save_for_backward(cls, reg, inds, flags, targets, out)
+        ctx.beta = beta
         ctx.mark_non_differentiable(inds, flags)
         return out[0], out[1]
 
@@ -38,46 +39,64 @@ class _RPNLoss(torch.autograd.Function):
         S = inds.numel() // B
         g = torch.stack([g_cls if g_cls is not None else out.new_zeros(()), g_bbox if g_bbox is not None else out.new_zeros(())]).float()
         dcls, dreg = torch.zeros_like(cls), torch.zeros_like(reg)
-        call("det_rpn_loss_bwd", _p(cls), _p(reg), B, A, S, _p(inds), _p(flags), _p(targets), _p(out), _p(g), _p(dcls), _p(dreg),
-             _dt(cls), _s())
-        return dcls, dreg, None, None, None
+        call("det_rpn_loss_bwd", _p(cls), _p(reg), B, A, S, _p(inds), _p(flags), _p(targets), ctx.beta, _p(out), _p(g), _p(dcls),
+             _p(dreg), _dt(cls), _s())
+        return dcls, dreg, None, None, None, None
 
 
-def rpn_loss(cls, reg, inds, flags, targets):
+def rpn_loss(cls, reg, inds, flags, targets, beta=0.0):
     """cls (B,A) logits, reg (B,A,4) deltas; inds / flags (B,S) and targets (B,S,4) of the sampled anchors ->
-    (loss_cls, loss_bbox): sums over the batch's samples divided by their count (anchor_head.py:375-434, 485-493)."""
-    return _RPNLoss.apply(cls, reg, inds.contiguous(), flags.contiguous(), targets.contiguous().float())
+    (loss_cls, loss_bbox): sums over the batch's samples divided by their count (anchor_head.py:375-434, 485-493).
+    ``beta`` 0: L1Loss; > 0: SmoothL1Loss(beta)."""
+    return _RPNLoss.apply(cls, reg, inds.contiguous(), flags.contiguous(), targets.contiguous().float(), float(beta))
+
+
+def _f4(v):
+    return (ctypes.c_float * 4)(*[float(x) for x in v])
 
 
 class _BBoxLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cls, bbox, labels, targets, flags, num_classes):
+    def forward(ctx, cls, bbox, labels, targets, flags, num_classes, reg):
         cls, bbox = cls.contiguous(), bbox.contiguous()
         n = cls.size(0)
+        mode, agnostic, beta, eps, rois, means, stds = reg
+        if bbox.numel() != n * (4 if agnostic else 4 * num_classes):
+            raise SwinHipError(f"bbox_loss: bbox_pred has {bbox.numel()} elements for {n} RoIs (class_agnostic={agnostic})")
         out = torch.empty(4, device=cls.device, dtype=torch.float32)
         lse = torch.empty(n, device=cls.device, dtype=torch.float32)
-        call("det_bbox_loss_fwd", _p(cls), _p(bbox), n, num_classes, _p(labels), _p(targets), _p(flags), _p(out), _p(lse), _dt(cls),
-             _s())
-        ctx.save_for_backward(cls, bbox, labels, targets, flags, out, lse)
+        ctx.reg_args = (mode, 1 if agnostic else 0, beta, eps, _p(rois), _f4(means) if means is not None else None,
+                        _f4(stds) if stds is not None else None)
+        call("det_bbox_loss_fwd", _p(cls), _p(bbox), n, num_classes, _p(labels), _p(targets), _p(flags), *ctx.reg_args, _p(out),
+             _p(lse), _dt(cls), _s())
+        ctx.save_for_backward(cls, bbox, labels, targets, flags, out, lse, rois)
         ctx.nc = num_classes
         return out[0], out[1], out[2]
 
     @staticmethod
     def backward(ctx, g_cls, g_acc, g_bbox):
-        cls, bbox, labels, targets, flags, out, lse = ctx.saved_tensors
+        cls, bbox, labels, targets, flags, out, lse, rois = ctx.saved_tensors
         n = cls.size(0)
         z = out.new_zeros(())
         g = torch.stack([g_cls if g_cls is not None else z, z, g_bbox if g_bbox is not None else z, z]).float()
         dcls, dbbox = torch.empty_like(cls), torch.empty_like(bbox)
-        call("det_bbox_loss_bwd", _p(cls), _p(bbox), n, ctx.nc, _p(labels), _p(targets), _p(flags), _p(out), _p(lse), _p(g), _p(dcls),
-             _p(dbbox), _dt(cls), _s())
-        return dcls, dbbox, None, None, None, None
+        call("det_bbox_loss_bwd", _p(cls), _p(bbox), n, ctx.nc, _p(labels), _p(targets), _p(flags), *ctx.reg_args, _p(out), _p(lse),
+             _p(g), _p(dcls), _p(dbbox), _dt(cls), _s())
+        return dcls, dbbox, None, None, None, None, None
 
 
-def bbox_loss(cls_score, bbox_pred, labels, targets, flags, num_classes):
-    """(loss_cls, acc %, loss_bbox) of BBoxHead.loss for a fixed-size sample (flags: bit 0 used, bit 1 positive)."""
+def bbox_loss(cls_score, bbox_pred, labels, targets, flags, num_classes, class_agnostic=False, beta=0.0, giou=None):
+    """(loss_cls, acc %, loss_bbox) of BBoxHead.loss for a fixed-size sample (flags: bit 0 used, bit 1 positive).
+    Regression term: L1 (beta 0) / SmoothL1(beta) between the labelled (or class-agnostic) deltas and ``targets``; or,
+    with ``giou=(rois (n,4), means, stds, eps)``, GIoU between the DECODED boxes and the gt boxes in ``targets``
+    (reg_decoded_bbox=True, bbox_head.py:215-216)."""
+    if giou is None:
+        reg = (0, bool(class_agnostic), float(beta), 1e-6, None, None, None)
+    else:
+        rois, means, stds, eps = giou
+        reg = (2, bool(class_agnostic), 0.0, float(eps), rois.contiguous().float(), tuple(means), tuple(stds))
     return _BBoxLoss.apply(cls_score, bbox_pred, labels.contiguous(), targets.contiguous().float(), flags.contiguous(),
-                           int(num_classes))
+                           int(num_classes), reg)
 
 
 class _MaskLoss(torch.autograd.Function):

@@ -108,10 +108,33 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     return out
 
 
-def paste_masks(mask_logits, labels, boxes, img_h, img_w, thr):
+def regress_by_class(rois, labels, cls_score, bbox_pred, num_classes, class_agnostic, means, stds, max_shape=None):
+    """BBoxHead.regress_by_class (bbox_head.py:409-436) with CascadeRoIHead's label choice (cascade_roi_head.py:274-284,
+    :316-323): rois (n,4); labels (n,) int64 or None -- None / background labels take argmax(cls_score[:, :-1]);
+    returns the (n,4) refined boxes clipped to ``max_shape``."""
+    if not rois.is_cuda:
+        raise SwinHipError("regress_by_class: GPU tensors only")
+    from .._lib import SWIN_BF16, SWIN_F32
+    c, b = cls_score.detach().contiguous(), bbox_pred.detach().contiguous()
+    if c.dtype != b.dtype or c.dtype not in (torch.float32, torch.bfloat16):
+        c, b = c.float(), b.float()
+    r = rois.detach().float().contiguous()
+    n = r.size(0)
+    if c.shape != (n, num_classes + 1) or b.numel() != n * (4 if class_agnostic else 4 * num_classes):
+        raise SwinHipError(f"regress_by_class: shapes {tuple(c.shape)} / {tuple(b.shape)} do not match {n} RoIs")
+    out = torch.empty_like(r)
+    mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    lab = None if labels is None else labels.long().contiguous()
+    call("det_regress_by_class", _p(r), _p(lab), _p(c), _p(b), n, int(num_classes), 1 if class_agnostic else 0, _f4(means), _f4(stds),
+         mh, mw, _p(out), SWIN_F32 if c.dtype == torch.float32 else SWIN_BF16, _s())
+    return out
+
+
+def paste_masks(mask_logits, labels, boxes, img_h, img_w, thr, is_prob=False):
     """FCNMaskHead.get_seg_masks pasting (fcn_mask_head.py:257-300 with _do_paste_mask :303-377) in one kernel:
     mask_logits (N, num_classes, mh, mw), labels (N,), boxes (N,4) in output-image coordinates ->
-    (N, img_h, img_w) bool: sigmoid mask of the labelled class resampled into its box, >= thr."""
+    (N, img_h, img_w) bool: sigmoid mask of the labelled class resampled into its box, >= thr.  ``is_prob``: the input
+    already holds probabilities (stage-averaged masks of CascadeRoIHead)."""
     if not mask_logits.is_cuda:
         raise SwinHipError("paste_masks: GPU tensors only")
     if mask_logits.dtype not in (torch.float32, torch.bfloat16):
@@ -122,5 +145,6 @@ def paste_masks(mask_logits, labels, boxes, img_h, img_w, thr):
     if N:
         from .._lib import SWIN_BF16, SWIN_F32
         call("det_paste_masks", _p(m), _p(labels.long().contiguous()), _p(boxes.detach().float().contiguous()), N, nc, mh, mw,
-             int(img_h), int(img_w), float(thr), SWIN_F32 if m.dtype == torch.float32 else SWIN_BF16, _p(out), _s())
+             int(img_h), int(img_w), float(thr), 1 if is_prob else 0, SWIN_F32 if m.dtype == torch.float32 else SWIN_BF16, _p(out),
+             _s())
     return out.bool()

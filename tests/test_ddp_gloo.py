@@ -76,3 +76,56 @@ def test_bucketed_reducer_gloo_world2():
         p.join(timeout=30)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _syncbn_worker(rank, world, port, q):
+    """SyncBN of the Cascade heads' ConvModules (detector._bn_act, CPU form of ops.batch_norm): with the batch split over
+    two ranks, outputs, input gradients and running statistics equal plain BatchNorm over the whole batch; the parameter
+    gradients are each rank's own share (the bucketed reducer then averages them, as DDP does for SyncBatchNorm)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch.nn.functional as F
+    from swin_transformer_object_detection_amd import detector
+    from swin_transformer_object_detection_amd.fpn import ConvModule
+    g = torch.Generator().manual_seed(7)
+    C = 8
+    x = torch.randn(6, C, 7, 7, generator=g) * 2 + 0.5
+    dy = torch.randn(6, C, 7, 7, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    cm = ConvModule(C, C, 3, padding=1, norm_cfg=dict(type='SyncBN', requires_grad=True))
+    with torch.no_grad():
+        cm.bn.weight.copy_(gamma); cm.bn.bias.copy_(beta)
+    cm.train()
+    sl = slice(0, 2) if rank == 0 else slice(2, 6)                 # uneven split: counts must be exchanged too
+    xl = x[sl].clone().requires_grad_(True)
+    y = detector._bn_act(xl, cm, True, relu=True)
+    y.backward(dy[sl])
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    yr = F.relu(F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5))
+    yr.backward(dy)
+    ok = torch.allclose(y, yr[sl].detach(), atol=1e-5) and torch.allclose(xl.grad, xr.grad[sl], atol=1e-5)
+    ok &= torch.allclose(cm.bn.running_mean, rm, atol=1e-6) and torch.allclose(cm.bn.running_var, rv, atol=1e-5)
+    both = [torch.zeros(2 * C) for _ in range(world)]
+    dist.all_gather(both, torch.cat([cm.bn.weight.grad, cm.bn.bias.grad]))
+    ok &= torch.allclose(both[0] + both[1], torch.cat([gr.grad, br.grad]), atol=1e-4)
+    ok &= int(cm.bn.num_batches_tracked) == 1
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_sync_batch_norm_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -429,3 +430,186 @@ def test_fused_swin_block_equals_per_op_blocks():
         floor = (2.0 ** -7 if n.endswith('.bias') else 1e-5) * float(gp0[n].abs().max())   # bias = sum of rounded parts
         bound = 2.0 ** -7 * torch.maximum(gp0[n].abs(), gp1[n].abs()) + floor + 1e-12
         assert bool((d <= bound).all()), (n, float(d.max()))
+
+
+# ------------------------------------------------------------------------------------------
+# Cascade Mask R-CNN (BASELINE configs[3]): ConvFCBBoxHead 4conv1fc + SyncBN, GIoU on decoded boxes, 3 stages
+# ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_convfc_bbox_head_matches_fp32_torch():
+    """ConvFCBBoxHead (4 shared convs with BN + ReLU, 1 fc) on the HIP conv / batch-norm kernels in bf16 against the same
+    module in fp32 torch (convfc_bbox_head.py:135-178): outputs, and the gradients of conv / BN / fc parameters."""
+    from swin_transformer_object_detection_amd import detector, presets
+    torch.manual_seed(4)
+    hc = presets.cascade_mask_rcnn_swin("tiny")["roi_head"]["bbox_head"][0]
+    hc = {k: v for k, v in hc.items() if k != 'type'}
+    head = detector.ConvFCBBoxHead(**hc, compute_dtype=torch.bfloat16).cuda().train()
+    head.init_weights()
+    with torch.no_grad():
+        head.fc_reg.weight.normal_(0, 0.01)
+        for cm in head.shared_convs:
+            cm.bn.weight.uniform_(0.5, 1.5); cm.bn.bias.normal_(0, 0.2)
+    x = torch.randn(96, 256, 7, 7, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    cls, reg = head(x)
+    (cls.float().square().mean() + reg.float().square().mean() * 100).backward()
+    # fp32 torch on the same parameters
+    import copy
+    ref = copy.deepcopy(head).float()
+    for p in ref.parameters():
+        p.grad = None
+    for cm in ref.shared_convs:
+        cm.bn.running_mean.zero_(); cm.bn.running_var.fill_(1)
+    def q(t):          # activations are stored in bf16 between the kernels: round at the same points, so that the two runs
+        return t.to(torch.bfloat16).float()     # agree on (nearly) every ReLU mask -- a flipped mask is a full-size error
+    y = x.float()
+    for cm in ref.shared_convs:
+        y = q(F.relu(F.batch_norm(q(F.conv2d(y, q(cm.conv.weight), None, padding=1)), cm.bn.running_mean, cm.bn.running_var,
+                                  cm.bn.weight, cm.bn.bias, True, 0.1, 1e-5)))
+    y = q(F.relu(F.linear(y.flatten(1), q(ref.shared_fcs[0].weight), q(ref.shared_fcs[0].bias))))
+    cls_r, reg_r = F.linear(y, ref.fc_cls.weight, ref.fc_cls.bias), F.linear(y, ref.fc_reg.weight, ref.fc_reg.bias)
+    (cls_r.square().mean() + reg_r.square().mean() * 100).backward()
+    # bf16 operands through 5 layers: tolerances relative to the tensor's scale
+    for got, want in ((cls, cls_r), (reg, reg_r)):
+        assert float((got.float() - want).abs().max()) <= 0.03 * float(want.abs().max()) + 1e-3
+    for cm, cr in zip(head.shared_convs, ref.shared_convs):
+        np.testing.assert_allclose(cm.bn.running_mean.cpu().numpy(), cr.bn.running_mean.cpu().numpy(),
+                                   atol=0.02 * float(cr.bn.running_mean.abs().max()) + 1e-3)
+        np.testing.assert_allclose(cm.bn.running_var.cpu().numpy(), cr.bn.running_var.cpu().numpy(), rtol=0.03, atol=1e-3)
+    pg, pr = dict(head.named_parameters()), dict(ref.named_parameters())
+    errs = {}
+    for n in pr:
+        g, r = pg[n].grad.float(), pr[n].grad
+        # bf16 activations through up to 4 conv+BN layers forward and back: relative L2 error of the whole tensor
+        errs[n] = float((g - r).norm() / r.norm().clamp(min=1e-12))
+    assert max(errs.values()) <= 0.05, errs
+
+
+@pytest.mark.gpu
+def test_cascade_training_step_and_refinement():
+    """One bf16 Cascade Mask R-CNN step (cascade_roi_head.py:200-284): per-stage losses with the stage weights, every
+    parameter of the three stages receives a gradient, and the boxes handed from stage to stage are the previous
+    stage's regress_by_class output with the gt proposals masked out."""
+    from oracle import callers_oracle as CO
+    from swin_transformer_object_detection_amd import data, ddp, detector, mixed, presets
+    torch.manual_seed(0)
+    cfg = presets.cascade_mask_rcnn_swin("tiny")
+    cfg["backbone"]["drop_path_rate"] = 0.0
+    model = detector.build_detector(cfg, compute_dtype=torch.bfloat16).cuda().train()
+    assert isinstance(model, detector.CascadeRCNN) and isinstance(model.roi_head, detector.CascadeRoIHead)
+    with torch.no_grad():
+        for h in model.roi_head.bbox_head:
+            h.fc_reg.weight.normal_(0, 0.01)
+    seen = []
+    orig = detector._roi_stage_train
+
+    def spy(x, proposal_list, *a, **k):
+        losses, st = orig(x, proposal_list, *a, **k)
+        seen.append((proposal_list, st))
+        return losses, st
+    detector._roi_stage_train = spy
+    sh = mixed.ShadowParams(model, torch.bfloat16)
+    try:
+        red = ddp.BucketedGradReducer(model.parameters(), leaf_of=sh.leaf_of)
+        batch = data.synthetic_batch(2, 256, 320, torch.device("cuda"), seed=3, num_boxes=4)
+        red.zero_grad()
+        losses = model.forward_train(**batch)
+        loss, _ = model.parse_losses(losses)
+        loss.backward()
+        red.finish()
+        torch.cuda.synchronize()
+        want = {f's{i}.{k}' for i in range(3) for k in ('loss_cls', 'acc', 'loss_bbox', 'loss_mask')} | {'loss_rpn_cls', 'loss_rpn_bbox'}
+        assert set(losses) == want and torch.isfinite(loss)
+        assert all(float(losses[f's{i}.loss_bbox']) > 0 for i in range(3))          # GIoU of random-init boxes is not 0
+        bad = [n for n, p in model.named_parameters()
+               if p.grad is None or not torch.isfinite(p.grad).all() or float(p.grad.abs().max()) == 0.0]
+        # allowed_border=0 (cascade configs) removes every stride-32/64 anchor that leaves this small 256x320 image, and no
+        # RoI is large enough for pyramid level 3: the P5 output conv legitimately receives no gradient here
+        bad = [n for n in bad if not n.startswith('neck.fpn_convs.3.')]
+        assert not bad, f"parameters without a usable gradient: {bad[:10]} ({len(bad)} total)"
+        # refinement hand-over, stage 0 -> 1, against the oracle
+        assert len(seen) == 3
+        (_, st0), (plist1, _) = seen[0], seen[1]
+        head = model.roi_head.bbox_head[0]
+        per = st0['rois'][0].size(0)
+        for j in range(2):
+            boxes1, valid1 = plist1[j]
+            sl = slice(j * per, (j + 1) * per)
+            ref = CO.regress_by_class(st0['rois'][j].cpu().numpy(), st0['labels'][sl].cpu().numpy(), st0['cls_score'][sl].detach().float().cpu().numpy(),
+                                      st0['bbox_pred'][sl].detach().float().cpu().numpy(), 80, False, head.means, head.stds, (256, 320))
+            np.testing.assert_allclose(boxes1.cpu().numpy(), ref, rtol=1e-5, atol=2e-3)
+            assert torch.equal(valid1, st0['valid'][j] & ~st0['pos_is_gt'][j])
+            assert int(st0['pos_is_gt'][j].sum()) == 4                                   # the 4 gt boxes were sampled as positives
+    finally:
+        detector._roi_stage_train = orig
+        sh.release()
+
+
+@pytest.mark.gpu
+def test_cascade_simple_test_matches_oracle_callers():
+    """CascadeRoIHead.simple_test (cascade_roi_head.py:286-411): rois refined stage by stage with the argmax class, scores
+    averaged over the stages, decoding with the last stage's deltas, masks = mean of the stages' sigmoid masks -- checked
+    with the oracle's restatements run on the model's own per-stage head outputs."""
+    from oracle import callers_oracle as CO
+    from swin_transformer_object_detection_amd import data, detector, presets
+    torch.manual_seed(12)
+    cfg = presets.cascade_mask_rcnn_swin("tiny")
+    cfg['test_cfg']['rcnn']['score_thr'] = 0.0125
+    model = detector.build_detector(cfg, compute_dtype=torch.bfloat16).cuda().eval()
+    rh = model.roi_head
+    with torch.no_grad():
+        for h in rh.bbox_head:
+            h.fc_cls.weight.normal_(0, 0.05); h.fc_reg.weight.normal_(0, 0.02)
+            for cm in h.shared_convs:                         # eval mode: running statistics of a "trained" model
+                cm.bn.running_mean.normal_(0, 0.1); cm.bn.running_var.uniform_(0.5, 1.5)
+    batch = data.synthetic_batch(2, 256, 320, torch.device("cuda"), seed=6, num_boxes=3)
+    metas = batch["img_metas"]
+    metas[1]['scale_factor'] = np.array([1.25, 1.25, 1.25, 1.25], np.float32)
+    metas[1]['ori_shape'] = (205, 256, 3)
+    cap = {'bbox': [], 'mask': []}
+    origs = []
+    for st in range(3):
+        ob, om = rh.bbox_head[st].forward, rh.mask_head[st].forward
+        origs.append((ob, om))
+        rh.bbox_head[st].forward = (lambda f, ob=ob: cap['bbox'].append(ob(f)) or cap['bbox'][-1])
+        rh.mask_head[st].forward = (lambda f, om=om: cap['mask'].append(om(f)) or cap['mask'][-1])
+    t = cfg['test_cfg']['rcnn']
+    for rescale in (False, True):
+        cap['bbox'].clear(); cap['mask'].clear()
+        x = model.extract_feat(batch["img"])
+        props = model.rpn_head.simple_test_rpn(x, metas)
+        res = rh.simple_test(x, props, metas, rescale=rescale)
+        assert len(res) == 2 and len(cap['bbox']) == 6 and len(cap['mask']) == 6
+        for i, (bbox_res, segm_res) in enumerate(res):
+            outs = cap['bbox'][3 * i:3 * i + 3]
+            r = props[i][:, :4].float().cpu().numpy()
+            for st in range(2):
+                h = rh.bbox_head[st]
+                r = CO.regress_by_class(r, None, outs[st][0].float().cpu().numpy(), outs[st][1].float().cpu().numpy(), 80, False,
+                                        h.means, h.stds, metas[i]['img_shape'])
+            rois = np.concatenate([np.full((r.shape[0], 1), i, np.float32), r], 1)
+            h = rh.bbox_head[2]
+            dets, labels = CO.bbox_head_get_bboxes(rois, [o[0].float().cpu().numpy() for o in outs], outs[2][1].float().cpu().numpy(),
+                                                   metas[i]['img_shape'], detector._sf4(metas[i]['scale_factor']), rescale,
+                                                   t['score_thr'], t['nms'], t['max_per_img'], h.means, h.stds)
+            ref = CO.bbox2result(dets, labels, 80)
+            assert sum(len(b) for b in bbox_res) == len(dets) > 0
+            for c in range(80):
+                np.testing.assert_allclose(bbox_res[c], ref[c], rtol=1e-5, atol=5e-3)
+            ml = [m.float().sigmoid().cpu().numpy() for m in cap['mask'][3 * i:3 * i + 3]]
+            prob = ((ml[0] + ml[1]) + ml[2]) / np.float32(3)
+            sf = np.asarray(detector._sf4(metas[i]['scale_factor']), np.float32)
+            if rescale:
+                ih, iw = metas[i]['ori_shape'][:2]
+            else:
+                ih = int(np.round(metas[i]['ori_shape'][0] * sf[1])); iw = int(np.round(metas[i]['ori_shape'][1] * sf[0]))
+            mref, mvals = CO.paste_masks(prob, labels, dets[:, :4], ih, iw, t['mask_thr_binary'], is_prob=True)
+            assert sum(len(s_) for s_ in segm_res) == len(dets)
+            seen = [0] * 80
+            for k, lab in enumerate(labels):
+                got = segm_res[lab][seen[lab]]; seen[lab] += 1
+                assert got.shape == (ih, iw) and got.dtype == np.bool_
+                assert not np.any((got != mref[k]) & (np.abs(mvals[k] - t['mask_thr_binary']) > 1e-4))
+    for st in range(3):
+        rh.bbox_head[st].forward, rh.mask_head[st].forward = origs[st]
+    out = model.simple_test(batch["img"], metas, rescale=True)
+    assert len(out) == 2 and len(out[0][0]) == 80 and len(out[0][1]) == 80

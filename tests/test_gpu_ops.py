@@ -526,15 +526,18 @@ def test_max_iou_assign_bit_exact(ops, n, g, pos, neg, minpos, lowq):
 
 def test_max_iou_assign_leading_gts_and_valid_mask(ops):
     """add_gt_as_proposals (base_sampler.py:77-84): the gt rows are appended to the ASSIGNED result, i.e. they match
-    themselves and do not take part in the per-gt maxima; padding slots (valid == 0) are never assigned."""
+    themselves and do not take part in the per-gt maxima; masked slots (valid == 0: padding of fixed-size lists, anchors
+    outside allowed_border which anchor_head.py:200-207 removes BEFORE assigning) are never assigned and do not feed
+    the per-gt maxima either -- the result equals assigning the valid boxes alone."""
     rng = np.random.RandomState(5)
     g, n = 6, 400
     gts, props = _boxes(rng, g), _boxes(rng, n)
     labels = rng.randint(0, 80, g)
     valid = rng.rand(n) > 0.2
-    a_ref, m_ref, l_ref = CO.max_iou_assign(props, gts, 0.5, 0.5, 0.5, True, labels)
-    a_ref = np.where(valid, a_ref, -1)
-    l_ref = np.where(a_ref > 0, l_ref, -1)
+    _, m_ref, _ = CO.max_iou_assign(props, gts, 0.5, 0.5, 0.5, True, labels)
+    a_v, _, l_v = CO.max_iou_assign(props[valid], gts, 0.5, 0.5, 0.5, True, labels)
+    a_ref = np.full(n, -1, np.int64); a_ref[valid] = a_v
+    l_ref = np.full(n, -1, np.int64); l_ref[valid] = l_v
     a_ref = np.concatenate([np.arange(1, g + 1), a_ref]); l_ref = np.concatenate([labels, l_ref])
     allb = np.concatenate([gts, props]); v = np.concatenate([np.ones(g, bool), valid])
     a, m, l = ops.max_iou_assign(dev(torch.from_numpy(allb)), dev(torch.from_numpy(gts)), 0.5, 0.5, 0.5, True,
@@ -725,6 +728,167 @@ def test_bbox_and_mask_loss_kernels(ops, dtype):
     (olm * 3).backward()
     close(olm, lm.detach(), 1e-5, 1e-5)
     close(p1.grad.float(), p0.grad, rel * float(p0.grad.abs().max()) + 1e-9, rel)
+
+
+@pytest.mark.parametrize("beta", [1.0 / 9.0, 1.0])
+def test_rpn_loss_smooth_l1(ops, beta):
+    """SmoothL1Loss(beta) regression term (smooth_l1_loss.py:10-28; the Cascade configs' RPN uses beta = 1/9)."""
+    g = torch.Generator().manual_seed(13)
+    B, A, S = 2, 3000, 256
+    cls = torch.randn(B, A, generator=g) * 2
+    reg = torch.randn(B, A, 4, generator=g) * 0.3
+    inds = torch.stack([torch.randperm(A, generator=g)[:S] for _ in range(B)])
+    flags = torch.randint(0, 3, (B, S), generator=g).to(torch.uint8)
+    flags = torch.where(flags == 2, torch.full_like(flags, 3), flags)
+    tgt = torch.randn(B, S, 4, generator=g) * 0.3
+    r0 = reg.clone().requires_grad_(True)
+    valid, pos = (flags & 1).bool(), (flags & 2).bool()
+    n = valid.sum().clamp(min=1).float()
+    ri = torch.gather(r0, 1, inds[..., None].expand(-1, -1, 4))
+    lb = (F.smooth_l1_loss(ri, tgt, beta=beta, reduction='none') * pos[..., None]).sum() / n
+    lb.backward()
+    ref = float((CO.smooth_l1((ri.detach() - tgt).numpy(), beta) * pos[..., None].numpy()).sum() / float(n))
+    assert abs(ref - float(lb)) < 1e-5                     # the oracle's formula == torch's smooth_l1_loss
+    c1, r1 = cls.cuda().requires_grad_(True), reg.cuda().requires_grad_(True)
+    _, olb = ops.rpn_loss(c1, r1, inds.cuda(), flags.cuda(), tgt.cuda(), beta)
+    olb.backward()
+    close(olb, lb.detach(), 1e-5, 1e-5)
+    close(r1.grad, r0.grad, 1e-7, 1e-5)
+
+
+def _giou_case(g, n, nc, agnostic):
+    xy = torch.rand(n, 2, generator=g) * 300
+    rois = torch.cat([xy, xy + torch.rand(n, 2, generator=g) * 120 + 4], 1)
+    txy = xy + (torch.rand(n, 2, generator=g) - 0.5) * 60
+    tgt = torch.cat([txy, txy + torch.rand(n, 2, generator=g) * 120 + 4], 1)
+    tgt[::7] = rois[::7] + 400                                  # disjoint pairs: the enclosing-box term alone
+    bbox = torch.randn(n, 4 if agnostic else 4 * nc, generator=g) * 1.5
+    bbox[::11] *= 8                                             # some deltas beyond the wh_ratio clip
+    return rois, tgt, bbox
+
+
+@pytest.mark.parametrize("agnostic", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bbox_loss_giou_decoded(ops, dtype, agnostic):
+    """reg_decoded_bbox=True + GIoULoss (bbox_head.py:215-216, iou_loss.py:78-101): value against the numpy oracle, input
+    gradients against autograd through the torch restatement (detector.giou_loss_elem over detector.delta2bbox)."""
+    from swin_transformer_object_detection_amd import detector
+    g = torch.Generator().manual_seed(21)
+    n, nc = 400, 80
+    means, stds = (0., 0., 0., 0.), (0.05, 0.05, 0.1, 0.1)
+    cls = (torch.randn(n, nc + 1, generator=g) * 2).to(dtype)
+    rois, tgt, bbox = _giou_case(g, n, nc, agnostic)
+    bbox = bbox.to(dtype)
+    labels = torch.randint(0, nc + 1, (n,), generator=g)
+    valid = torch.rand(n, generator=g) > 0.2
+    pos = (labels < nc) & valid
+    labels = torch.where(valid & ~pos, torch.full_like(labels, nc), labels)
+    flags = valid.to(torch.uint8) + 2 * pos.to(torch.uint8)
+    b0 = bbox.float().clone().requires_grad_(True)
+    nv = valid.sum().clamp(min=1).float()
+    pred = b0.view(n, 4) if agnostic else b0.view(n, nc, 4)[torch.arange(n), labels.clamp(max=nc - 1)]
+    dec = detector.delta2bbox(rois, pred, means, stds)
+    lb = (detector.giou_loss_elem(dec, tgt, 1e-6) * pos).sum() / nv
+    lb.backward()
+    lc_ref, acc_ref, lb_ref = CO.bbox_head_loss(cls.float().numpy(), bbox.float().numpy(), labels.numpy(), tgt.numpy(), flags.numpy(),
+                                                nc, agnostic, 0.0, (rois.numpy(), means, stds, 1e-6))
+    assert abs(lb_ref - float(lb)) < 2e-5                   # numpy oracle == torch restatement
+    c1, b1 = cls.cuda().requires_grad_(True), bbox.cuda().requires_grad_(True)
+    olc, oacc, olb = ops.bbox_loss(c1, b1, labels.cuda(), tgt.cuda(), flags.cuda(), nc, agnostic, 0.0,
+                                   (rois.cuda(), means, stds, 1e-6))
+    (olc + olb * 10).backward()
+    close(olb, torch.tensor(lb_ref), 2e-5, 1e-5); close(olc, torch.tensor(lc_ref), 1e-5, 1e-5); close(oacc, torch.tensor(acc_ref), 1e-3)
+    rel = 1e-4 if dtype == torch.float32 else 2.0 ** -7
+    gref = b0.grad * 10
+    close(b1.grad.float(), gref, rel * float(gref.abs().max()) + 1e-8, rel)
+    assert float(b1.grad.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("agnostic", [False, True])
+def test_bbox_loss_smooth_l1_and_agnostic(ops, agnostic):
+    """The _base_ cascade heads: class-agnostic SmoothL1(beta=1) on encoded deltas (cascade_mask_rcnn_swin_fpn.py:52-70)."""
+    g = torch.Generator().manual_seed(8)
+    n, nc = 300, 80
+    cls = torch.randn(n, nc + 1, generator=g) * 2
+    bbox = torch.randn(n, 4 if agnostic else 4 * nc, generator=g) * 1.2
+    labels = torch.randint(0, nc + 1, (n,), generator=g)
+    valid = torch.rand(n, generator=g) > 0.1
+    pos = (labels < nc) & valid
+    labels = torch.where(valid & ~pos, torch.full_like(labels, nc), labels)
+    tgt = torch.randn(n, 4, generator=g)
+    flags = valid.to(torch.uint8) + 2 * pos.to(torch.uint8)
+    b0 = bbox.clone().requires_grad_(True)
+    nv = valid.sum().clamp(min=1).float()
+    pred = b0.view(n, 4) if agnostic else b0.view(n, nc, 4)[torch.arange(n), labels.clamp(max=nc - 1)]
+    lb = (F.smooth_l1_loss(pred, tgt, beta=1.0, reduction='none') * pos[:, None]).sum() / nv
+    lb.backward()
+    _, _, lb_ref = CO.bbox_head_loss(cls.numpy(), bbox.numpy(), labels.numpy(), tgt.numpy(), flags.numpy(), nc, agnostic, 1.0)
+    assert abs(lb_ref - float(lb)) < 1e-5
+    c1, b1 = cls.cuda().requires_grad_(True), bbox.cuda().requires_grad_(True)
+    _, _, olb = ops.bbox_loss(c1, b1, labels.cuda(), tgt.cuda(), flags.cuda(), nc, agnostic, 1.0)
+    olb.backward()
+    close(olb, lb.detach(), 1e-5, 1e-5)
+    close(b1.grad, b0.grad, 1e-7, 1e-5)
+
+
+@pytest.mark.parametrize("agnostic", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_regress_by_class_kernel(ops, dtype, agnostic):
+    """bbox_head.py:409-436 + the label choice of cascade_roi_head.py:274-281 / :316-317 against the numpy oracle."""
+    g = torch.Generator().manual_seed(5)
+    n, nc = 700, 80
+    means, stds = (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2)
+    xy = torch.rand(n, 2, generator=g) * 500
+    rois = torch.cat([xy, xy + torch.rand(n, 2, generator=g) * 200 + 2], 1)
+    cls = torch.randn(n, nc + 1, generator=g).to(dtype)
+    cls[:, nc] += 3                                               # background often the overall maximum: must be ignored
+    bbox = torch.randn(n, 4 if agnostic else 4 * nc, generator=g).to(dtype)
+    labels = torch.randint(0, nc + 1, (n,), generator=g)
+    for lab in (labels, None):
+        ref = CO.regress_by_class(rois.numpy(), None if lab is None else lab.numpy(), cls.float().numpy(), bbox.float().numpy(), nc,
+                                  agnostic, means, stds, (480, 640))
+        out = ops.regress_by_class(rois.cuda(), None if lab is None else lab.cuda(), cls.cuda(), bbox.cuda(), nc, agnostic, means,
+                                   stds, (480, 640))
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=2e-3)
+    assert float(out[:, 2].max()) <= 640 and float(out[:, 3].max()) <= 480
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 256), (torch.bfloat16, 256), (torch.bfloat16, 96), (torch.float32, 36)])
+def test_batch_norm_kernels(ops, dtype, C, relu):
+    """csrc/batchnorm.hip (the SyncBN of ConvFCBBoxHead's ConvModules) against the float64 oracle: output, running
+    statistics, dx / dgamma / dbeta; and eval mode against running statistics."""
+    g = torch.Generator().manual_seed(2)
+    N, H, W = 37, 7, 7
+    x = (torch.randn(N, C, H, W, generator=g) * 1.7 + torch.randn(C, generator=g)[None, :, None, None]).to(dtype)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    dy = torch.randn(N, C, H, W, generator=g).to(dtype)
+    rows = x.float().permute(0, 2, 3, 1).reshape(-1, C).numpy()
+    y_ref, mean, var = CO.batch_norm_train(rows, gamma.numpy(), beta.numpy(), 1e-5, relu)
+    dx_ref, dg_ref, db_ref = CO.batch_norm_train_bwd(rows, gamma.numpy(), beta.numpy(), dy.float().permute(0, 2, 3, 1).reshape(-1, C).numpy(),
+                                                     1e-5, relu)
+    # the oracle's formula == torch's own batch norm (known answer)
+    yt = F.batch_norm(x.float(), None, None, gamma, beta, True, 0.1, 1e-5)
+    yt = F.relu(yt) if relu else yt
+    np.testing.assert_allclose(yt.permute(0, 2, 3, 1).reshape(-1, C).numpy(), y_ref, rtol=1e-4, atol=1e-4)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gg, bg = gamma.cuda().requires_grad_(True), beta.cuda().requires_grad_(True)
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    y = ops.batch_norm(xg, gg, bg, rm, rv, True, 1e-5, 0.1, relu)
+    y.backward(dy.cuda())
+    tol = 1e-4 if dtype == torch.float32 else 2.0 ** -7
+    R = rows.shape[0]
+    np.testing.assert_allclose(y.detach().float().permute(0, 2, 3, 1).reshape(-1, C).cpu().numpy(), y_ref, rtol=tol, atol=tol * 4)
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * mean, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), 0.9 + 0.1 * var * R / (R - 1), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gg.grad.cpu().numpy(), dg_ref, rtol=1e-3, atol=2e-3 * np.abs(dg_ref).max())
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), db_ref, rtol=1e-3, atol=2e-3 * np.abs(db_ref).max())
+    np.testing.assert_allclose(xg.grad.float().permute(0, 2, 3, 1).reshape(-1, C).cpu().numpy(), dx_ref, rtol=tol,
+                               atol=tol * 4 * float(np.abs(dx_ref).max()))
+    ye = ops.batch_norm(xg.detach(), gg.detach(), bg.detach(), rm, rv, False, 1e-5, 0.1, relu)
+    yr = F.batch_norm(x.float(), rm.cpu(), rv.cpu(), gamma, beta, False, 0.1, 1e-5)
+    yr = F.relu(yr) if relu else yr
+    close(ye.float().cpu(), yr, tol * 4, tol)
 
 
 def test_batched_nms_static_multi_equals_per_image(ops):

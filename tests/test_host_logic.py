@@ -74,10 +74,17 @@ def test_reference_swin_configs_load_unchanged():
         nk = registry.build_neck(cfg.model.neck)
         assert bb.num_features[-1] == cfg.model.neck.in_channels[-1] and nk.num_outs == 5
         assert cfg.optimizer.type == 'AdamW' and cfg.runner.type == 'EpochBasedRunnerAmp'
+        det = pkg.build_detector(cfg.model)
         if cfg.model.type == 'MaskRCNN':
-            det = pkg.build_detector(cfg.model)
             assert abs(sum(p.numel() for p in det.parameters()) / 1e6 - {96: 47.8, }.get(cfg.model.backbone.embed_dim, 0)) < 0.2 \
                 or cfg.model.backbone.depths[2] == 18
+        else:                                   # Cascade Mask R-CNN: 3 ConvFCBBoxHead (4conv1fc + SyncBN) and 3 mask heads
+            assert cfg.model.type == 'CascadeRCNN' and len(det.roi_head.bbox_head) == 3 and len(det.roi_head.mask_head) == 3
+            keys = set(det.state_dict())
+            assert {'roi_head.bbox_head.0.shared_convs.3.conv.weight', 'roi_head.bbox_head.2.shared_convs.0.bn.running_var',
+                    'roi_head.bbox_head.1.shared_fcs.0.weight', 'roi_head.mask_head.2.conv_logits.bias'} <= keys
+            assert 'roi_head.bbox_head.0.shared_convs.0.conv.bias' not in keys          # ConvModule bias='auto' with a norm
+            assert det.roi_head.bbox_head[0].shared_fcs[0].weight.shape == (1024, 256 * 49)
 
 
 @pytest.mark.skipif(not has_ref, reason="reference tree not present (GPU box)")
@@ -93,6 +100,10 @@ def test_presets_equal_reference_config():
     assert plain(cfg.to_dict()["model"]) == plain(presets.mask_rcnn_swin("tiny"))
     assert cfg.optimizer.lr == presets.OPTIMIZER["lr"] and cfg.optimizer.weight_decay == presets.OPTIMIZER["weight_decay"]
     assert set(cfg.optimizer.paramwise_cfg.custom_keys) == set(presets.OPTIMIZER["no_decay_keys"])
+    for variant, name in (("base", "cascade_mask_rcnn_swin_base_patch4_window7_mstrain_480-800_giou_4conv1f_adamw_3x_coco.py"),
+                          ("tiny", "cascade_mask_rcnn_swin_tiny_patch4_window7_mstrain_480-800_giou_4conv1f_adamw_3x_coco.py")):
+        cfg = config.Config.fromfile(os.path.join(REF, "configs/swin", name))
+        assert plain(cfg.to_dict()["model"]) == plain(presets.cascade_mask_rcnn_swin(variant))
 
 
 def test_box_utils_match_oracle_callers():
