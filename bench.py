@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="mask_rcnn_swin_t", choices=sorted(WORKLOADS),
+                    help="default: BASELINE.json configs[1] (the headline metric); the others are the BASELINE parity configurations, "
+                         "timed for DESIGN.md only")
     ap.add_argument("--check-sync", action="store_true",
                     help="after the timed steps, verify that all ranks hold bit-identical parameters (N > 1)")
     return ap.parse_args()
@@ -180,6 +183,22 @@ def cpu_baseline():
                       "C batched NMS(8780 boxes); heads/losses/optimizer excluded", "seconds": round(dt, 2)}
 
 
+# name -> (preset builder, variant, H, W, description).  configs[3] / configs[4] of BASELINE.json besides the headline configs[1].
+WORKLOADS = {
+    "mask_rcnn_swin_t": ("mask_rcnn_swin", "tiny", 800, 1280,
+                         "Mask R-CNN Swin-T patch4 window7, 2x3x800x1280 per GPU, 8 GT boxes+masks/image, AdamW, DropPath 0.1 "
+                         "(BASELINE.json configs[1])"),
+    "cascade_swin_b": ("cascade_mask_rcnn_swin", "base", 800, 1280,
+                       "Cascade Mask R-CNN Swin-B patch4 window7 (3 stages, 4conv1fc + SyncBN, GIoU), 2x3x800x1280 per GPU, AdamW, "
+                       "DropPath 0.3 (BASELINE.json configs[3])"),
+    "cascade_swin_t": ("cascade_mask_rcnn_swin", "tiny", 800, 1280,
+                       "Cascade Mask R-CNN Swin-T patch4 window7 (3 stages, 4conv1fc + SyncBN, GIoU), 2x3x800x1280 per GPU, AdamW"),
+    "mask_rcnn_swin_s_1024": ("mask_rcnn_swin", "small", 1024, 1024,
+                              "Mask R-CNN Swin-S window7, 2x3x1024x1024 per GPU, AdamW, DropPath 0.2 (BASELINE.json configs[4]; bf16 "
+                              "in place of fp16)"),
+}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,7 +226,9 @@ def main():
     from swin_transformer_object_detection_amd import data, ddp, detector, presets
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)                       # identical weights on every rank
-    model = detector.build_detector(presets.mask_rcnn_swin("tiny"), compute_dtype=dtype).to(device)
+    builder, variant, img_h, img_w, workload_desc = WORKLOADS[args.workload]
+    headline = args.workload == "mask_rcnn_swin_t"
+    model = detector.build_detector(getattr(presets, builder)(variant), compute_dtype=dtype).to(device)
     model.train()
     from swin_transformer_object_detection_amd import mixed
     shadows = mixed.ShadowParams(model, dtype) if dtype != torch.float32 else None
@@ -218,7 +239,7 @@ def main():
     opt_cfg = presets.OPTIMIZER
     from swin_transformer_object_detection_amd.optim import FusedAdamW
     optim = FusedAdamW(build_param_groups(model, opt_cfg), lr=opt_cfg["lr"], betas=opt_cfg["betas"])      # one launch, refreshes the bf16 shadows
-    batch = data.synthetic_batch(PER_GPU_BATCH, IMG_H, IMG_W, device, seed=rank)     # per-rank data
+    batch = data.synthetic_batch(PER_GPU_BATCH, img_h, img_w, device, seed=rank)     # per-rank data
     torch.manual_seed(1000 + rank)             # per-rank sampling / DropPath randomness
 
     def step():
@@ -267,17 +288,17 @@ def main():
     roof = attention_roofline(device) if rank == 0 else None
     roof_gemm = gemm_rooflines(device) if rank == 0 else None
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and headline:
         cpu = cpu_baseline()
     if rank == 0:
         gb = PER_GPU_BATCH * world
         out = {
-            "metric": "images/sec/node Mask R-CNN Swin-T 800x1280 bf16 train (fwd+bwd+allreduce+AdamW)",
+            "metric": ("images/sec/node Mask R-CNN Swin-T 800x1280 bf16 train (fwd+bwd+allreduce+AdamW)" if headline else
+                       f"images/sec/node {args.workload} {img_h}x{img_w} {args.dtype} train (fwd+bwd+allreduce+AdamW)"),
             "value": round(gb * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "Mask R-CNN Swin-T patch4 window7, 2x3x800x1280 per GPU, 8 GT boxes+masks/image, "
-                                   "AdamW, DropPath 0.1 (BASELINE.json configs[1])",
+            "config": {"workload": workload_desc,
                        "global_batch": gb, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
             "losses": {k: round(v, 4) for k, v in logs.items()},
             "roofline": roof, "roofline_mfma_kernels": roof_gemm, "cpu_baseline": cpu, "sync_check": sync_check,

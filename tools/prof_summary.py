@@ -20,6 +20,8 @@ def cat(n):
     if 'nms' in n: return 'nms'
     if 'assign_' in n or 'sample_' in n: return 'targets'
     if 'upsample' in n or 'im2row' in n: return 'fpn/embed (mine)'
+    if 'bn_' in n: return 'batchnorm'
+    if 'loss' in n or 'regress' in n or 'bbox_targets' in n or 'delta2bbox' in n or 'rpn_flatten' in n: return 'losses/targets (mine)'
     if 'adamw_kernel' in n: return 'optimizer (mine)'
     if 'multi_tensor' in n: return 'optimizer (torch)'
     if 'rocprim' in n or 'sort' in n.lower() or 'topk' in n.lower(): return 'sort/topk (torch)'
