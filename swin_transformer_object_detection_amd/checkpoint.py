@@ -43,9 +43,14 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=No
             S1, S2 = int(L1 ** 0.5), int(L2 ** 0.5)
             r = F.interpolate(t.permute(1, 0).view(1, nH1, S1, S1), size=(S2, S2), mode='bicubic')
             sd[k] = r.view(nH2, L2).permute(1, 0)
+    # mmcv's load_state_dict (mmcv_custom/checkpoint.py:41-106) reports size mismatches instead of raising when not strict
+    # (e.g. a bias table with another head count, :342-343; a detection head with another class count)
+    mismatched = [k for k, v in sd.items() if k in own and tuple(v.shape) != tuple(own[k].shape)]
+    if mismatched and not strict:
+        sd = {k: v for k, v in sd.items() if k not in mismatched}
     missing, unexpected = model.load_state_dict(sd, strict=strict)
-    if logger is not None and (missing or unexpected):
-        logger.warning(f'missing keys: {missing}; unexpected keys: {unexpected}')
+    if logger is not None and (missing or unexpected or mismatched):
+        logger.warning(f'missing keys: {missing}; unexpected keys: {unexpected}; size mismatch (skipped): {mismatched}')
     return ckpt
 
 
