@@ -110,3 +110,32 @@ class FusedAdamW:
                 idx += 1
             groups.append({**{k: v for k, v in g.items() if k != 'params'}, 'params': ids})
         return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        """Resume (mmcv_custom/runner/epoch_based_runner.py:70-104 restores ``checkpoint['optimizer']``): accepts this
+        class's state_dict or one written by torch.optim.AdamW over the same parameter order.  Moments are copied into
+        this optimizer's own buffers (the kernel's pointer table stays valid), hyper-parameters of the groups are taken
+        from the checkpoint."""
+        groups = sd['param_groups']
+        if len(groups) != len(self.param_groups) or any(len(a['params']) != len(b['params']) for a, b in zip(groups, self.param_groups)):
+            raise ValueError("FusedAdamW.load_state_dict: parameter groups do not match")
+        steps = set()
+        for g_src, g in zip(groups, self.param_groups):
+            for k, v in g_src.items():
+                if k != 'params' and k in ('lr', 'betas', 'eps', 'weight_decay', 'initial_lr'):
+                    g[k] = tuple(v) if k == 'betas' else v
+            for idx, p in zip(g_src['params'], g['params']):
+                st_src = sd['state'].get(idx)
+                if not st_src:
+                    continue
+                if tuple(st_src['exp_avg'].shape) != tuple(p.shape):
+                    raise ValueError(f"FusedAdamW.load_state_dict: moment shape {tuple(st_src['exp_avg'].shape)} != {tuple(p.shape)}")
+                st = self.state.setdefault(p, {})
+                for name in ('exp_avg', 'exp_avg_sq'):
+                    if name not in st:
+                        st[name] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st[name].copy_(st_src[name])
+                steps.add(int(float(st_src['step'])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdamW.load_state_dict: one step count for all parameters (the bias corrections are shared)")
+        self.step_count = steps.pop() if steps else 0

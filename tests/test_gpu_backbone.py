@@ -377,9 +377,11 @@ def test_fused_adamw_matches_torch_adamw():
 
 
 @pytest.mark.gpu
-def test_two_rank_replicas_stay_identical():
+@pytest.mark.parametrize("workload", ["mask_rcnn_swin_t", "cascade_swin_t"])
+def test_two_rank_replicas_stay_identical(workload):
     """N > 1 path on one GPU (2 ranks over gloo, `BENCH_REHEARSAL_GLOO`): bucketed all-reduce fed by autograd hooks AND
-    by the kernels that write the buckets directly, the fused AdamW; the replicas must stay bit-identical."""
+    by the kernels that write the buckets directly, the fused AdamW; the replicas must stay bit-identical.  The cascade
+    workload adds the SyncBN statistics exchange of the 12 head convs."""
     import json
     import subprocess
     import sys
@@ -387,7 +389,7 @@ def test_two_rank_replicas_stay_identical():
     env = dict(os.environ, BENCH_REHEARSAL_GLOO="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--check-sync"]
+           "--no-cpu-baseline", "--check-sync", "--workload", workload]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -613,3 +615,41 @@ def test_cascade_simple_test_matches_oracle_callers():
         rh.bbox_head[st].forward, rh.mask_head[st].forward = origs[st]
     out = model.simple_test(batch["img"], metas, rescale=True)
     assert len(out) == 2 and len(out[0][0]) == 80 and len(out[0][1]) == 80
+
+
+@pytest.mark.gpu
+def test_checkpoint_resume_continues_identically(tmp_path):
+    """save_checkpoint -> load_checkpoint + FusedAdamW.load_state_dict (the resume path of
+    mmcv_custom/runner/epoch_based_runner.py:70-104): the resumed run's next step produces the same parameters, bit for bit,
+    as the run that was never interrupted."""
+    import torch.nn as nn
+    from swin_transformer_object_detection_amd import checkpoint
+    from swin_transformer_object_detection_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+
+    def make():
+        m = nn.Sequential(nn.Linear(40, 64), nn.LayerNorm(64), nn.Linear(64, 8)).cuda()
+        decay = [p for n, p in m.named_parameters() if not n.startswith('1.')]
+        no_decay = [p for n, p in m.named_parameters() if n.startswith('1.')]
+        return m, FusedAdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=1e-2)
+    xs = [torch.randn(16, 40, device='cuda') for _ in range(3)]
+
+    def train(m, o, x):
+        o.zero_grad()
+        m(x).square().mean().backward()
+        o.step()
+    a, oa = make()
+    train(a, oa, xs[0]); train(a, oa, xs[1])
+    f = str(tmp_path / "latest.pth")
+    checkpoint.save_checkpoint(a, f, optimizer=oa, meta=dict(epoch=2, iter=2))
+    train(a, oa, xs[2])
+    b, ob = make()
+    with torch.no_grad():
+        for p in b.parameters():
+            p.add_(1.0)                                   # the resumed model starts elsewhere
+    ck = checkpoint.load_checkpoint(b, f, map_location='cuda')
+    ob.load_state_dict(ck['optimizer'])
+    assert ob.step_count == 2 and ck['meta']['epoch'] == 2
+    train(b, ob, xs[2])
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(p, q), n
