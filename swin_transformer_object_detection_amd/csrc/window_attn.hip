@@ -299,14 +299,18 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg)
-                        if ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1) sacc[kt][reg] += mask_raw;   // -100 / scale  (:389)
+                        if (!(kt == 1 && reg >= 9) && ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1)) sacc[kt][reg] += mask_raw;   // -100 / scale  (:389)
             }
             // 4 independent partial reductions (ILP), then a VALU half-swap instead of an LDS bpermute
+            // keys 49..63 are padding: in the accumulator layout (key = 32 kt + (reg & 3) + 8 (reg >> 2) + 4 h) that is
+            // kt == 1, reg >= 9 for every lane (reg 8 is key 48 for h == 0) -- resolved at compile time, those 7 of the 32
+            // elements never enter the max / exp / sum and are zero in P^T
             float m4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) m4[reg & 3] = fmaxf(m4[reg & 3], sacc[kt][reg]);
+                for (int reg = 0; reg < 16; ++reg)
+                    if (!(kt == 1 && reg >= 9)) m4[reg & 3] = fmaxf(m4[reg & 3], sacc[kt][reg]);
             float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
             m = half_swap_max(m);
             // p = exp2(s * sl2 - m * sl2): one packed fma + one exp per element pair / element; packed partial sums
@@ -318,9 +322,10 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r2 = 0; r2 < 8; ++r2) {
+                    if (kt == 1 && r2 >= 5) { sacc[kt][2 * r2] = 0.f; sacc[kt][2 * r2 + 1] = 0.f; continue; }   // padded keys
                     f32x2 x = {sacc[kt][2 * r2], sacc[kt][2 * r2 + 1]};
                     x = __builtin_elementwise_fma(x, sc2, mc2);
-                    f32x2 p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    f32x2 p = {__builtin_amdgcn_exp2f(x[0]), (kt == 1 && r2 == 4) ? 0.f : __builtin_amdgcn_exp2f(x[1])};
                     sacc[kt][2 * r2] = p[0]; sacc[kt][2 * r2 + 1] = p[1];
                     sum2[r2 & 1] += p;
                 }
@@ -661,6 +666,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
+                    if (kt == 1 && reg >= 9) { pacc[kt][reg] = 0.f; continue; }   // keys 49..63 (padding) for every lane: P = 0
                     float v = fmaf(pacc[kt][reg], sl2, biasr[kt][qt][reg]);
                     if (edge && ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1)) v += -100.0f * LOG2E;
                     float p = qv ? __builtin_amdgcn_exp2f(v - l2) : 0.f;   // padded query columns carry garbage
@@ -676,6 +682,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int reg = 4 * gq + e;
+                        if (kt == 1 && reg >= 9) { dpacc[kt][reg] = 0.f; p4[e] = (bf16)0.f; s4[e] = (bf16)0.f; continue; }   // padded keys
                         float ds = pacc[kt][reg] * (dpacc[kt][reg] - delta);
                         dbacc[kt][qt][reg] += ds;
                         ds *= scale;                              // scale * dS^T from here on
@@ -723,9 +730,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             int tok = 32 * tt + c;
+            bool pad = false;
             if (tok < NTOK) {
                 bf16* op = nullptr;
-                bool pad = false;
                 if (interior) {
                     op = dqkv + ((size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift) * C3 + L.st_off[tt] + head * HD + 4 * h;
                 } else {
@@ -747,16 +754,26 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
                         *(bf16x4*)(op + g.C + 8 * gq) = bb;
                         *(bf16x4*)(op + 2 * g.C + 8 * gq) = cc;
                     }
-                } else if (pad) {
-                    // padded token: its q|k|v ARE qkv.bias, so the gradient lands on the bias.  Summed per wave in
-                    // LDS (global atomics from every padded token onto 3C addresses serialise: ~1 ms per launch)
-                    float* bp = Lm->padacc + 4 * h;
+                }
+            }
+            // padded tokens: their q|k|v ARE qkv.bias, so the gradient lands on the bias.  The padded tokens of this
+            // 32-lane half are summed with lane shuffles and added to the wave's LDS accumulator by one lane per half.
+            // (History: global atomics from every padded token onto 3C addresses serialised at the memory side, ~1 ms
+            // per launch; LDS atomics from the 32 lanes of a half onto the SAME address serialise too -- 48 of them
+            // per token tile made every edge window several times slower than an interior one, and with persistent
+            // waves the slowest wave sets the kernel time.)
+            if (__ballot(pad)) {                               // wave-uniform
+                float* bp = Lm->padacc + 4 * h;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int d = (r & 3) + 8 * (r >> 2);
-                        atomicAdd(bp + d, dq[tt][r]);
-                        atomicAdd(bp + HD + d, dk[tt][r]);
-                        atomicAdd(bp + 2 * HD + d, dv[tt][r]);
+                for (int r = 0; r < 16; ++r) {
+                    float a = pad ? dq[tt][r] : 0.f, bq = pad ? dk[tt][r] : 0.f, cv = pad ? dv[tt][r] : 0.f;
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) {
+                        a += __shfl_xor(a, o); bq += __shfl_xor(bq, o); cv += __shfl_xor(cv, o);
+                    }
+                    if (c == 0) {
+                        const int d = (r & 3) + 8 * (r >> 2);
+                        bp[d] += a; bp[HD + d] += bq; bp[2 * HD + d] += cv;
                     }
                 }
             }
