@@ -11,6 +11,8 @@
 //   lane^32 exchange and P^T is directly the B operand of  O^T = V^T P^T  (no LDS trip).
 //   The expanded bias tile of the wave's head stays in 64 VGPRs across its windows.
 // fp32 path: exact-fp32 VALU kernel (parity path for the 1e-4 gate).
+#include <cstdlib>
+
 #include "common.h"
 
 #define NTOK 49
@@ -913,14 +915,25 @@ static int check_attn_args(const void* qkv, const float* qkv_bias, const float* 
     return SWIN_OK;
 }
 
+// Grid sizing of the persistent kernels.  4 waves per block; the total wave count must be a multiple of nH so that a
+// wave keeps its head (and its bias tile in registers): blocks % nH == 0.  Block counts were swept on one MI355X at the
+// four Swin-T stage geometries of the 2x800x1280 workload (tools/microbench.py attn with SWIN_ATTN_{FWD,BWD}_BLOCKS):
+//   forward (2 blocks resident per CU = 512): 448-480 blocks are best (stage 1: 28.4 us vs 30.8 at 513 and 33.8 at
+//     256); rounding the cap UP to a multiple of nH (513 / 516 blocks) leaves blocks that start only when a resident
+//     block has finished all its rounds -- a second, almost empty phase.
+//   backward (1 block resident per CU = 256): many rounds per wave (stage 1, 8 rounds) -> stay below the resident
+//     count (240: 96 us; 258: 106; 288: 123); few rounds (stages 2-4) -> MORE blocks than CUs, so the dispatcher
+//     back-fills finished CUs and evens out the round quantisation (stage 2: 68 us at 320-384 blocks vs 91 at 258;
+//     stage 3: 55-58 vs 63).
+static int round_blocks(int want, int n_tasks, int nH) {
+    const int all = ((n_tasks + 3) / 4 + nH - 1) / nH * nH;      // one task per wave
+    int b = want >= nH ? want / nH * nH : nH;
+    return b < all ? b : all;
+}
+
 static int attn_grid_blocks(int n_tasks, int nH) {
-    // persistent waves: 4 per block; total wave count must be a multiple of nH so a wave keeps its head
-    int blocks = (n_tasks + 3) / 4;
-    const int cap = 256 * 2;  // 2 blocks (8 waves) per CU
-    if (blocks > cap) blocks = cap;
-    // 4*blocks % nH == 0  <=  blocks % nH == 0
-    blocks = (blocks + nH - 1) / nH * nH;
-    return blocks;
+    static const int forced = getenv("SWIN_ATTN_FWD_BLOCKS") ? atoi(getenv("SWIN_ATTN_FWD_BLOCKS")) : 0;   // development sweep
+    return round_blocks(forced > 0 ? forced : 480, n_tasks, nH);
 }
 
 extern "C" int swin_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bias_exp, void* out,
@@ -956,9 +969,10 @@ extern "C" int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int n
 }
 
 static int attn_bwd_blocks(int n_tasks, int nH) {
-    int blocks = (n_tasks + 3) / 4;
-    if (blocks > 256) blocks = 256;           // LDS allows one 4-wave block per CU
-    return (blocks + nH - 1) / nH * nH;
+    static const int forced = getenv("SWIN_ATTN_BWD_BLOCKS") ? atoi(getenv("SWIN_ATTN_BWD_BLOCKS")) : 0;   // development sweep
+    if (forced > 0) return round_blocks(forced, n_tasks, nH);
+    const bool many_rounds = n_tasks >= 6 * 960;                 // >= 6 rounds at 240 blocks
+    return round_blocks(many_rounds ? 240 : 384, n_tasks, nH);
 }
 
 extern "C" int64_t swin_window_attn_bwd_workspace_bytes(int B, int H, int W, int nH, int dtype) {
