@@ -94,10 +94,17 @@ def attention_roofline(device, steps=30):
             traffic = round(json.load(f)["kernels"]["win_attn_fwd_bf16@grid131328"]["hbm_bytes_per_launch_corrected"])
     except Exception:
         pass
+    # the BASELINE metric also names "WindowAttn MFMA util%": the core is HBM-bound (AI ~ 24 flop/B, ridge ~ 310), so this is
+    # small by construction.  useful flops = 4*B_*49^2*C (QK^T + PV); issued = the 49->64 padded tiles actually executed.
+    n_win = B * ((H + 6) // 7) * ((W + 6) // 7)
+    useful_tflops = 4.0 * n_win * 49 * 49 * C / (avg_ms * 1e-3) / 1e12
+    issued_tflops = 4.0 * n_win * 64 * 64 * C / (avg_ms * 1e-3) / 1e12
     return {"kernel": "win_attn_fwd_bf16_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(avg_ms, 5), "median_launch_ms": round(ms[len(ms) // 2], 5),
             "algorithmic_bytes_per_launch": alg_bytes,
+            "mfma_util": {"useful_tflops": round(useful_tflops, 1), "issued_tflops": round(issued_tflops, 1),
+                          "issued_frac_of_dense_bf16_peak": round(issued_tflops / MFMA_PEAK_TFLOPS, 4)},
             "shape": {"B": B, "H": H, "W": W, "C": C, "heads": nH, "shift": 3, "windows": B * 29 * 46}}
 
 

@@ -576,6 +576,30 @@ class SingleRoIExtractor(nn.Module):
         lv = torch.floor(torch.log2(scale / self.finest_scale + 1e-6))
         return lv.clamp(min=0, max=num_levels - 1).long()
 
+    def _fast_ok(self, feats, rois):
+        f0 = feats[0]
+        return (1 < len(feats) <= 4 and f0.is_cuda and f0.shape[1] % 4 == 0 and rois.size(0) > 0
+                and f0.dtype in (torch.float32, torch.bfloat16))
+
+    def forward_with(self, other, feats, rois, valid, other_rois, other_valid):
+        """This extractor's and ``other``'s RoI features from the same pyramid (the bbox and mask extractors of one
+        R-CNN stage): values equal the two separate calls; on the one-launch path their backward shares one fp32
+        gradient accumulator (ops.roi_align_multilevel_group)."""
+        a, b = self.roi_layers[0], other.roi_layers[0]
+        same = (len(feats) == other.num_inputs and tuple(self.featmap_strides) == tuple(other.featmap_strides)
+                and self.finest_scale == other.finest_scale and a.sampling_ratio == b.sampling_ratio and a.aligned == b.aligned)
+        if not (same and self._fast_ok(feats, rois) and other_rois.size(0) > 0):
+            return self(feats, rois, valid=valid), other(feats[:other.num_inputs], other_rois, valid=other_valid)
+        n = len(feats)
+        groups = []
+        for ext, r, v in ((self, rois, valid), (other, other_rois, other_valid)):
+            lv = ext.map_roi_levels(r, n)
+            if v is not None:
+                lv = torch.where(v, lv, torch.full_like(lv, -1))
+            groups.append((r, lv, ext.roi_layers[0].output_size))
+        return tuple(ops.roi_align_multilevel_group(list(feats), groups, self.featmap_strides[:n], a.sampling_ratio, a.aligned,
+                                                    out_dtype=feats[0].dtype))
+
     def forward(self, feats, rois, roi_scale_factor=None, valid=None):
         out_size = self.roi_layers[0].output_size
         num_levels = len(feats)
@@ -895,14 +919,19 @@ def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox
     valid = torch.cat(val_l)
     labels = torch.cat(lab_l)
     feats = x[:bbox_roi_extractor.num_inputs]
-    bbox_feats = bbox_roi_extractor(feats, rois, valid=valid)                      # HIP RoIAlign, all levels at once
+    mask_feats = None
+    if mask_head is not None and isinstance(bbox_roi_extractor, SingleRoIExtractor) and isinstance(mask_roi_extractor, SingleRoIExtractor):
+        # both RoI sets of the stage are known here: pool them together (shared backward accumulator)
+        bbox_feats, mask_feats = bbox_roi_extractor.forward_with(mask_roi_extractor, feats, rois, valid, bbox2roi(m_roi), torch.cat(m_val))
+    else:
+        bbox_feats = bbox_roi_extractor(feats, rois, valid=valid)                  # HIP RoIAlign, all levels at once
     cls_score, bbox_pred = bbox_head(bbox_feats)
     losses.update(bbox_head.loss(cls_score, bbox_pred, labels, torch.cat(tgt_l), torch.cat(pos_l), valid, rois=rois))
     state = dict(rois=roi_l, labels=labels, cls_score=cls_score, bbox_pred=bbox_pred, valid=val_l, pos_is_gt=isgt_l)
     if mask_head is not None:
-        pos_rois = bbox2roi(m_roi)
         mvalid = torch.cat(m_val)
-        mask_feats = mask_roi_extractor(x[:mask_roi_extractor.num_inputs], pos_rois, valid=mvalid)
+        if mask_feats is None:
+            mask_feats = mask_roi_extractor(x[:mask_roi_extractor.num_inputs], bbox2roi(m_roi), valid=mvalid)
         mask_pred = mask_head(mask_feats)
         size = cfg.get('mask_size', 28)
         # mask_target.py:66-122 on the device.  When every image has gt masks of one size, all images go through ONE

@@ -424,6 +424,47 @@ def test_linear_wgrad_bf16(ops, T, N1, N2):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_roi_align_multilevel_group_equals_separate_calls(ops, dtype):
+    """The grouped form (bbox 7x7 + mask 14x14 RoIs of one stage, one shared fp32 backward accumulator) == two separate
+    roi_align_multilevel calls (which are checked against the oracle): same outputs; summed feature gradients equal up to
+    the rounding of ONE cast instead of two casts + an addition."""
+    rng = np.random.RandomState(7)
+    N, C = 2, 16
+    strides = [4, 8, 16, 32]
+    shapes = [(48, 64), (24, 32), (12, 16), (6, 8)]
+    feats_np = [rng.randn(N, C, h, w).astype(np.float32) for h, w in shapes]
+    sets = []
+    for K, size in ((120, 7), (40, 14)):
+        rois = _rand_rois(rng, K, N, 256, 192)
+        lvls = rng.randint(-1, 4, K).astype(np.int32)
+        sets.append((torch.from_numpy(rois).cuda(), torch.from_numpy(lvls).cuda(), size))
+    gys = [torch.from_numpy(rng.randn(K, C, sz, sz).astype(np.float32)).cuda() for (K, sz) in ((120, 7), (40, 14))]
+
+    def leaves():
+        return [torch.from_numpy(f).cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True) for f in feats_np]
+    fa = leaves()
+    outs_a = [ops.roi_align_multilevel(fa, r, l, sz, strides, 0, True, out_dtype=dtype) for r, l, sz in sets]
+    sum((o.float() * g).sum() for o, g in zip(outs_a, gys)).backward()
+    fb = leaves()
+    outs_b = ops.roi_align_multilevel_group(fb, sets, strides, 0, True, out_dtype=dtype)
+    sum((o.float() * g).sum() for o, g in zip(outs_b, gys)).backward()
+    for a, b in zip(outs_a, outs_b):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    for a, b in zip(fa, fb):
+        tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+        close(b.grad.float(), a.grad.float(), tol * float(a.grad.float().abs().max()) + 1e-6, tol)
+    # a set without an incoming gradient is skipped
+    fc = leaves()
+    oc = ops.roi_align_multilevel_group(fc, sets, strides, 0, True, out_dtype=dtype)
+    (oc[0].float() * gys[0]).sum().backward()
+    fd = leaves()
+    (ops.roi_align_multilevel(fd, *sets[0][:2], sets[0][2], strides, 0, True, out_dtype=dtype).float() * gys[0]).sum().backward()
+    for a, b in zip(fd, fc):        # same launches; the fp32 atomics of the backward kernel may land in another order
+        tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+        close(b.grad.float(), a.grad.float(), tol * float(a.grad.float().abs().max()) + 1e-6, tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("out_size", [7, 14])
 def test_roi_align_multilevel(ops, dtype, out_size):
     """One launch over the pyramid == per-level mmcv roi_align on the rois of that level (single_level_roi_extractor.py
