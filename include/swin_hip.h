@@ -253,7 +253,7 @@ int det_paste_masks(const void* mask_logits, const int64_t* labels, const float*
                     void* stream);
 
 /* swin_adamw_step: AdamW over all parameters in ONE launch (+ the bf16 operand copy of the GEMM/conv weights).
- * Replaces torch.optim.AdamW.step as configured by configs/swin/*_coco.py:64-67 and the master->half copy of apex O1
+ * Replaces torch.optim.AdamW.step as configured by configs/swin/ *_coco.py:64-67 and the master->half copy of apex O1
  * (mmdet/apis/train.py:82-89).  segs: DEVICE array of {float* p; const float* g; float* m; float* v; bf16* shadow
  * (nullable); int64 n; int32 group; int32 pad} (56 bytes each); chunks: DEVICE array of int32 pairs (segment, chunk
  * index), one per swin_adamw_chunk_elems() elements of a segment; lr / weight_decay: HOST arrays of n_groups <= 8. */
