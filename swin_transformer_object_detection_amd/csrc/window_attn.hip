@@ -43,6 +43,29 @@ __device__ __forceinline__ int token_src(const WinGeom& g, int b, int wr, int wc
     return (b * g.H + r) * g.W + c;
 }
 
+// Window coordinates of a persistent wave's tasks.  Successive tasks of a wave are `n_waves / nH` windows apart; the
+// (image, window row, window column) triple is advanced by that constant stride with carries instead of being
+// re-derived from the task index with three integer divisions per task (and three more for the prefetched one).
+struct WinPos { int b, wr, wc; };
+struct WinStride { int db, dwr, dwc; };
+__device__ __forceinline__ WinPos win_decode(const WinGeom& g, int win) {
+    WinPos p;
+    p.b = win / g.nW;
+    const int wrem = win - p.b * g.nW;
+    p.wr = wrem / g.nWw; p.wc = wrem - p.wr * g.nWw;
+    return p;
+}
+__device__ __forceinline__ void win_advance(WinPos& p, const WinStride& s, const WinGeom& g) {
+    p.wc += s.dwc;
+    if (p.wc >= g.nWw) { p.wc -= g.nWw; p.wr += 1; }
+    p.wr += s.dwr;
+    if (p.wr >= g.nWh) { p.wr -= g.nWh; p.b += 1; }
+    p.b += s.db;
+}
+__device__ __forceinline__ bool win_interior(const WinGeom& g, const WinPos& p) {
+    return (p.wr * 7 + 6 + g.shift < g.H) && (p.wc * 7 + 6 + g.shift < g.W);
+}
+
 // ------------------------------------------------------------------------------------
 // relative position bias: table (169,nH) <-> expanded (nH,64,64) [head][key][query]
 // ------------------------------------------------------------------------------------
@@ -235,26 +258,25 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
     }
     const int which = L.which, part = L.part, tokr = L.tokr;
 
-    auto decode = [&](int t_, int& b, int& wr, int& wc, bool& interior) {
-        const int win = t_ / g.nH;
-        b = win / g.nW;
-        const int wrem = win - b * g.nW;
-        wr = wrem / g.nWw; wc = wrem - wr * g.nWw;
-        interior = (wr * 7 + 6 + g.shift < g.H) && (wc * 7 + 6 + g.shift < g.W);
-    };
+    WinPos cur = win_decode(g, task / g.nH);
+    WinStride stride;
+    {
+        const WinPos d = win_decode(g, n_waves / g.nH);          // n_waves % nH == 0
+        stride.db = d.b; stride.dwr = d.wr; stride.dwc = d.wc;
+    }
+    WinPos nxt = cur;
+    win_advance(nxt, stride, g);
 
     bf16x8 stg[10];
     {
-        int b, wr, wc; bool in;
-        decode(task, b, wr, wc, in);
-        if (in) fwd_issue_loads<true>(stg, L, g, qkv, qkv_bias, head, b, wr, wc);
-        else fwd_issue_loads<false>(stg, L, g, qkv, qkv_bias, head, b, wr, wc);
+        if (win_interior(g, cur)) fwd_issue_loads<true>(stg, L, g, qkv, qkv_bias, head, cur.b, cur.wr, cur.wc);
+        else fwd_issue_loads<false>(stg, L, g, qkv, qkv_bias, head, cur.b, cur.wr, cur.wc);
     }
     __builtin_amdgcn_wave_barrier();
 
-    for (; task < n_tasks; task += n_waves) {
-        int b, wr, wc; bool interior;
-        decode(task, b, wr, wc, interior);
+    for (; task < n_tasks; task += n_waves, cur = nxt, win_advance(nxt, stride, g)) {
+        const int b = cur.b, wr = cur.wr, wc = cur.wc;
+        const bool interior = win_interior(g, cur);
 
         // ---- registers -> LDS (q,k,v head slices, 49 x 32 each), then prefetch the next task ----
 #pragma unroll
@@ -265,10 +287,8 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (task + n_waves < n_tasks) {
-            int b2, wr2, wc2; bool in2;
-            decode(task + n_waves, b2, wr2, wc2, in2);
-            if (in2) fwd_issue_loads<true>(stg, L, g, qkv, qkv_bias, head, b2, wr2, wc2);
-            else fwd_issue_loads<false>(stg, L, g, qkv, qkv_bias, head, b2, wr2, wc2);
+            if (win_interior(g, nxt)) fwd_issue_loads<true>(stg, L, g, qkv, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
+            else fwd_issue_loads<false>(stg, L, g, qkv, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
         }
 
         const bool edge = g.shift > 0 && (wr == g.nWh - 1 || wc == g.nWw - 1);
@@ -590,26 +610,25 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
     }
     const int which = L.which, part = L.part, tokr = L.tokr;
 
-    auto decode = [&](int t_, int& b, int& wr, int& wc, bool& interior) {
-        const int win = t_ / g.nH;
-        b = win / g.nW;
-        const int wrem = win - b * g.nW;
-        wr = wrem / g.nWw; wc = wrem - wr * g.nWw;
-        interior = (wr * 7 + 6 + g.shift < g.H) && (wc * 7 + 6 + g.shift < g.W);
-    };
+    WinPos cur = win_decode(g, task / g.nH);
+    WinStride stride;
+    {
+        const WinPos d = win_decode(g, n_waves / g.nH);          // n_waves % nH == 0
+        stride.db = d.b; stride.dwr = d.wr; stride.dwc = d.wc;
+    }
+    WinPos nxt = cur;
+    win_advance(nxt, stride, g);
 
     bf16x8 stg[13];
     {
-        int b, wr, wc; bool in;
-        decode(task, b, wr, wc, in);
-        if (in) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, b, wr, wc);
-        else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, b, wr, wc);
+        if (win_interior(g, cur)) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, cur.b, cur.wr, cur.wc);
+        else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, cur.b, cur.wr, cur.wc);
     }
     __builtin_amdgcn_wave_barrier();
 
-    for (; task < n_tasks; task += n_waves) {
-        int b, wr, wc; bool interior;
-        decode(task, b, wr, wc, interior);
+    for (; task < n_tasks; task += n_waves, cur = nxt, win_advance(nxt, stride, g)) {
+        const int b = cur.b, wr = cur.wr, wc = cur.wc;
+        const bool interior = win_interior(g, cur);
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
             int t = 4 * i + tokr;
@@ -618,10 +637,8 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (task + n_waves < n_tasks) {
-            int b2, wr2, wc2; bool in2;
-            decode(task + n_waves, b2, wr2, wc2, in2);
-            if (in2) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, b2, wr2, wc2);
-            else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, b2, wr2, wc2);
+            if (win_interior(g, nxt)) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
+            else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
         }
 
         // ---------------- phase A -------------------------------------------------------------
