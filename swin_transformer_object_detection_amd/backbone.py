@@ -201,9 +201,10 @@ class SwinTransformer(nn.Module):
         else:
             raise TypeError('pretrained must be a str or None')
 
-    def train(self, mode=True):                                 # :627-630
+    def train(self, mode=True):                                 # :627-630 (returns self, as nn.Module.train / .eval() do)
         super().train(mode)
         self._freeze_stages()
+        return self
 
     # ------------------------------------------------------------------ the fused plan
     def _dp_scale(self, blk, B, device):

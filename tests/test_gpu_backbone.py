@@ -106,6 +106,35 @@ def test_swin_mini_bf16_vs_oracle(pkg, golden_dir):
         assert err.max() < 6e-2 * max(1.0, np.abs(ref).max()) and err.mean() < 2e-2, (i, err.max(), err.mean())
 
 
+@pytest.mark.parametrize("variant", ["base", "small"])
+def test_swin_base_and_small_geometries_vs_oracle(pkg, variant):
+    """The other BASELINE configurations' backbones (configs[3]: Swin-B C=128, heads 4/8/16/32; configs[4]: Swin-S) at
+    reduced depth: the fp32 HIP path against the oracle (atol 1e-4) on an image that needs padding at every stage, and the
+    bf16 path within bf16 accumulation error.  Exercises head counts that do not divide the persistent grids the way
+    Swin-T's do."""
+    dims = dict(base=(128, (4, 8, 16, 32)), small=(96, (3, 6, 12, 24)))[variant]
+    depths = (2, 2, 2, 2) if variant == "base" else (2, 2, 4, 2)
+    p = S.make_params(dims[0], depths, dims[1], seed=21, out_indices=(0, 1, 2, 3), randomize_norm=True)
+    img = torch.randn(1, 3, 150, 210, generator=torch.Generator().manual_seed(5))
+    ref = S.swin_forward(img, p, depths=depths, num_heads=dims[1])
+    for dtype in (torch.float32, torch.bfloat16):
+        m = pkg.backbone.SwinTransformer(embed_dim=dims[0], depths=list(depths), num_heads=list(dims[1]), drop_path_rate=0.0,
+                                         compute_dtype=dtype)
+        missing, unexpected = m.load_state_dict(p, strict=False)
+        assert not unexpected
+        m = m.cuda().eval()
+        with torch.no_grad():
+            outs = m(img.cuda())
+        for i, (o, r) in enumerate(zip(outs, ref)):
+            r = r.detach().numpy()
+            assert tuple(o.shape) == r.shape
+            if dtype == torch.float32:
+                _cmp(o, r, ATOL32, msg=f"{variant} out{i}")
+            else:
+                err = np.abs(o.float().cpu().numpy() - r)
+                assert err.max() < 6e-2 * max(1.0, np.abs(r).max()) and err.mean() < 2e-2, (variant, i, err.max(), err.mean())
+
+
 def test_fpn_vs_reference_golden(pkg, golden_dir):
     g = _load(golden_dir, "fpn_small")
     p = fpn_oracle.make_params((8, 16, 32, 64), 16, seed=int(g["seed"]))
