@@ -281,7 +281,9 @@ int swin_gemm_bf16(const void* a, const void* b, const void* bias, void* c, int6
  *   iou2d_calculator.py:108-158): the deltas are decoded against rois (n,4) with means/stds (HOST float[4]) and compared
  *   with gt boxes in `targets`; eps is GIoULoss.eps.  rois/means/stds may be NULL in mode 0.
  * det_mask_loss_*: FCNMaskHead.loss / mask_cross_entropy (cross_entropy_loss.py): mean BCE of the labelled channel over
- *   the valid RoIs; out2 = {loss, n_valid}.
+ *   the valid RoIs; out2 = {loss, n_valid}.  deconv_w 0: pred (n, nc, P) NCHW; deconv_w = mask width (P = deconv_w^2):
+ *   pred in the row order of the ConvTranspose2d(k=2,s=2)-as-GEMM output, (roi, h, w, ky, kx, class) -- the logits
+ *   before the 2x2 pixel shuffle of fcn_mask_head.py:122-126, so training skips the shuffle and layout copies.
  * Backward entries take grad_out aligned with the forward's out array; dcls/dreg (rpn) and dpred (mask) must be zeroed
  * by the caller, dcls/dbbox (bbox) are fully written. */
 int det_rpn_loss_fwd(const void* cls, const void* reg, int B, int64_t A, int S, const int64_t* inds, const uint8_t* flags,
@@ -296,10 +298,11 @@ int det_bbox_loss_bwd(const void* cls, const void* bbox, int n, int num_classes,
                       const uint8_t* flags, int reg_mode, int class_agnostic, float beta, float eps, const float* rois,
                       const float* means, const float* stds, const float* out4, const float* lse, const float* grad_out,
                       void* dcls, void* dbbox, int dtype, void* stream);
-int det_mask_loss_fwd(const void* pred, int n, int num_classes, int P, const float* target, const int64_t* labels,
-                      const uint8_t* valid, float* out2, float* per_roi, int dtype, void* stream);
-int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, const float* target, const int64_t* labels,
-                      const uint8_t* valid, const float* out2, const float* grad_out, void* dpred, int dtype, void* stream);
+int det_mask_loss_fwd(const void* pred, int n, int num_classes, int P, int deconv_w, const float* target,
+                      const int64_t* labels, const uint8_t* valid, float* out2, float* per_roi, int dtype, void* stream);
+int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, int deconv_w, const float* target,
+                      const int64_t* labels, const uint8_t* valid, const float* out2, const float* grad_out, void* dpred,
+                      int dtype, void* stream);
 
 /* swin_block_fwd / swin_block_bwd: the whole SwinTransformerBlock (swin_transformer.py:204-255) and its backward as ONE
  * call each -- the library's own kernels launched in sequence from native code (csrc/block_runner.hip lists the

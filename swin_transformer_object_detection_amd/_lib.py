@@ -64,8 +64,8 @@ SIGNATURES = {
     "det_bn_apply": [_p, _p, _i64, _i, _p, _p, _p, _i, _i, _p],
     "det_bn_bwd_reduce": [_p, _p, _i64, _i, _p, _p, _p, _i, _p, _p, _i, _p],
     "det_bn_bwd_apply": [_p, _p, _p, _i64, _i, _p, _p, _p, _i, _p, _p, _i, _p],
-    "det_mask_loss_fwd": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
-    "det_mask_loss_bwd": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
+    "det_mask_loss_fwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
+    "det_mask_loss_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "det_rpn_flatten_fwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
     "det_rpn_flatten_bwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
     "det_paste_masks": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p],

@@ -242,17 +242,27 @@ __global__ __launch_bounds__(256) void bbox_loss_bwd_kernel(const T* __restrict_
 // ------------------------------------------------------------------------------------------------ mask head
 // pred (n, nc, P) logits (P = 28*28), target (n, P) in {0,1}, labels (n), valid (n) u8.
 // out[0] = sum_valid mean_P BCE / max(#valid,1), out[1] = max(#valid,1).  grid = n blocks.
+// Element (i, c, pixel k) of the mask logits.  pw == 0: (n, nc, P) NCHW.  pw > 0 ("deconv order", pw = width of the
+// 2H x 2W mask): the rows of the ConvTranspose2d(k=2,s=2)-as-GEMM output, (roi, h, w, ky, kx) with the class innermost --
+// what FCNMaskHead produces BEFORE the 2x2 pixel shuffle, so the training path needs neither the shuffle copy of the
+// 256-channel activation nor the NHWC->NCHW copy of the logits (fcn_mask_head.py:117-126 computes the same values).
+__device__ __forceinline__ int64_t mask_elem(int i, int c, int k, int nc, int P, int pw) {
+    if (pw == 0) return ((int64_t)i * nc + c) * P + k;
+    const int Y = k / pw, X = k - Y * pw, W = pw >> 1;
+    return (((int64_t)i * (P >> 2) + (Y >> 1) * W + (X >> 1)) * 4 + (Y & 1) * 2 + (X & 1)) * nc + c;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const T* __restrict__ pred, int n, int nc, int P,
+__global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const T* __restrict__ pred, int n, int nc, int P, int pw,
                                                             const float* __restrict__ target, const int64_t* __restrict__ labels,
                                                             const uint8_t* __restrict__ valid, float* __restrict__ per_roi) {
     __shared__ float red[16];
     const int i = blockIdx.x;
     float s = 0.f;
     if (valid[i]) {
-        const T* p = pred + ((int64_t)i * nc + labels[i]) * P;
+        const int lab = (int)labels[i];
         const float* t = target + (int64_t)i * P;
-        for (int k = threadIdx.x; k < P; k += 256) s += bce_logits(Elt<T>::ld(p + k), t[k]);
+        for (int k = threadIdx.x; k < P; k += 256) s += bce_logits(Elt<T>::ld(pred + mask_elem(i, lab, k, nc, P, pw)), t[k]);
     }
     s = block_sum(s, red);
     if (threadIdx.x == 0) per_roi[i] = s / (float)P;
@@ -270,17 +280,19 @@ __global__ __launch_bounds__(1024) void mask_loss_final_kernel(const float* __re
 
 // dpred is ZEROED by the caller; only the labelled channel of valid RoIs is written.
 template <typename T>
-__global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const T* __restrict__ pred, int n, int nc, int P,
+__global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const T* __restrict__ pred, int n, int nc, int P, int pw,
                                                             const float* __restrict__ target, const int64_t* __restrict__ labels,
                                                             const uint8_t* __restrict__ valid, const float* __restrict__ out,
                                                             const float* __restrict__ gout, T* __restrict__ dpred) {
     const int i = blockIdx.x;
     if (!valid[i]) return;
     const float g = gout[0] / (out[1] * (float)P);
-    const int64_t base = ((int64_t)i * nc + labels[i]) * P;
+    const int lab = (int)labels[i];
     const float* t = target + (int64_t)i * P;
-    for (int k = threadIdx.x; k < P; k += 256)
-        Elt<T>::st(dpred + base + k, (sigmoidf(Elt<T>::ld(pred + base + k)) - t[k]) * g);
+    for (int k = threadIdx.x; k < P; k += 256) {
+        const int64_t e = mask_elem(i, lab, k, nc, P, pw);
+        Elt<T>::st(dpred + e, (sigmoidf(Elt<T>::ld(pred + e)) - t[k]) * g);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ RPN flatten
@@ -392,25 +404,29 @@ extern "C" int det_bbox_loss_bwd(const void* cls, const void* bbox, int n, int n
     return swin_launch_status();
 }
 
-// out2: loss, n_valid; per_roi (n) f32 scratch.
-extern "C" int det_mask_loss_fwd(const void* pred, int n, int num_classes, int P, const float* target, const int64_t* labels,
-                                 const uint8_t* valid, float* out2, float* per_roi, int dtype, void* stream) {
+// out2: loss, n_valid; per_roi (n) f32 scratch.  deconv_w: 0 = pred is (n, nc, P) NCHW; > 0 = "deconv order" rows with the
+// class innermost, deconv_w = width of the square mask (P == deconv_w^2, even) -- see mask_elem.
+extern "C" int det_mask_loss_fwd(const void* pred, int n, int num_classes, int P, int deconv_w, const float* target,
+                                 const int64_t* labels, const uint8_t* valid, float* out2, float* per_roi, int dtype, void* stream) {
     if (!pred || !target || !labels || !valid || !out2 || !per_roi || n <= 0 || num_classes <= 0 || P <= 0) return SWIN_ERR_BAD_ARG;
+    if (deconv_w != 0 && (deconv_w < 2 || (deconv_w & 1) || deconv_w * deconv_w != P)) return SWIN_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_T(dtype, (mask_loss_fwd_kernel<float><<<n, 256, 0, s>>>((const float*)pred, n, num_classes, P, target, labels, valid, per_roi)),
-               (mask_loss_fwd_kernel<bf16><<<n, 256, 0, s>>>((const bf16*)pred, n, num_classes, P, target, labels, valid, per_roi)))
+    DISPATCH_T(dtype, (mask_loss_fwd_kernel<float><<<n, 256, 0, s>>>((const float*)pred, n, num_classes, P, deconv_w, target, labels, valid, per_roi)),
+               (mask_loss_fwd_kernel<bf16><<<n, 256, 0, s>>>((const bf16*)pred, n, num_classes, P, deconv_w, target, labels, valid, per_roi)))
     mask_loss_final_kernel<<<1, 1024, 0, s>>>(per_roi, valid, n, out2);
     return swin_launch_status();
 }
 
-// dpred (n, nc, P): zeroed by the caller.
-extern "C" int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, const float* target, const int64_t* labels,
-                                 const uint8_t* valid, const float* out2, const float* grad_out, void* dpred, int dtype, void* stream) {
+// dpred (same layout as pred): zeroed by the caller.
+extern "C" int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, int deconv_w, const float* target,
+                                 const int64_t* labels, const uint8_t* valid, const float* out2, const float* grad_out, void* dpred,
+                                 int dtype, void* stream) {
     if (!pred || !target || !labels || !valid || !out2 || !grad_out || !dpred || n <= 0 || num_classes <= 0 || P <= 0)
         return SWIN_ERR_BAD_ARG;
+    if (deconv_w != 0 && (deconv_w < 2 || (deconv_w & 1) || deconv_w * deconv_w != P)) return SWIN_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_T(dtype, (mask_loss_bwd_kernel<float><<<n, 256, 0, s>>>((const float*)pred, n, num_classes, P, target, labels, valid, out2, grad_out, (float*)dpred)),
-               (mask_loss_bwd_kernel<bf16><<<n, 256, 0, s>>>((const bf16*)pred, n, num_classes, P, target, labels, valid, out2, grad_out, (bf16*)dpred)))
+    DISPATCH_T(dtype, (mask_loss_bwd_kernel<float><<<n, 256, 0, s>>>((const float*)pred, n, num_classes, P, deconv_w, target, labels, valid, out2, grad_out, (float*)dpred)),
+               (mask_loss_bwd_kernel<bf16><<<n, 256, 0, s>>>((const bf16*)pred, n, num_classes, P, deconv_w, target, labels, valid, out2, grad_out, (bf16*)dpred)))
     return swin_launch_status();
 }
 

@@ -828,17 +828,40 @@ class FCNMaskHead(nn.Module):
         x = self._deconv2x2_relu(x, dt)
         return _conv(x, self.conv_logits, dt)
 
-    def _deconv2x2_relu(self, x, dt):
-        """ConvTranspose2d(k=2, s=2) + ReLU (fcn_mask_head.py:122-125) as one GEMM over tokens followed by a
-        2x2 pixel shuffle: out[n,co,2y+ky,2x+kx] = sum_ci x[n,ci,y,x] W[ci,co,ky,kx] + b[co]."""
+    def _deconv_rows(self, x, dt):
+        """ConvTranspose2d(k=2, s=2) + ReLU (fcn_mask_head.py:122-125) as one GEMM over tokens:
+        rows[(n,y,x), (ky,kx,co)] = relu(sum_ci x[n,ci,y,x] W[ci,co,ky,kx] + b[co]) = out[n, co, 2y+ky, 2x+kx]."""
         P, C, H, W = x.shape
         Co = self.upsample.out_channels
         tok = x.permute(0, 2, 3, 1).reshape(P * H * W, C)
         w = _cast(self.upsample.weight, dt).permute(2, 3, 1, 0).reshape(4 * Co, C)     # rows (ky,kx,co)
         b = _cast(self.upsample.bias, dt).repeat(4)
-        y = F.relu(ops.linear(tok, w, b, dt), inplace=True)                            # (P*H*W, 4*Co)
+        return F.relu(ops.linear(tok, w, b, dt), inplace=True)                         # (P*H*W, 4*Co)
+
+    def _deconv2x2_relu(self, x, dt):
+        """_deconv_rows followed by the 2x2 pixel shuffle -> (P, Co, 2H, 2W) channels-last view."""
+        P, C, H, W = x.shape
+        Co = self.upsample.out_channels
+        y = self._deconv_rows(x, dt)
         y = y.view(P, H, W, 2, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(P, 2 * H, 2 * W, Co)
         return y.permute(0, 3, 1, 2)                                                   # channels-last view
+
+    def forward_rows(self, x):
+        """Training form of forward(): the same logits as rows in deconvolution order, (roi, y, x, ky, kx) x class, i.e.
+        WITHOUT the pixel shuffle of the 256-channel activation and without the NHWC->NCHW copy of the logits -- the 1x1
+        conv_logits is per pixel, so it commutes with the shuffle, and ops.mask_loss(deconv_order=True) indexes the rows
+        directly.  forward(x)[n, c, 2y+ky, 2x+kx] == forward_rows(x)[((n*H + y)*W + x)*4 + ky*2 + kx, c]."""
+        dt = self.compute_dtype
+        x = _cast(x, dt).contiguous(memory_format=torch.channels_last)
+        for c in self.convs:
+            x = _conv(x, c.conv, dt, padding=1, relu=True)
+        Co = self.upsample.out_channels
+        rows = self._deconv_rows(x, dt).view(-1, Co)                                   # (P*H*W*4, Co)
+        return ops.linear(rows, self.conv_logits.weight, self.conv_logits.bias, dt)    # (P*H*W*4, num_classes)
+
+    def loss_rows(self, rows, mask_targets, labels, valid):
+        """loss() on forward_rows() output (GPU)."""
+        return dict(loss_mask=ops.mask_loss(rows, mask_targets, labels, valid, deconv_order=True) * self.loss_mask_weight)
 
     def loss(self, mask_pred, mask_targets, labels, valid=None):
         """mask_cross_entropy (cross_entropy_loss.py): mean BCE over (positives x 28 x 28) of the class channel."""
@@ -932,7 +955,8 @@ def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox
         mvalid = torch.cat(m_val)
         if mask_feats is None:
             mask_feats = mask_roi_extractor(x[:mask_roi_extractor.num_inputs], bbox2roi(m_roi), valid=mvalid)
-        mask_pred = mask_head(mask_feats)
+        rows_path = mask_feats.is_cuda and hasattr(mask_head, 'forward_rows') and mask_feats.size(0) > 0
+        mask_pred = mask_head.forward_rows(mask_feats) if rows_path else mask_head(mask_feats)
         size = cfg.get('mask_size', 28)
         # mask_target.py:66-122 on the device.  When every image has gt masks of one size, all images go through ONE
         # RoIAlign launch (the gt masks stacked along the batch axis, the RoI's batch index offset by its image's
@@ -957,7 +981,10 @@ def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox
                 r = torch.cat([m_gt[i].to(m_roi[i].dtype)[:, None], m_roi[i]], 1)
                 t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)
                 tg.append((t[:, 0] >= 0.5).float())
-        losses.update(mask_head.loss(mask_pred, torch.cat(tg), torch.cat(m_lab), mvalid))
+        if rows_path:
+            losses.update(mask_head.loss_rows(mask_pred, torch.cat(tg), torch.cat(m_lab), mvalid))
+        else:
+            losses.update(mask_head.loss(mask_pred, torch.cat(tg), torch.cat(m_lab), mvalid))
     return losses, state
 
 

@@ -101,30 +101,44 @@ def bbox_loss(cls_score, bbox_pred, labels, targets, flags, num_classes, class_a
 
 class _MaskLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, labels, valid):
+    def forward(ctx, pred, target, labels, valid, deconv_w):
         pred = pred.contiguous()
-        n, nc = pred.shape[0], pred.shape[1]
-        P = pred.shape[2] * pred.shape[3]
+        n = target.shape[0]
+        P = target.shape[1] * target.shape[2]
+        if deconv_w:
+            nc = pred.shape[-1]
+            if pred.numel() != n * P * nc or deconv_w * deconv_w != P:
+                raise SwinHipError(f"mask_loss: deconv-order logits {tuple(pred.shape)} do not match {n} RoIs of {P} pixels")
+        else:
+            nc = pred.shape[1]
+            if pred.shape[0] != n or pred.shape[2] * pred.shape[3] != P:
+                raise SwinHipError(f"mask_loss: logits {tuple(pred.shape)} do not match targets {tuple(target.shape)}")
         out = torch.empty(2, device=pred.device, dtype=torch.float32)
         per_roi = torch.empty(n, device=pred.device, dtype=torch.float32)
-        call("det_mask_loss_fwd", _p(pred), n, nc, P, _p(target), _p(labels), _p(valid), _p(out), _p(per_roi), _dt(pred), _s())
+        call("det_mask_loss_fwd", _p(pred), n, nc, P, int(deconv_w), _p(target), _p(labels), _p(valid), _p(out), _p(per_roi), _dt(pred),
+             _s())
         ctx.save_for_backward(pred, target, labels, valid, out)
+        ctx.meta = (n, nc, P, int(deconv_w))
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
         pred, target, labels, valid, out = ctx.saved_tensors
-        n, nc = pred.shape[0], pred.shape[1]
-        P = pred.shape[2] * pred.shape[3]
+        n, nc, P, deconv_w = ctx.meta
         dpred = torch.zeros_like(pred)
-        call("det_mask_loss_bwd", _p(pred), n, nc, P, _p(target), _p(labels), _p(valid), _p(out), _p(g.float().reshape(1)), _p(dpred),
-             _dt(pred), _s())
-        return dpred, None, None, None
+        call("det_mask_loss_bwd", _p(pred), n, nc, P, deconv_w, _p(target), _p(labels), _p(valid), _p(out), _p(g.float().reshape(1)),
+             _p(dpred), _dt(pred), _s())
+        return dpred, None, None, None, None
 
 
-def mask_loss(mask_pred, mask_targets, labels, valid):
-    """mean sigmoid-BCE of the labelled class channel over the valid RoIs (mask_cross_entropy, reduction 'mean')."""
-    return _MaskLoss.apply(mask_pred, mask_targets.contiguous().float(), labels.contiguous(), valid.to(torch.uint8).contiguous())
+def mask_loss(mask_pred, mask_targets, labels, valid, deconv_order=False):
+    """mean sigmoid-BCE of the labelled class channel over the valid RoIs (mask_cross_entropy, reduction 'mean').
+    mask_pred: (n, num_classes, h, w) logits; or, with ``deconv_order``, the (n * h/2 * w/2 * 4, num_classes) rows of
+    FCNMaskHead.forward_rows -- the same logits before the 2x2 pixel shuffle."""
+    t = mask_targets.contiguous().float()
+    if t.shape[0] == 0:
+        return mask_pred.sum() * 0
+    return _MaskLoss.apply(mask_pred, t, labels.contiguous(), valid.to(torch.uint8).contiguous(), int(t.shape[2]) if deconv_order else 0)
 
 
 class _RPNFlatten(torch.autograd.Function):

@@ -682,3 +682,42 @@ def test_checkpoint_resume_continues_identically(tmp_path):
     train(b, ob, xs[2])
     for (n, p), q in zip(a.named_parameters(), b.parameters()):
         assert torch.equal(p, q), n
+
+
+@pytest.mark.gpu
+def test_mask_head_rows_path_equals_standard_path():
+    """FCNMaskHead.forward_rows / loss_rows (training: logits kept in deconvolution row order, no pixel-shuffle or layout
+    copies) == forward / loss (fcn_mask_head.py:117-126 + mask_cross_entropy): same logits element for element, same
+    loss, same gradients for the input and every parameter."""
+    from swin_transformer_object_detection_amd import detector
+    torch.manual_seed(3)
+    head = detector.FCNMaskHead(num_convs=2, in_channels=256, conv_out_channels=256, num_classes=80,
+                                compute_dtype=torch.bfloat16).cuda()
+    head.init_weights()
+    P = 40                                                     # 40 * 14 * 14 tokens >= the GEMM path's minimum row count
+    x = torch.randn(P, 256, 14, 14, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    tgt = (torch.rand(P, 28, 28, device='cuda') > 0.5).float()
+    labels = torch.randint(0, 80, (P,), device='cuda')
+    valid = torch.rand(P, device='cuda') > 0.25
+    res = {}
+    for mode in ("std", "rows"):
+        for p_ in head.parameters():
+            p_.grad = None
+        xi = x.clone().requires_grad_(True)
+        if mode == "std":
+            pred = head(xi)
+            loss = head.loss(pred, tgt, labels, valid)['loss_mask']
+            logits = pred.float()
+        else:
+            rows = head.forward_rows(xi)
+            loss = head.loss_rows(rows, tgt, labels, valid)['loss_mask']
+            logits = rows.float().view(P, 14, 14, 2, 2, 80).permute(0, 5, 1, 3, 2, 4).reshape(P, 80, 28, 28)
+        loss.backward()
+        res[mode] = (logits.detach(), float(loss), xi.grad.float(), {n: p_.grad.float().clone() for n, p_ in head.named_parameters()})
+    assert torch.equal(res["std"][0], res["rows"][0])
+    assert abs(res["std"][1] - res["rows"][1]) < 1e-5 * max(1.0, abs(res["std"][1]))
+    gs, gr = res["std"][2], res["rows"][2]
+    assert float((gs - gr).abs().max()) <= 2.0 ** -7 * float(gs.abs().max()) + 1e-9
+    for n in res["std"][3]:
+        a, b = res["std"][3][n], res["rows"][3][n]
+        assert float((a - b).abs().max()) <= 2.0 ** -6 * float(a.abs().max()) + 1e-9, n
