@@ -177,20 +177,22 @@ __device__ __forceinline__ void fwd_issue_loads(bf16x8 (&stg)[10], const FwdLane
                                                 const float* __restrict__ qkv_bias, int head, int b, int wr, int wc) {
     const int C3 = 3 * g.C;
     const int ch = L.which * g.C + head * HD + L.part * 8;
+    // Every lane issues every load (offsets of the unused tail pieces are clamped to the last token; only the LDS write
+    // is predicated): a load inside a divergent `if` makes the compiler close the region with s_waitcnt vmcnt(0), i.e.
+    // the wave would sit out the full latency of the prefetch it has just issued.
     if (INTERIOR) {
         const bf16* pb = qkv + ((size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift) * C3 + ch;
 #pragma unroll
-        for (int i = 0; i < 10; ++i)
-            if (i < 9 || L.tokr < 4) stg[i] = *(const bf16x8*)(pb + L.ld_off[i]);
+        for (int i = 0; i < 10; ++i) stg[i] = *(const bf16x8*)(pb + L.ld_off[i]);
     } else {
+        // general path (wrap-around / padding): padded tokens read qkv.bias (their q|k|v); clamped address, fixed up by VALUE
+        const bf16x8 padv = bias_to_bf16x8(qkv_bias + ch);
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            int t = 5 * i + L.tokr;
-            if (t < NTOK) {
-                int src = token_src(g, b, wr, wc, t);
-                if (src >= 0) stg[i] = *(const bf16x8*)(qkv + (size_t)src * C3 + ch);
-                else stg[i] = bias_to_bf16x8(qkv_bias + ch);
-            }
+            int t = 5 * i + L.tokr; if (t >= NTOK) t = NTOK - 1;
+            const int src = token_src(g, b, wr, wc, t);
+            const bf16x8 v = *(const bf16x8*)(qkv + (size_t)(src >= 0 ? src : 0) * C3 + ch);
+            stg[i] = src >= 0 ? v : padv;
         }
     }
 }
@@ -518,8 +520,7 @@ __device__ __forceinline__ void bwd_issue_loads(bf16x8 (&stg)[13], const BwdLane
         const size_t wbase = (size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift;
         const bf16* pb = is_do ? dout + wbase * g.C + ch : qkv + wbase * C3 + ch;
 #pragma unroll
-        for (int i = 0; i < 13; ++i)
-            if (i < 12 || L.tokr == 0) stg[i] = *(const bf16x8*)(pb + L.ld_off[i]);
+        for (int i = 0; i < 13; ++i) stg[i] = *(const bf16x8*)(pb + L.ld_off[i]);    // unpredicated: see fwd_issue_loads
     } else {
         // general path (windows touching the wrap-around or the padding): padded tokens read qkv.bias (their q|k|v)
         // or zero (dO of a cropped row).  Loads go to a clamped address and are fixed up by VALUE.
@@ -532,12 +533,10 @@ __device__ __forceinline__ void bwd_issue_loads(bf16x8 (&stg)[13], const BwdLane
         const int stride = is_do ? g.C : C3;
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
-            int t = 4 * i + L.tokr;
-            if (t < NTOK) {
-                int src = token_src(g, b, wr, wc, t);
-                bf16x8 v = *(const bf16x8*)(pb + (size_t)(src >= 0 ? src : 0) * stride);
-                stg[i] = src >= 0 ? v : padv;
-            }
+            int t = 4 * i + L.tokr; if (t >= NTOK) t = NTOK - 1;
+            const int src = token_src(g, b, wr, wc, t);
+            const bf16x8 v = *(const bf16x8*)(pb + (size_t)(src >= 0 ? src : 0) * stride);
+            stg[i] = src >= 0 ? v : padv;
         }
     }
 }
