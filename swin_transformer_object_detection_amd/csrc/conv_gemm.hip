@@ -69,13 +69,6 @@ struct ConvA {
     }
 };
 
-__device__ __forceinline__ uint4 masked_load16(const bf16* p, int64_t off) {
-    const bool ok = off >= 0;
-    uint4 v = *(const uint4*)(p + (ok ? off : 0));
-    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-    return v;
-}
-
 __device__ __forceinline__ int swz(int row, int piece) { return piece ^ ((row >> 1) & 7); }
 
 __device__ uint4 g_zero16[4];      // zero-initialised: source of padded 16-byte pieces

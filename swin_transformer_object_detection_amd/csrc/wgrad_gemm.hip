@@ -51,13 +51,6 @@ struct ConvX {
     }
 };
 
-__device__ __forceinline__ uint4 masked_load16w(const bf16* p, int64_t off) {
-    const bool ok = off >= 0;
-    uint4 v = *(const uint4*)(p + (ok ? off : 0));
-    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-    return v;
-}
-
 // transposed fragment: rows t0 + 8*h + j (j = 0..7) of column (col0 + lane&31) of a [WT][WROW] tile
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t0, int col0, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
@@ -105,12 +98,25 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
             X.init(xs[i], trow[i], n2_0 + spiece * 8);
         }
     }
+    // Loads are issued RAW from a clamped address and zeroed by value only when they are stored to LDS (gmask, after the
+    // MFMAs of the current stage): a select right behind the load makes the compiler wait for the load on the spot
+    // (s_waitcnt vmcnt(0)), i.e. the "prefetch" of the next stage was not overlapping anything.
+    bool oka[4], okb[4];
     auto gload = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool tin = trow[i] < t_end;
-            ra[i] = masked_load16w(dy, (tin && n1ok) ? aoff[i] : -1);
-            rb[i] = masked_load16w(X.x, tin ? X.offset(xs[i]) : -1);
+            const int64_t ob = tin ? X.offset(xs[i]) : -1;
+            oka[i] = tin && n1ok; okb[i] = ob >= 0;
+            ra[i] = *(const uint4*)(dy + (oka[i] ? aoff[i] : 0));
+            rb[i] = *(const uint4*)(X.x + (okb[i] ? ob : 0));
+        }
+    };
+    auto gmask = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!oka[i]) ra[i] = uint4{0u, 0u, 0u, 0u};
+            if (!okb[i]) rb[i] = uint4{0u, 0u, 0u, 0u};
         }
     };
     auto gadvance = [&]() {
@@ -151,12 +157,13 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
     const int iters = (int)((stages + WKG - 1) / WKG);
     if (iters > 0) {
         gload();
+        gmask();
         if (do_bias) bias_acc();
         lstore();
         __syncthreads();
         for (int it = 0; it < iters; ++it) {
             const bool more = it + 1 < iters;
-            if (more) { gadvance(); gload(); if (do_bias) bias_acc(); }
+            if (more) { gadvance(); gload(); }                // in flight during the MFMAs below
 #pragma unroll
             for (int s = 0; s < 4; ++s) {                     // 16 t per MFMA k-step
                 bf16x8 af[2], bfr[2];
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
             __syncthreads();                                  // everyone is done reading this stage
-            if (more) lstore();
+            if (more) { gmask(); if (do_bias) bias_acc(); lstore(); }
             __syncthreads();
         }
     }
