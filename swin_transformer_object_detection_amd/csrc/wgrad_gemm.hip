@@ -7,6 +7,8 @@
 // activation for a 3x3/pad-1 convolution (N2 = 9*Cin ordered (ky,kx,cin); replaces torch.cat + library GEMM).
 // Reference sites: the autograd of nn.Linear at swin_transformer.py:129,151,33,36,296 and of the 3x3 convs at
 // fpn.py:195-197, rpn_head.py:43, fcn_mask_head.py:119-121.
+#include <cstdlib>
+
 #include "common.h"
 
 #define WT 64          // t rows per stage
@@ -255,7 +257,11 @@ static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, i
     // blocks to aim for: 512 wave-quads for the two-k-group form (256 blocks of 8 waves); 384 for the many-tile form,
     // of the Linear layers, where fewer splits (less atomic traffic) outweigh the fuller chip (47 -> 42 us at 1536x384;
     // the conv form, 36 big-K tiles, prefers the 512: 303 vs 340 us at P2)
-    const int target = WKG == 1 ? XLoader::kBlocksManyTiles : 512;
+    static const int forced = getenv("SWIN_WGRAD_BLOCKS") ? atoi(getenv("SWIN_WGRAD_BLOCKS")) : 0;      // development sweep
+    // ConvX (36 tiles): swept again with the overlapped loads -- 640 blocks for the long contractions (P2 291 -> 275 us, mask
+    // head convs 112 -> 104 us), 384 for the short ones (T < 24000: P4 42 -> 40 us)
+    const int many = XLoader::kBlocksManyTiles == 512 ? (T >= 24000 ? 640 : 384) : XLoader::kBlocksManyTiles;
+    const int target = forced > 0 ? forced : (WKG == 1 ? many : 512);
     int splits = (int)((target / WKG + (int64_t)g1 * g2 - 1) / ((int64_t)g1 * g2));
     int64_t max_splits = (stages + WKG - 1) / WKG;
     if (splits > max_splits) splits = (int)max_splits;
