@@ -619,7 +619,13 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
     win_advance(nxt, stride, g);
 
     bf16x8 stg[13];
+    float lse_n[2];
     {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = 32 * qt + c;
+            lse_n[qt] = lse[(size_t)task * TILE + (q < NTOK ? q : 0)];
+        }
         if (win_interior(g, cur)) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, cur.b, cur.wr, cur.wc);
         else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, cur.b, cur.wr, cur.wc);
     }
@@ -635,7 +641,16 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // this task's log-sum-exp rows were loaded WITH its q|k|v|dO pieces, one iteration ahead: the load counter is in
+        // order, so a load issued after the 13 prefetch loads and consumed in phase A meant s_waitcnt vmcnt(0) there --
+        // a wait for the whole prefetch in the middle of the task
+        const float lse_q[2] = {lse_n[0], lse_n[1]};
         if (task + n_waves < n_tasks) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int q = 32 * qt + c;
+                lse_n[qt] = lse[(size_t)(task + n_waves) * TILE + (q < NTOK ? q : 0)];
+            }
             if (win_interior(g, nxt)) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
             else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
         }
@@ -678,7 +693,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
             }
             const int q = 32 * qt + c;
             const bool qv = q < NTOK;
-            const float l2 = lse[(size_t)task * TILE + (qv ? q : 0)] * LOG2E;
+            const float l2 = lse_q[qt] * LOG2E;
             float d4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
