@@ -38,7 +38,11 @@ const size_t kWorkspace = 32u << 20;
 // First use of a shape: time the library's top candidates on the caller's own buffers and keep the fastest (the
 // heuristic's first choice is not always the best for these tall-skinny shapes).  One-off host synchronisation per
 // shape, during warm-up; SWIN_GEMM_TUNE=0 keeps the heuristic's first choice.
-static const int kCandidates = 12;
+static const int kMaxCandidates = 64;
+static int candidates() {                                    // SWIN_GEMM_CANDIDATES: development sweep (default 12)
+    static const int n = getenv("SWIN_GEMM_CANDIDATES") ? atoi(getenv("SWIN_GEMM_CANDIDATES")) : 12;
+    return n < 1 ? 1 : (n > kMaxCandidates ? kMaxCandidates : n);
+}
 
 static float time_algo(Plan& p, const hipblasLtMatmulHeuristicResult_t& h, const void* a, const void* b, const void* bias,
                        void* c, void* workspace, hipStream_t s) {
@@ -99,9 +103,9 @@ Plan* get_plan(int64_t M, int N, int K, int layout, int bias, const void* a = nu
         const void* dummy = bias_ptr ? bias_ptr : (const void*)0x1000;
         hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &dummy, sizeof(dummy));
     }
-    hipblasLtMatmulHeuristicResult_t cand[kCandidates];
+    hipblasLtMatmulHeuristicResult_t cand[kMaxCandidates];
     static const bool tune = !(getenv("SWIN_GEMM_TUNE") && getenv("SWIN_GEMM_TUNE")[0] == '0');
-    const int want = (tune && a && b && c && workspace) ? kCandidates : 1;
+    const int want = (tune && a && b && c && workspace) ? candidates() : 1;
     hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.c, pref, want, cand, &found);
     hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) return nullptr;
