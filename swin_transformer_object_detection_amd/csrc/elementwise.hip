@@ -1,5 +1,7 @@
 // HBM-bound elementwise / gather kernels of the Swin block and the FPN top-down path.
 // All of them move 16 bytes per lane per access (coalesced dwordx4).
+#include <cstdlib>
+
 #include "common.h"
 
 static inline int ew_blocks(int64_t n_items) {
@@ -111,11 +113,16 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_cols_kernel(const T* __rest
 
 static inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
-// grid with (blocks * 256) % vec_per_row == 0, about 2048 blocks at most
+static int gelu_cap() {                                     // SWIN_GELU_BLOCKS: development sweep (default 2048)
+    static const int n = getenv("SWIN_GELU_BLOCKS") ? atoi(getenv("SWIN_GELU_BLOCKS")) : 2048;
+    return n < 1 ? 1 : n;
+}
+
+// grid with (blocks * 256) % vec_per_row == 0, about gelu_cap() blocks at most
 static int bias_gelu_blocks(int64_t nvec, int vpr) {
     int unit = vpr / gcd_i(256, vpr);
     int64_t want = (nvec + 255) / 256;
-    if (want > 2048) want = 2048;
+    if (want > gelu_cap()) want = gelu_cap();
     int64_t b = (want + unit - 1) / unit * unit;
     return (int)(b > 0 ? b : unit);
 }
@@ -133,7 +140,7 @@ static int bias_gelu_launch(const void* x, const float* bias, const void* dy, vo
         if (C % vec) return SWIN_ERR_UNSUPPORTED;
         const int vpr = C / vec, cw = gcd_i(vpr, 64), rpb = 256 / cw, nchunk = vpr / cw;
         int64_t ny = (rows + rpb - 1) / rpb;
-        int64_t cap = (2048 + nchunk - 1) / nchunk;            // ~2048 blocks: 8 per CU
+        int64_t cap = (gelu_cap() + nchunk - 1) / nchunk;      // ~2048 blocks: 8 per CU
         if (ny > cap) ny = cap;
         dim3 grid(nchunk, (unsigned)ny);
         if (dtype == SWIN_BF16)
