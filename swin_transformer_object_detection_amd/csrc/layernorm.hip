@@ -56,7 +56,8 @@ template <typename T> static LnLaunch ln_plan(int64_t rows, int C) {
     for (int a : allowed) if (a >= NV) { nv2 = a; break; }
     LnLaunch p; p.G = G; p.NV = nv2; p.rows_per_block = 256 / G;
     int64_t nb = (rows + p.rows_per_block - 1) / p.rows_per_block;
-    p.blocks = (int)(nb < 2048 ? nb : 2048);
+    static const int cap = getenv("SWIN_LN_BLOCKS") ? atoi(getenv("SWIN_LN_BLOCKS")) : 2048;      // development sweep
+    p.blocks = (int)(nb < cap ? nb : cap);
     return p;
 }
 
