@@ -12,10 +12,17 @@ and cannot be imported here):
   smooth_l1 / giou_loss / bbox_head_loss   mmdet/models/losses/{smooth_l1_loss,iou_loss}.py, bbox_head.py:188-238
   regress_by_class mmdet/models/roi_heads/bbox_heads/bbox_head.py:409-436 (+ cascade_roi_head.py:274-281)
   batch_norm_train torch.nn.SyncBatchNorm arithmetic (norm layer of ConvFCBBoxHead, convfc_bbox_head.py:99-107)
-Pinned by the reference's own known-answer test for delta2bbox
-(tests/test_utils/test_coder.py:26-60, docstring example at
-delta_xywh_bbox_coder.py:172-182); the rest: PARITY UNPINNED (shape-only tests
-upstream), cross-checked by properties in tests/test_oracle_callers.py.
+  bbox2delta       mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:87-130
+  cross_entropy / binary_cross_entropy / mask_cross_entropy   mmdet/models/losses/cross_entropy_loss.py:9-138
+  crop_and_resize / mask_target   mmdet/core/mask/structures.py:328-358, mmdet/core/mask/mask_target.py:6-122
+
+PINNED (round 2) by fixtures generated from the reference's own files, loaded by path in the build container
+(tests/golden/make_golden_callers.py -> tests/golden/callers_pure.npz: anchors, coder, IoU/GIoU, MaxIoUAssigner, losses,
+_do_paste_mask, map_roi_levels, bbox2roi, bbox2result; callers_with_ops.npz: RPNHead._get_bboxes, multiclass_nms,
+mask_target run from the reference's code with the two absent mmcv ops replaced by det_ops_oracle), checked in
+tests/test_oracle_callers_golden.py, plus the reference's known-answer tests (tests/test_utils/test_coder.py:26-60,
+test_assigner.py:14-152, test_anchor.py:22-40).  What stays PARITY UNPINNED is only the arithmetic of RoIAlign and nms
+themselves (mmcv-full absent) -- oracle/__init__.py.
 """
 import numpy as np
 
@@ -156,19 +163,32 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, n
 
 
 # ---- training targets (checker for csrc/det_targets.hip) ---------------------------------------------------------
-def bbox_overlaps(b1, b2, eps=1e-6):
-    """IoU matrix (len(b1), len(b2)) in float32, operation order of
-    mmdet/core/bbox/iou_calculators/iou2d_calculator.py (bbox_overlaps, mode='iou', is_aligned=False)."""
-    b1 = np.asarray(b1, np.float32).reshape(-1, 4)
-    b2 = np.asarray(b2, np.float32).reshape(-1, 4)
+def bbox_overlaps(b1, b2, eps=1e-6, mode='iou', is_aligned=False):
+    """IoU / IoF / GIoU, matrix (len(b1), len(b2)) or aligned pairs, float32, operation order of
+    mmdet/core/bbox/iou_calculators/iou2d_calculator.py:71-158 (bbox_overlaps)."""
+    f = np.float32
+    b1 = np.asarray(b1, f).reshape(-1, 4)
+    b2 = np.asarray(b2, f).reshape(-1, 4)
     a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
     a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
-    lt = np.maximum(b1[:, None, :2], b2[None, :, :2])
-    rb = np.minimum(b1[:, None, 2:], b2[None, :, 2:])
-    wh = np.maximum(rb - lt, np.float32(0))
+    if is_aligned:
+        B1, B2, A1, A2 = b1, b2, a1, a2
+    else:
+        B1, B2, A1, A2 = b1[:, None, :], b2[None, :, :], a1[:, None], a2[None, :]
+    lt = np.maximum(B1[..., :2], B2[..., :2])
+    rb = np.minimum(B1[..., 2:], B2[..., 2:])
+    wh = np.maximum(rb - lt, f(0))
     inter = wh[..., 0] * wh[..., 1]
-    union = np.maximum(a1[:, None] + a2[None, :] - inter, np.float32(eps))
-    return (inter / union).astype(np.float32)
+    union = (A1 + A2 - inter) if mode in ('iou', 'giou') else (A1 + f(0) * inter)
+    union = np.maximum(union, f(eps))
+    ious = (inter / union).astype(f)
+    if mode in ('iou', 'iof'):
+        return ious
+    elt = np.minimum(B1[..., :2], B2[..., :2])
+    erb = np.maximum(B1[..., 2:], B2[..., 2:])
+    ewh = np.maximum(erb - elt, f(0))
+    earea = np.maximum(ewh[..., 0] * ewh[..., 1], f(eps))
+    return (ious - (earea - union) / earea).astype(f)
 
 
 def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_low_quality=True, gt_labels=None):
@@ -352,3 +372,101 @@ def batch_norm_train_bwd(x, gamma, beta, dy, eps=1e-5, relu=False):
     n = x.shape[0]
     dx = g * invstd * (dy - sdy / n - xhat * sdyx / n)
     return dx, sdyx, sdy
+
+
+# ---- round 2: the remaining callers, each pinned by tests/golden/callers_*.npz ---------------------------------------
+def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+    """delta_xywh_bbox_coder.py:87-130 (fp32)."""
+    f = np.float32
+    p, g = np.asarray(proposals, f), np.asarray(gt, f)
+    px, py = (p[:, 0] + p[:, 2]) * f(0.5), (p[:, 1] + p[:, 3]) * f(0.5)
+    pw, ph = p[:, 2] - p[:, 0], p[:, 3] - p[:, 1]
+    gx, gy = (g[:, 0] + g[:, 2]) * f(0.5), (g[:, 1] + g[:, 3]) * f(0.5)
+    gw, gh = g[:, 2] - g[:, 0], g[:, 3] - g[:, 1]
+    d = np.stack([(gx - px) / pw, (gy - py) / ph, np.log(gw / pw), np.log(gh / ph)], -1).astype(f)
+    return ((d - np.asarray(means, f)) / np.asarray(stds, f)).astype(f)
+
+
+def cross_entropy(logits, labels, weight=None, avg_factor=None):
+    """cross_entropy_loss.py:9-43 (+ weight_reduce_loss, losses/utils.py:27-58, reduction='mean'): float64 scalar and
+    d loss / d logits."""
+    c = np.asarray(logits, np.float64)
+    n = c.shape[0]
+    m = c.max(1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(c - m).sum(1))
+    per = lse - c[np.arange(n), labels]
+    w = np.ones(n) if weight is None else np.asarray(weight, np.float64)
+    den = float(n) if avg_factor is None else float(avg_factor)
+    p = np.exp(c - lse[:, None])
+    p[np.arange(n), labels] -= 1.0
+    return float((per * w).sum() / den), p * (w / den)[:, None]
+
+
+def binary_cross_entropy(logits, labels, weight=None, avg_factor=None):
+    """cross_entropy_loss.py:46-95 for (N,1) logits of a one-class sigmoid head (the RPN): label 0 = foreground ->
+    target 1, label 1 (= num_classes) = background -> target 0 (_expand_onehot_labels :46-58).  float64 scalar, grad."""
+    z = np.asarray(logits, np.float64).reshape(-1)
+    t = (np.asarray(labels) == 0).astype(np.float64)
+    per = np.maximum(z, 0) - z * t + np.log1p(np.exp(-np.abs(z)))
+    w = np.ones_like(z) if weight is None else np.asarray(weight, np.float64)
+    den = float(z.size) if avg_factor is None else float(avg_factor)
+    sig = 1.0 / (1.0 + np.exp(-z))
+    return float((per * w).sum() / den), ((sig - t) * w / den).reshape(np.asarray(logits).shape)
+
+
+def mask_cross_entropy(sel_logits, targets):
+    """cross_entropy_loss.py:98-138: mean BCE-with-logits over the labelled class's (N,h,w) logits.  float64 scalar,
+    d loss / d those logits."""
+    z, t = np.asarray(sel_logits, np.float64), np.asarray(targets, np.float64)
+    per = np.maximum(z, 0) - z * t + np.log1p(np.exp(-np.abs(z)))
+    return float(per.mean()), (1.0 / (1.0 + np.exp(-z)) - t) / z.size
+
+
+def giou_loss_grad(pred, target, w, eps=1e-6):
+    """d/dpred of sum_i w_i * giou_loss(pred_i, target_i) by central differences in float64 (checker for the analytic
+    backward of det_bbox_loss_bwd; iou_loss.py:78-101)."""
+    p = np.asarray(pred, np.float64).copy()
+    g = np.zeros_like(p)
+    h = 1e-6
+    for j in range(4):
+        pp, pm = p.copy(), p.copy()
+        pp[:, j] += h
+        pm[:, j] -= h
+        g[:, j] = (giou_loss(pp, target, eps) - giou_loss(pm, target, eps)) / (2 * h) * np.asarray(w, np.float64)
+    return g
+
+
+def accuracy_top1(logits, labels):
+    """losses/accuracy.py:5-49, topk=1 -> percent."""
+    return float((np.asarray(logits).argmax(1) == np.asarray(labels)).mean() * 100.0)
+
+
+def crop_and_resize(masks, bboxes, out_shape, inds):
+    """BitmapMasks.crop_and_resize (structures.py:328-358): rois = [arange(K), bboxes]; gather masks[inds] as float;
+    roi_align(m[:, None], rois, out_shape, 1.0, 0, 'avg', True) >= 0.5  -> bool (K, h, w)."""
+    bboxes = np.asarray(bboxes, np.float32).reshape(-1, 4)
+    K = bboxes.shape[0]
+    oh, ow = (out_shape, out_shape) if isinstance(out_shape, int) else tuple(out_shape)
+    if K == 0 or len(masks) == 0:
+        return np.zeros((0, oh, ow), bool)
+    rois = np.concatenate([np.arange(K, dtype=np.float32)[:, None], bboxes], 1)
+    m = np.asarray(masks)[np.asarray(inds, np.int64)].astype(np.float32)[:, None]
+    return D.roi_align_c(m, rois, (oh, ow), 1.0, 0, True)[:, 0] >= np.float32(0.5)
+
+
+def mask_target_single(pos_proposals, pos_assigned_gt_inds, gt_masks, mask_size):
+    """mask_target.py:66-122: clip the proposals to the mask's extent, crop_and_resize, float32 0/1."""
+    p = np.asarray(pos_proposals, np.float32).reshape(-1, 4).copy()
+    oh, ow = (mask_size, mask_size) if isinstance(mask_size, int) else tuple(mask_size)
+    if p.shape[0] == 0:
+        return np.zeros((0, oh, ow), np.float32)
+    maxh, maxw = np.asarray(gt_masks).shape[1:]
+    p[:, [0, 2]] = np.clip(p[:, [0, 2]], 0, maxw)
+    p[:, [1, 3]] = np.clip(p[:, [1, 3]], 0, maxh)
+    return crop_and_resize(gt_masks, p, (oh, ow), pos_assigned_gt_inds).astype(np.float32)
+
+
+def mask_target(pos_proposals_list, pos_assigned_gt_inds_list, gt_masks_list, mask_size):
+    """mask_target.py:6-63: per image, concatenated in image order."""
+    out = [mask_target_single(p, i, m, mask_size) for p, i, m in zip(pos_proposals_list, pos_assigned_gt_inds_list, gt_masks_list)]
+    return np.concatenate(out, 0) if out else out
