@@ -327,6 +327,17 @@ int det_regress_by_class(const float* rois, const int64_t* labels, const void* c
                          int num_classes, int class_agnostic, const float* means, const float* stds, float max_h,
                          float max_w, float* out, int dtype, void* stream);
 
+/* det_rpn_topk_decode: RPNHead._get_bboxes proposal selection (rpn_head.py:126-187) for all images and levels in one
+ *   launch -- sigmoid, per-level top-`nms_pre` by (score descending, anchor index ascending: what a stable sort keeps,
+ *   rpn_head.py:162-169), gather of deltas / anchors, DeltaXYWHBBoxCoder.decode with max_shape (:185-186), level ids
+ *   (:174-180).  cls (B,total) / reg (B,total,4) f32|bf16 in (level,h,w,a) order; anchors (total,4) f32; level_sizes: HOST
+ *   array.  Outputs (B, sum_l min(n_l, nms_pre)), each level's survivors in ascending anchor order (callers sort by
+ *   score, stably, exactly as batched_nms does): scores f32, boxes f32 (B,.,4), ids i64.  workspace: 4 B per logit. */
+int64_t det_rpn_topk_decode_workspace_bytes(int64_t B, int64_t total_anchors);
+int det_rpn_topk_decode(const void* cls, const void* reg, const float* anchors, const int* level_sizes, int num_levels,
+                        int64_t B, int nms_pre, const float* means, const float* stds, float max_h, float max_w,
+                        void* workspace, float* out_scores, float* out_boxes, int64_t* out_ids, int dtype, void* stream);
+
 /* ---- batch normalisation over channel-last rows (csrc/batchnorm.hip): the SyncBN of the Cascade configs' ConvFCBBoxHead
  *   (convfc_bbox_head.py:99-107, norm_cfg=dict(type='SyncBN')); x (R, C) f32|bf16, C % (16 / elt size) == 0.
  *   det_bn_stats: sums (2C+1) = {sum x, sum x^2 per channel, R}; the caller all-reduces sums over ranks for SyncBN.

@@ -68,10 +68,13 @@ SIGNATURES = {
     "det_mask_loss_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "det_rpn_flatten_fwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
     "det_rpn_flatten_bwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
+    "det_rpn_topk_decode_workspace_bytes": [_i64, _i64],
+    "det_rpn_topk_decode": [_p, _p, _p, _p, _i, _i64, _i, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p],
     "det_paste_masks": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p],
 }
 _RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_gemm_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
-            "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64, "det_bn_workspace_bytes": _i64}
+            "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64, "det_bn_workspace_bytes": _i64,
+            "det_rpn_topk_decode_workspace_bytes": _i64}
 
 _lib = None
 

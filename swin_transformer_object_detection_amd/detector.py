@@ -499,6 +499,17 @@ class RPNHead(nn.Module):
         nms_pre = cfg['nms_pre']
         sc_l, bp_l, an_l, id_l = [], [], [], []
         cls_all, reg_all = self._flattened(cls_scores, bbox_preds)
+        if (static and cls_all.is_cuda and cfg.get('min_bbox_size', 0) <= 0
+                and sum(min(a.size(0), nms_pre) for a in mlvl_anchors) < cfg['nms'].get('split_thr', 10000)
+                and all(tuple(sh[:2]) == tuple(img_shapes[0][:2]) for sh in img_shapes)):
+            # all images, all levels: ONE selection + decode launch (csrc/rpn_select.hip: radix select of the nms_pre-th
+            # score per level, survivors compacted in anchor order and decoded), then one sort + one pair of NMS launches
+            # (the per-image reductions run side by side).  Equal to the sort-based path below including ties.
+            anchors_cat = self.anchor_generator.grid_anchors_cat(sizes, cls_all.device)
+            scores, props, ids = ops.rpn_topk_decode(cls_all, reg_all, anchors_cat, [a.size(0) for a in mlvl_anchors], nms_pre,
+                                                     self.means, self.stds, img_shapes[0])
+            dets, valid = ops.batched_nms_static_multi(props, scores, ids, cfg['nms']['iou_threshold'], cfg['max_per_img'])
+            return [(dets[i], valid[i]) for i in range(B)]
         s_all, d_all = cls_all.detach().float().sigmoid(), reg_all.detach().float()
         off = 0
         for lvl in range(len(cls_scores)):
@@ -507,14 +518,9 @@ class RPNHead(nn.Module):
             off += na
             an = mlvl_anchors[lvl][None].expand(B, -1, -1)
             if s.shape[1] > nms_pre:
-                if static and s.is_cuda:
-                    # only the SET of the nms_pre best anchors matters here: the NMS below orders all levels' candidates
-                    # by score itself.  A radix select (one kernel) instead of a full segmented sort (~15 kernels).
-                    s, topk = s.topk(nms_pre, dim=1, sorted=False)
-                else:
-                    ranked, rank_inds = s.sort(dim=1, descending=True, stable=True)
-                    topk = rank_inds[:, :nms_pre]
-                    s = ranked[:, :nms_pre]
+                ranked, rank_inds = s.sort(dim=1, descending=True, stable=True)
+                topk = rank_inds[:, :nms_pre]
+                s = ranked[:, :nms_pre]
                 d = torch.gather(d, 1, topk[..., None].expand(-1, -1, 4))
                 an = torch.gather(an, 1, topk[..., None].expand(-1, -1, 4))
             sc_l.append(s); bp_l.append(d); an_l.append(an)
@@ -906,6 +912,45 @@ class FCNMaskHead(nn.Module):
         return cls_segms
 
 
+def mask_target(pos_proposals_list, pos_assigned_gt_inds_list, gt_masks_list, mask_size):
+    """mmdet.core.mask_target (mask_target.py:6-122) over BitmapMasks.crop_and_resize (structures.py:328-358) on the
+    device: proposals clipped to the mask's extent (:104-107), rois = [index of the assigned gt mask, box],
+    roi_align(masks[:, None], rois, mask_size, 1.0, 0, 'avg', True) >= 0.5 -> float 0/1 targets (sum_i K_i, h, w).
+    gt_masks_list[i]: (G_i, H, W) uint8 / bool tensor.  When every image has masks of one size, all images go through ONE
+    RoIAlign launch (the masks stacked along the batch axis, a RoI's batch index offset by its image's first mask) --
+    the per-image launches are latency-bound and would run back to back; the reference selects masks[inds] first
+    (a K-times larger copy) and loops over images on the host.  Slot arithmetic stays on the device: no sync."""
+    size = (mask_size, mask_size) if isinstance(mask_size, int) else tuple(mask_size)
+    nimg = len(pos_proposals_list)
+    m_roi, m_gt, gt_masks = pos_proposals_list, pos_assigned_gt_inds_list, gt_masks_list
+
+    def rois_of(i, off):
+        r = torch.cat([(m_gt[i] + off).to(m_roi[i].dtype)[:, None], m_roi[i][:, :4]], 1)
+        maxh, maxw = gt_masks[i].shape[1:]
+        r[:, 1::2].clamp_(0, maxw)
+        r[:, 2::2].clamp_(0, maxh)
+        return r
+    same = (nimg > 0 and all(g_.size(0) > 0 for g_ in gt_masks) and all(r_.size(0) > 0 for r_ in m_roi)
+            and all(g_.shape[1:] == gt_masks[0].shape[1:] for g_ in gt_masks) and m_roi[0].is_cuda)
+    if same:
+        m = torch.cat(list(gt_masks), 0).to(torch.bfloat16)[:, None]      # 0/1 exact in bf16
+        offs, o_ = [], 0
+        for g_ in gt_masks:
+            offs.append(o_); o_ += g_.size(0)
+        r = torch.cat([rois_of(i, offs[i]) for i in range(nimg)], 0)
+        t = ops.roi_align(m, r, size, 1.0, 0, 'avg', True)                # structures.py:353-354
+        return (t[:, 0] >= 0.5).float()
+    tg = []
+    for i in range(nimg):
+        if m_roi[i].size(0) == 0 or gt_masks[i].size(0) == 0:
+            tg.append(m_roi[i].new_zeros((m_roi[i].size(0),) + size))
+            continue
+        m = gt_masks[i].to(torch.bfloat16)[:, None].contiguous()
+        t = ops.roi_align(m, rois_of(i, 0), size, 1.0, 0, 'avg', True)
+        tg.append((t[:, 0] >= 0.5).float())
+    return torch.cat(tg) if tg else tg
+
+
 def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox_roi_extractor, bbox_head, mask_roi_extractor,
                      mask_head):
     """One R-CNN stage of training (standard_roi_head.py:70-131; cascade_roi_head.py:228-270 runs it per stage) with
@@ -957,30 +1002,7 @@ def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox
             mask_feats = mask_roi_extractor(x[:mask_roi_extractor.num_inputs], bbox2roi(m_roi), valid=mvalid)
         rows_path = mask_feats.is_cuda and hasattr(mask_head, 'forward_rows') and mask_feats.size(0) > 0
         mask_pred = mask_head.forward_rows(mask_feats) if rows_path else mask_head(mask_feats)
-        size = cfg.get('mask_size', 28)
-        # mask_target.py:66-122 on the device.  When every image has gt masks of one size, all images go through ONE
-        # RoIAlign launch (the gt masks stacked along the batch axis, the RoI's batch index offset by its image's
-        # first mask): the per-image launches are latency-bound and would run back to back.
-        same = (all(g_.size(0) > 0 for g_ in gt_masks) and all(r_.size(0) > 0 for r_ in m_roi)
-                and all(g_.shape[1:] == gt_masks[0].shape[1:] for g_ in gt_masks))
-        if same:
-            m = torch.cat(list(gt_masks), 0).to(torch.bfloat16)[:, None]      # 0/1 exact in bf16
-            offs, o_ = [], 0
-            for g_ in gt_masks:
-                offs.append(o_); o_ += g_.size(0)
-            r = torch.cat([torch.cat([(m_gt[i] + offs[i]).to(m_roi[i].dtype)[:, None], m_roi[i]], 1) for i in range(nimg)], 0)
-            t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)        # structures.py:353-354
-            tg = [(t[:, 0] >= 0.5).float()]
-        else:
-            tg = []
-            for i in range(nimg):
-                if m_roi[i].size(0) == 0 or gt_masks[i].size(0) == 0:
-                    tg.append(m_roi[i].new_zeros((m_roi[i].size(0), size, size)))
-                    continue
-                m = gt_masks[i].to(torch.bfloat16)[:, None].contiguous()
-                r = torch.cat([m_gt[i].to(m_roi[i].dtype)[:, None], m_roi[i]], 1)
-                t = ops.roi_align(m, r, (size, size), 1.0, 0, 'avg', True)
-                tg.append((t[:, 0] >= 0.5).float())
+        tg = [mask_target(m_roi, m_gt, gt_masks, cfg.get('mask_size', 28))]
         if rows_path:
             losses.update(mask_head.loss_rows(mask_pred, torch.cat(tg), torch.cat(m_lab), mvalid))
         else:

@@ -108,6 +108,34 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     return out
 
 
+def rpn_topk_decode(cls_all, reg_all, anchors, level_sizes, nms_pre, means, stds, max_shape):
+    """RPNHead._get_bboxes up to batched_nms (rpn_head.py:126-187) in one launch: cls_all (B,total) logits, reg_all
+    (B,total,4) deltas (float32 or bfloat16, anchors flattened (level,h,w,a)), anchors (total,4) float32 ->
+    (scores (B,n) f32, proposals (B,n,4) f32, level ids (B,n) int64), n = sum_l min(n_l, nms_pre); inside a level the
+    survivors come in ascending anchor order (sorting by score, stably, restores the reference's order)."""
+    if not cls_all.is_cuda:
+        raise SwinHipError("rpn_topk_decode: GPU tensors only")
+    from .._lib import SWIN_BF16, SWIN_F32, lib
+    c, r = cls_all.detach().contiguous(), reg_all.detach().contiguous()
+    if c.dtype != r.dtype or c.dtype not in (torch.float32, torch.bfloat16):
+        c, r = c.float(), r.float()
+    B, total = c.shape
+    if sum(level_sizes) != total or r.shape != (B, total, 4) or anchors.shape != (total, 4):
+        raise SwinHipError(f"rpn_topk_decode: shapes {tuple(c.shape)} / {tuple(r.shape)} / {tuple(anchors.shape)} vs levels {level_sizes}")
+    a = anchors.detach().float().contiguous()
+    n = sum(min(int(s), int(nms_pre)) for s in level_sizes)
+    dev = c.device
+    scores = torch.empty((B, n), device=dev, dtype=torch.float32)
+    boxes = torch.empty((B, n, 4), device=dev, dtype=torch.float32)
+    ids = torch.empty((B, n), device=dev, dtype=torch.int64)
+    ws = torch.empty(max(lib().det_rpn_topk_decode_workspace_bytes(B, total), 16), device=dev, dtype=torch.uint8)
+    ls = (ctypes.c_int * len(level_sizes))(*[int(s) for s in level_sizes])
+    mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    call("det_rpn_topk_decode", _p(c), _p(r), _p(a), ls, len(level_sizes), B, int(nms_pre), _f4(means), _f4(stds), mh, mw, _p(ws),
+         _p(scores), _p(boxes), _p(ids), SWIN_F32 if c.dtype == torch.float32 else SWIN_BF16, _s())
+    return scores, boxes, ids
+
+
 def regress_by_class(rois, labels, cls_score, bbox_pred, num_classes, class_agnostic, means, stds, max_shape=None):
     """BBoxHead.regress_by_class (bbox_head.py:409-436) with CascadeRoIHead's label choice (cascade_roi_head.py:274-284,
     :316-323): rois (n,4); labels (n,) int64 or None -- None / background labels take argmax(cls_score[:, :-1]);
