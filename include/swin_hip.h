@@ -327,6 +327,17 @@ int det_regress_by_class(const float* rois, const int64_t* labels, const void* c
                          int num_classes, int class_agnostic, const float* means, const float* stds, float max_h,
                          float max_w, float* out, int dtype, void* stream);
 
+/* ---- token-stationary fused MLP (csrc/ts_mlp.hip): Mlp.forward (swin_transformer.py:32-38: fc1 -> exact-erf GELU -> fc2)
+ *   and its backward, bf16 in / fp32 accumulate, for C in {96, 192} (stages 1-2, where the 4C hidden activation is the
+ *   step's largest HBM stream).  x, y, dy, dx (T,C) bf16; w1 (4C,C), w2 (C,4C) bf16; b1 (4C), b2 (C) f32.
+ *   swin_mlp_fwd_bf16: y = fc2(gelu(fc1(x) + b1)) + b2; nothing of size T x 4C is written.
+ *   swin_mlp_bwd_bf16: recomputes fc1(x) + b1, writes dx = ((dy w2) * gelu') w1 and, for the weight-gradient GEMMs
+ *   (wgrad_linear_bf16), h = gelu(.) and dhpre = (dy w2) * gelu' as (T,4C) bf16. */
+int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t T,
+                      int C, void* stream);
+int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, const float* b1, const void* w2, void* dx, void* h,
+                      void* dhpre, int64_t T, int C, void* stream);
+
 /* det_rpn_topk_decode: RPNHead._get_bboxes proposal selection (rpn_head.py:126-187) for all images and levels in one
  *   launch -- sigmoid, per-level top-`nms_pre` by (score descending, anchor index ascending: what a stable sort keeps,
  *   rpn_head.py:162-169), gather of deltas / anchors, DeltaXYWHBBoxCoder.decode with max_shape (:185-186), level ids

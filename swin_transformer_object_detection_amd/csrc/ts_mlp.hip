@@ -1,0 +1,292 @@
+// Token-stationary fused MLP for gfx950 (Mlp.forward swin_transformer.py:32-38 and its backward).
+//
+//   forward :  y = fc2(gelu(fc1(x) + b1)) + b2                 one launch, the 4C hidden activation never leaves the CU
+//   backward:  hpre recomputed from x;  dh = dy W2;  dhpre = dh * gelu'(hpre);  dx = dhpre W1
+//              h and dhpre are written once (bf16) for the two weight-gradient GEMMs -- nothing else of size T x 4C moves
+//
+// Decomposition.  A wave OWNS 32 tokens for the whole kernel and computes everything TRANSPOSED:
+//     Ht[hid x tok]  = W1[hid x C]  . Xt[C x tok]        A = weight rows from LDS,  B = the wave's token fragments (registers)
+//     Yt[C   x tok] += W2[C x hid]  . gelu(Ht)           B = the accumulator tile of the first product, as it stands
+// A 32x32 accumulator of v_mfma_f32_32x32x16_bf16 has its column (token) on the lane and its rows in the registers, so it IS
+// the B operand of a product that sums over its rows (guide: "an accumulator tile as the next MFMA's operand"): the hidden
+// tile goes from the first GEMM to the second through 8 cvt_pk per lane -- no LDS round trip, no barrier, no cross-wave
+// dependency.  Only the weights are shared: a block stages them chunk by chunk (CH hidden units) into LDS.
+// The k order of an accumulator-fed operand is permuted (row 16s + 8(j>>2) + 4h + (j&3) for element j of lane half h); the
+// permutation is absorbed by which weight ROW a lane feeds to the first product (pi = swap bits 2,3 of the row index):
+// the second product then reads its weight fragment with one natural 16-byte LDS read, and every lane ends up holding
+// 8 CONTIGUOUS channels / hidden units per register octet -> all global stores are 16-byte.
+// LDS rows are padded so that (row stride / 16 B) is odd: ds_read_b128 of 16 different rows is conflict-free.
+//
+// Roofline: 16 T C^2 flops over 2 T C bpe bytes -> MFMA-bound on paper (AI = 4C >= 384); at C = 96 the exact-erf GELU
+// (one v_exp + one v_rcp + 14 plain VALU per element) makes the VALU pipe the co-limit.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// swap bits 2 and 3 of a row index (an involution on 0..15, applied inside each 16-row group)
+__device__ __forceinline__ int pi16(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on z = |x| / sqrt(2); returns q = 1 - erf(z) = poly(t) * exp(-z^2)
+// and e = exp(-x^2 / 2).  gelu(x) = x * Phi(x),  Phi(x) = x > 0 ? 1 - q/2 : q/2;  gelu'(x) = Phi(x) + x e / sqrt(2 pi).
+__device__ __forceinline__ void erfc_parts(float x, float& q, float& e) {
+    const float z = fabsf(x) * 0.70710678118f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    e = __builtin_amdgcn_exp2f(-z * z * 1.44269504089f);
+    q = p * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float q, e;
+    erfc_parts(x, q, e);
+    const float cdf = x > 0.f ? fmaf(-0.5f, q, 1.0f) : 0.5f * q;
+    return x * cdf;
+}
+__device__ __forceinline__ void gelu_fg(float x, float& g, float& dg) {
+    float q, e;
+    erfc_parts(x, q, e);
+    const float cdf = x > 0.f ? fmaf(-0.5f, q, 1.0f) : 0.5f * q;
+    g = x * cdf;
+    dg = fmaf(x * e, 0.3989422804f, cdf);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (bf16)a[8 * s + e];
+    return f;
+}
+
+// transposed A fragment from a row-major [k][n] LDS image: lane (r = lane&31, h = lane>>5) gets img[k0 + 8h + e][n0 + pi(r)],
+// e = 0..7 (two ds_read_b64_tr_b16; the pi column permutation is a permutation of the 4-column quads a lane addresses)
+__device__ __forceinline__ bf16x8 tr_frag_pi(const bf16* img, int stride, int k0, int n0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int h = g >> 1, dh = g & 1;
+    const int pp = ((p & 1) << 1) | (p >> 1);
+    const bf16* a0 = img + (k0 + 8 * h + q) * stride + n0 + 16 * dh + 4 * pp;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * stride));
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    return f;
+}
+
+template <int C, int CH> struct TsGeom {
+    static constexpr int HID = 4 * C;
+    static constexpr int NCH = HID / CH;
+    static constexpr int KS = C / 16;          // k-steps over the channels
+    static constexpr int CT = C / 32;          // 32-row output tiles over the channels
+    static constexpr int HT = CH / 32;         // hidden tiles per chunk
+    static_assert(C % 32 == 0 && CH % 32 == 0 && HID % CH == 0, "tile sizes");
+};
+
+// Weight chunk images in LDS, filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, the next chunk lands while
+// this one feeds the MFMAs).  An image is a sequence of 16-byte slots, ROWS x (COLS/8 + 1) of them (the last slot of a row is
+// the pad); a wave instruction writes 64 consecutive slots, every lane reading the source piece of ITS slot (the pad slot
+// re-reads the row's last piece; slots past the image re-read the last row and land in the image's rounded-up tail).
+template <int ROWS, int COLS> struct WImg {
+    static constexpr int SPR = COLS / 8 + 1;                      // slots per row
+    static constexpr int RS = COLS + 8;                           // row stride in bf16
+    static constexpr int SLOTS = ROWS * SPR;
+    static constexpr int SLOTS_PAD = (SLOTS + 63) / 64 * 64;
+    static constexpr int BYTES = SLOTS_PAD * 16;
+    static_assert((SPR & 1) == 1, "row stride must be an odd number of 16-byte slots (conflict-free ds_read_b128)");
+};
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA piece (16 B per lane, 1 KiB per wave) as inline asm: hipcc waits vmcnt(0) at the first ds_read after a
+// __builtin_amdgcn_global_load_lds (an LDS-DMA is a pending LDS write it cannot disambiguate), which would drain the
+// prefetch of the NEXT chunk before the MFMAs of this one.  An asm DMA is invisible to that bookkeeping; its completion is
+// waited for by hand (s_waitcnt vmcnt(0) + barrier at the end of the chunk).  M0 = wave-uniform LDS byte address, written
+// in the statement that reads it and restored (guide 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+
+// src: element pointer of (row 0, col 0) of the chunk; ld: source row stride in elements
+template <int ROWS, int COLS, int WAVES>
+__device__ __forceinline__ void dma_image(const bf16* src, int64_t ld, unsigned char* img, int wave, int lane) {
+    using I = WImg<ROWS, COLS>;
+    constexpr int ROUNDS = (I::SLOTS_PAD / 64 + WAVES - 1) / WAVES;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+        const int blk = i * WAVES + wave;                         // wave-uniform
+        if (blk * 64 < I::SLOTS_PAD) {
+            const int p = blk * 64 + lane;
+            int row = p / I::SPR, sl = p - row * I::SPR;
+            if (sl == I::SPR - 1) sl = I::SPR - 2;
+            if (row >= ROWS) row = ROWS - 1;
+            const bf16* g = src + (int64_t)row * ld + sl * 8;
+            glds16(g, (unsigned)(uintptr_t)(lptr_t)(img + blk * 1024));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int C, int WAVES, int CH, int OCC, int ABL = 0>
+__global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_fwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W1,
+                                                               const float* __restrict__ b1, const bf16* __restrict__ W2,
+                                                               const float* __restrict__ b2, bf16* __restrict__ Y, int64_t T) {
+    using G = TsGeom<C, CH>;
+    using I1 = WImg<CH, C>;                                          // W1 chunk: CH hidden rows x C
+    using I2 = WImg<C, CH>;                                          // W2 chunk: C rows x CH hidden
+    constexpr int NT = WAVES * 64;
+    constexpr int BUF = I1::BYTES + I2::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* b1s = (float*)(smem + 2 * BUF);                           // [4C]
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tok = (int64_t)blockIdx.x * (WAVES * 32) + wave * 32 + r;
+    const int64_t tokc = tok < T ? tok : T - 1;
+
+    auto stage = [&](int j, int buf) {
+        dma_image<CH, C, WAVES>(W1 + (int64_t)j * CH * C, C, smem + buf * BUF, wave, lane);
+        dma_image<C, CH, WAVES>(W2 + (int64_t)j * CH, G::HID, smem + buf * BUF + I1::BYTES, wave, lane);
+    };
+    stage(0, 0);
+    for (int i = tid; i < G::HID; i += NT) b1s[i] = b1[i];
+    bf16x8 xf[G::KS];
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) xf[s] = *(const bf16x8*)(X + tokc * C + 16 * s + 8 * h);
+    f32x16 yacc[G::CT];
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) yacc[ct][q] = 0.f;
+    const int pr = pi16(r & 15) | (r & 16);
+    // the token fragments are consumed here, once: hipcc then waits for them HERE and not at their first MFMA inside the
+    // chunk loop, where its vmcnt would also drain the (invisible to it, younger) DMA of the next chunk every iteration
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) asm volatile("" :: "v"(xf[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int j = 0; j < G::NCH; ++j) {
+        if (j + 1 < G::NCH) stage(j + 1, (j + 1) & 1);              // lands under this chunk's MFMAs
+        const bf16* W1s = (const bf16*)(smem + (j & 1) * BUF);
+        const bf16* W2s = (const bf16*)(smem + (j & 1) * BUF + I1::BYTES);
+        // software pipeline over the hidden tiles: the W1 fragments of tile t+1 and the W2 fragments of tile t are read from
+        // LDS while the GELU of tile t runs on the VALU (hipcc otherwise issues read -> wait -> MFMA one fragment at a time)
+        bf16x8 wf[G::KS];
+        {
+            const bf16* w1row = W1s + pr * I1::RS + 8 * h;
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) wf[s] = *(const bf16x8*)(w1row + 16 * s);
+        }
+#pragma unroll 1
+        for (int t = 0; t < G::HT; ++t) {
+            // ---- Ht tile = W1 rows (pi order) . Xt, bias as the initial accumulator ----
+            f32x16 a;
+            {
+                const float4* bp = (const float4*)&b1s[j * CH + 32 * t + 8 * h];
+                const float4 v0 = bp[0], v1 = bp[1], v2 = bp[4], v3 = bp[5];      // hidden 8h..8h+7 and 16+8h..16+8h+7
+                a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+                a[8] = v2.x; a[9] = v2.y; a[10] = v2.z; a[11] = v2.w; a[12] = v3.x; a[13] = v3.y; a[14] = v3.z; a[15] = v3.w;
+            }
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) a = mfma32(wf[s], xf[s], a);
+            bf16x8 w2f[G::CT][2];
+#pragma unroll
+            for (int ct = 0; ct < G::CT; ++ct) {
+                const bf16* w2row = W2s + (32 * ct + pr) * I2::RS + 32 * t + 8 * h;
+                w2f[ct][0] = *(const bf16x8*)(w2row);
+                w2f[ct][1] = *(const bf16x8*)(w2row + 16);
+            }
+            {
+                const int tn = t + 1 < G::HT ? t + 1 : t;
+                const bf16* w1row = W1s + (32 * tn + pr) * I1::RS + 8 * h;
+#pragma unroll
+                for (int s = 0; s < G::KS; ++s) wf[s] = *(const bf16x8*)(w1row + 16 * s);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- GELU on the accumulators, packed straight into the next product's B fragments ----
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = (ABL == 1) ? a[q] * 0.5f : gelu_f(a[q]);
+            const bf16x8 pf0 = pack8(a, 0), pf1 = pack8(a, 1);
+            // ---- Yt += W2 rows (pi order) . gelu(Ht) ----
+#pragma unroll
+            for (int ct = 0; ct < G::CT; ++ct) {
+                yacc[ct] = mfma32(w2f[ct][0], pf0, yacc[ct]);
+                yacc[ct] = mfma32(w2f[ct][1], pf1, yacc[ct]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next chunk's DMA has landed (this wave's part)
+        __syncthreads();                                            // ... everyone's; and everyone is done with this buffer
+    }
+    // ---- epilogue: + b2, bf16, two 16-byte stores per channel tile (registers 0..7 = channels 8h.., 8..15 = 16+8h..) ----
+    if (tok < T) {
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c0 = 32 * ct + 16 * s + 8 * h;
+                const float4 ba = *(const float4*)(b2 + c0), bb = *(const float4*)(b2 + c0 + 4);
+                bf16x8 o;
+                o[0] = (bf16)(yacc[ct][8 * s + 0] + ba.x); o[1] = (bf16)(yacc[ct][8 * s + 1] + ba.y);
+                o[2] = (bf16)(yacc[ct][8 * s + 2] + ba.z); o[3] = (bf16)(yacc[ct][8 * s + 3] + ba.w);
+                o[4] = (bf16)(yacc[ct][8 * s + 4] + bb.x); o[5] = (bf16)(yacc[ct][8 * s + 5] + bb.y);
+                o[6] = (bf16)(yacc[ct][8 * s + 6] + bb.z); o[7] = (bf16)(yacc[ct][8 * s + 7] + bb.w);
+                *(bf16x8*)(Y + tok * C + c0) = o;
+            }
+        }
+    }
+}
+
+template <int C, int WAVES, int CH, int OCC, int ABL = 0>
+int launch_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t T, hipStream_t s) {
+    using G = TsGeom<C, CH>;
+    const size_t lds = 2 * (size_t)(WImg<CH, C>::BYTES + WImg<C, CH>::BYTES) + G::HID * sizeof(float);
+    static bool attr_set[16] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    auto kern = ts_mlp_fwd_kernel<C, WAVES, CH, OCC, ABL>;
+    if (dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SWIN_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    const unsigned blocks = (unsigned)((T + WAVES * 32 - 1) / (WAVES * 32));
+    kern<<<blocks, WAVES * 64, lds, s>>>((const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, (bf16*)y, T);
+    return swin_launch_status();
+}
+
+}  // namespace
+
+// y (T,C) = fc2(gelu(fc1(x))) : x (T,C) bf16, w1 (4C,C) bf16, b1 (4C) f32, w2 (C,4C) bf16, b2 (C) f32.  C in {96, 192}.
+extern "C" int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t T,
+                                 int C, void* stream) {
+    if (T == 0) return SWIN_OK;
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || T < 0) return SWIN_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 96: {
+            static const int abl = getenv("SWIN_MLP_ABL") ? atoi(getenv("SWIN_MLP_ABL")) : 0;     // development ablations
+            if (abl == 1) return launch_fwd<96, 8, 128, 2, 1>(x, w1, b1, w2, b2, y, T, s);
+            if (abl == 2) return launch_fwd<96, 4, 128, 1, 0>(x, w1, b1, w2, b2, y, T, s);
+            if (abl == 3) return launch_fwd<96, 4, 64, 1, 0>(x, w1, b1, w2, b2, y, T, s);
+            return launch_fwd<96, 8, 128, 2>(x, w1, b1, w2, b2, y, T, s);
+        }
+        case 192: return launch_fwd<192, 4, 64, 1>(x, w1, b1, w2, b2, y, T, s);
+        default: return SWIN_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, const float* b1, const void* w2, void* dx, void* h,
+                                 void* dhpre, int64_t T, int C, void* stream) {
+    (void)x; (void)dy; (void)w1; (void)b1; (void)w2; (void)dx; (void)h; (void)dhpre; (void)T; (void)C; (void)stream;
+    return SWIN_ERR_UNSUPPORTED;
+}

@@ -16,8 +16,18 @@ Design for MI355X / xGMI (one process per GPU, backend "nccl" == RCCL):
     every link busy and the per-collective launch cost negligible (Mask R-CNN Swin-T: 192 MB of fp32
     gradients -> 4 buckets);
   * the loss scalars for logging are packed into ONE tensor and reduced once, without .item().
+  * collectives are issued STRICTLY in bucket-index order on every rank (bucket i only after buckets 0..i-1), whatever
+    order the buckets complete in: a rank-dependent graph (a parameter unused on one rank) must not pair mismatched
+    collectives; a bucket that never completes is issued by finish(), still in index order;
+  * one backward() per finish(): a gradient that arrives for a bucket whose all-reduce is already in flight would be
+    dropped or race with the collective, so it raises (gradient accumulation over several backward calls is not
+    supported -- accumulate in the loss instead);
+  * every launch / completion is time-stamped relative to mark_backward_start() (``timeline``) so a multi-GPU run
+    shows by itself how much of the exchange overlapped backward.
 Works unchanged on CPU with the gloo backend (tests/test_ddp_gloo.py, world_size 2).
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -33,6 +43,9 @@ class BucketedGradReducer:
         self.average = average
         self.buckets = []
         self._l2b = {}
+        self._next = 0                      # index of the next bucket whose collective may be issued
+        self._t0 = None
+        self.timeline = []                  # per step: [(bucket, launch_s, done_s | None, bytes)] relative to mark_backward_start
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
             cur.append(p)
@@ -64,8 +77,8 @@ class BucketedGradReducer:
             off += p.numel()
         leaves = [self.leaf_of(p) for p in plist]
         b = dict(flat=flat, params=list(plist), leaves=leaves, views=views, pending=len(plist), handle=None,
-                 arrived=[False] * len(plist), direct=[False] * len(plist),
-                 index={id(l): i for i, l in enumerate(leaves)})
+                 arrived=[False] * len(plist), direct=[False] * len(plist), launched=False, ready=False,
+                 no=len(self.buckets), index={id(l): i for i, l in enumerate(leaves)})
         for l in leaves:
             self._l2b[id(l)] = b
         for p, v in zip(plist, views):
@@ -92,19 +105,43 @@ class BucketedGradReducer:
                 leaf.grad = None
             p.grad = v
 
+    def mark_backward_start(self):
+        """Time origin of ``timeline`` (call right before loss.backward())."""
+        self._t0 = time.perf_counter()
+
+    def _now(self):
+        return time.perf_counter() - (self._t0 if self._t0 is not None else time.perf_counter())
+
     def _launch(self, b):
         self._gather(b)
-        if self.world > 1 and b['handle'] is None:
+        b['launched'] = True
+        if self.world > 1:
             if self.average:
                 b['flat'].div_(self.world)
             b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.timeline.append([b['no'], self._now(), None, b['flat'].numel() * 4])
+
+    def _issue_ready(self, force=False):
+        """issue the collectives of buckets _next, _next+1, ... while they are complete (all, when force)"""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if not (b['ready'] or force):
+                break
+            self._launch(b)
+            self._next += 1
 
     def _arrive(self, b, i):
+        if b['launched']:
+            raise RuntimeError(
+                f"gradient for parameter {i} of bucket {b['no']} arrived after the bucket's all-reduce was issued: more "
+                "than one backward() per finish(), or a parameter used both through a gradient-sink kernel and plain "
+                "autograd in different backward passes.  Not supported (it would be dropped or race with the collective).")
         if not b['arrived'][i]:
             b['arrived'][i] = True
             b['pending'] -= 1
             if b['pending'] == 0:
-                self._launch(b)
+                b['ready'] = True
+                self._issue_ready()
 
     def _on_grad(self, leaf):
         b = self._l2b[id(leaf)]
@@ -116,24 +153,29 @@ class BucketedGradReducer:
         self._arrive(b, i)
 
     def finish(self):
-        """Call after backward: handles buckets with parameters that got no gradient, waits for the collectives."""
+        """Call after backward: issues the buckets with parameters that got no gradient (in index order), waits for the
+        collectives, re-arms the reducer for the next step."""
         from . import mixed
         mixed.flush_pending()
-        for b in self.buckets:
-            if b['pending'] > 0:
-                self._launch(b)
+        self._issue_ready(force=True)
         for b in self.buckets:
             if b['handle'] is not None:
                 b['handle'].wait()
                 b['handle'] = None
+                for rec in self.timeline:
+                    if rec[0] == b['no'] and rec[2] is None:
+                        rec[2] = self._now()
             b['pending'] = len(b['params'])
             b['arrived'] = [False] * len(b['params'])
             b['direct'] = [False] * len(b['params'])
+            b['launched'] = b['ready'] = False
+        self._next = 0
 
     def zero_grad(self):
         """Before forward: ONE memset per bucket (kernels accumulate into the views) and drop the leaves' grads."""
         from . import mixed
         mixed.reset_step()
+        self.timeline = []
         for b in self.buckets:
             b['flat'].zero_()
             for leaf in b['leaves']:

@@ -578,3 +578,32 @@ def linear(x, weight, bias=None, dtype=None):
             b = mixed.weight(bias, dtype)
         return _LinearBf16.apply(x, w, b, weight, bias)
     return torch.nn.functional.linear(x, w, mixed.weight(bias, dtype))
+
+
+# --------------------------------------------------------------------------------------
+# Token-stationary fused MLP (csrc/ts_mlp.hip): fc1 -> GELU -> fc2 in one launch, C in {96, 192}
+# --------------------------------------------------------------------------------------
+MLP_FUSED_C = (96, 192)
+
+
+def mlp_fused_ok(x, C):
+    return x.is_cuda and x.dtype == torch.bfloat16 and C in MLP_FUSED_C
+
+
+def mlp_fwd_raw(x2, w1, b1, w2, b2):
+    """y (T,C) = fc2(gelu(fc1(x))) on bf16 (T,C) rows; w1 (4C,C) / w2 (C,4C) bf16, b1 / b2 fp32.  No autograd."""
+    T, C = x2.shape
+    y = torch.empty_like(x2)
+    call("swin_mlp_fwd_bf16", _p(x2), _p(w1), _p(_f32(b1)), _p(w2), _p(_f32(b2)), _p(y), T, C, _s())
+    return y
+
+
+def mlp_bwd_raw(x2, dy2, w1, b1, w2):
+    """-> (dx (T,C), h (T,4C), dhpre (T,4C)) bf16: data gradient of the fused MLP plus the two operands the weight-gradient
+    GEMMs need (dW2 = dy^T h, dW1 = dhpre^T x, db1 = colsum dhpre)."""
+    T, C = x2.shape
+    dx = torch.empty_like(x2)
+    h = torch.empty((T, 4 * C), device=x2.device, dtype=torch.bfloat16)
+    dhpre = torch.empty_like(h)
+    call("swin_mlp_bwd_bf16", _p(x2), _p(dy2), _p(w1), _p(_f32(b1)), _p(w2), _p(dx), _p(h), _p(dhpre), T, C, _s())
+    return dx, h, dhpre

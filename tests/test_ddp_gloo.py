@@ -129,3 +129,76 @@ def test_sync_batch_norm_gloo_world2():
         p.join(timeout=30)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _order_worker(rank, world, port, q):
+    """A parameter that only rank 1 uses sits in the FIRST bucket: on rank 0 that bucket never completes during backward
+    while the later buckets do, i.e. the completion order differs between the ranks.  Collectives are issued in bucket-index
+    order on both ranks all the same: no hang, and every gradient is the mean over ranks.  A second backward() before
+    finish() must raise instead of dropping / racing gradients."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from swin_transformer_object_detection_amd import ddp
+    torch.manual_seed(0)
+    trunk = nn.Sequential(nn.Linear(16, 32), nn.ReLU(), nn.Linear(32, 32))
+    head = nn.Linear(32, 4)
+    extra = nn.Linear(32, 4)                                  # used by rank 1 only; registered last -> bucket 0
+    params = list(trunk.parameters()) + list(head.parameters()) + list(extra.parameters())
+    red = ddp.BucketedGradReducer(params, bucket_bytes=256)
+    red.broadcast_parameters()
+    assert id(extra.weight) in [id(p) for p in red.buckets[0]['params']] and len(red.buckets) >= 4
+
+    def loss_of(r, x):
+        f = trunk(x)
+        out = head(f)
+        if r == 1:
+            out = out + extra(f)
+        return out.square().mean()
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(8, 16, generator=g) for _ in range(world)]
+    red.zero_grad()
+    red.mark_backward_start()
+    loss_of(rank, xs[rank]).backward()
+    order = [rec[0] for rec in red.timeline]                  # buckets issued DURING backward
+    red.finish()
+    ok = [rec[0] for rec in red.timeline] == list(range(len(red.buckets)))          # index order, all issued
+    ok &= all(rec[2] is not None and rec[2] >= rec[1] for rec in red.timeline)
+    if rank == 0:
+        ok &= 0 not in order                                  # bucket 0 could only be issued by finish() on rank 0 ...
+        ok &= len(order) == 0                                 # ... and it held back every later bucket
+    got = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    want = torch.autograd.grad(sum(loss_of(r, xs[r]) for r in range(world)) / world, params, allow_unused=True)
+    for a, b in zip(got, want):
+        ok &= torch.allclose(a, b if b is not None else torch.zeros_like(a), atol=1e-6)
+    # second backward without finish(): raises as soon as a gradient arrives for a bucket whose collective is in flight
+    # (rank 1: bucket 0 was issued during the first backward; rank 0 issued nothing yet, so plain accumulation is still safe)
+    red.zero_grad()
+    loss_of(rank, xs[rank]).backward()
+    issued = len(red.timeline) > 0
+    raised = False
+    try:
+        loss_of(rank, xs[rank]).backward()
+    except RuntimeError as e:
+        raised = "arrived after" in str(e)
+    ok &= raised == issued and issued == (rank == 1)
+    red.finish()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_collectives_in_index_order_with_rank_dependent_graph():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]

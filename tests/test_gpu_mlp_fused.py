@@ -1,0 +1,59 @@
+"""Token-stationary fused MLP (csrc/ts_mlp.hip) through the C ABI against the oracle: Mlp.forward of the reference
+(swin_transformer.py:32-38: fc1 -> nn.GELU (exact erf) -> fc2) evaluated in fp32 on the CPU on the same bf16-rounded
+operands.  Tolerance: the kernel keeps the hidden activation in fp32 until ONE bf16 rounding feeds fc2 and rounds the output
+once: a few bf16 ulps (2^-8 relative) of the output scale; stated per assertion."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fn():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from swin_transformer_object_detection_amd.ops import functional
+    return functional
+
+
+def _case(T, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, C, generator=g).bfloat16()
+    w1 = (torch.randn(4 * C, C, generator=g) * (1.0 / C) ** 0.5).bfloat16()
+    w2 = (torch.randn(C, 4 * C, generator=g) * (1.0 / (4 * C)) ** 0.5).bfloat16()
+    b1 = torch.randn(4 * C, generator=g) * 0.3
+    b2 = torch.randn(C, generator=g) * 0.3
+    return x, w1, b1, w2, b2
+
+
+def _tol(ref, ulps):
+    return float(ulps * 2.0 ** -8 * max(ref.abs().max().item(), 1e-3))
+
+
+@pytest.mark.parametrize("T,C", [(1, 96), (33, 96), (256, 96), (1000, 96), (128000, 96), (77, 192), (1024, 192), (32000, 192)])
+def test_mlp_fused_forward_vs_oracle(fn, T, C):
+    x, w1, b1, w2, b2 = _case(T, C, T + C)
+    ref = F.linear(F.gelu(F.linear(x.float(), w1.float(), b1)), w2.float(), b2)       # swin_transformer.py:32-38
+    y = fn.mlp_fwd_raw(x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    torch.cuda.synchronize()
+    assert y.shape == (T, C) and y.dtype == torch.bfloat16
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), rtol=0, atol=_tol(ref, 3))
+    # the hidden activation's single bf16 rounding is the dominant error; the mean error must be far below one ulp
+    assert (y.float().cpu() - ref).abs().mean().item() < _tol(ref, 0.25)
+
+
+def test_mlp_fused_gelu_tails(fn):
+    """large |fc1| outputs: gelu(x) -> x and -> -0 (the erfc form must not lose the negative tail to cancellation)"""
+    C = 96
+    x = torch.zeros(64, C).bfloat16()
+    x[:, 0] = torch.linspace(-12, 12, 64).bfloat16()
+    w1 = torch.zeros(4 * C, C).bfloat16()
+    w1[:, 0] = 1.0
+    w2 = torch.zeros(C, 4 * C).bfloat16()
+    w2[0, 5] = 1.0
+    b1, b2 = torch.zeros(4 * C), torch.zeros(C)
+    ref = F.linear(F.gelu(F.linear(x.float(), w1.float(), b1)), w2.float(), b2)
+    y = fn.mlp_fwd_raw(x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda()).float().cpu()
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=2.0 ** -7, atol=1e-6)

@@ -124,6 +124,41 @@ def wgrad():
         print(f"wgrad_conv {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
 
 
+def mlp():
+    """fused MLP (ts_mlp.hip) against the unfused chain fc1 (library) -> bias+GELU kernel -> fc2 (library)"""
+    B = 2
+    for (H, W, C, nH) in STAGES[:2]:
+        T = B * H * W
+        x = torch.randn(T, C, device="cuda").bfloat16()
+        w1 = (torch.randn(4 * C, C, device="cuda") * 0.05).bfloat16()
+        w2 = (torch.randn(C, 4 * C, device="cuda") * 0.05).bfloat16()
+        b1 = torch.randn(4 * C, device="cuda") * 0.1
+        b2 = torch.randn(C, device="cuda") * 0.1
+        b216 = b2.bfloat16()
+        dy = torch.randn(T, C, device="cuda").bfloat16()
+
+        def fused():
+            return Fn.mlp_fwd_raw(x, w1, b1, w2, b2)
+
+        def unfused():
+            hp = Fn.gemm_bf16(x, w1)
+            hh = torch.empty_like(hp)
+            Fn.call("swin_bias_gelu_fwd", Fn._p(hp), Fn._p(b1), Fn._p(hh), T, 4 * C, Fn.SWIN_BF16, Fn._s())
+            return Fn.gemm_bf16(hh, w2, b216)
+        a, b = fused().float(), unfused().float()
+        err = (a - b).abs().max().item()
+        mf, nf = timeit(fused)
+        mu, nu = timeit(unfused)
+        fl = 16.0 * T * C * C
+        print(f"mlp fwd T={T} C={C}: fused {mf:7.1f} us (min {nf:7.1f}; {fl / mf / 1e6:6.1f} TFLOP/s)  unfused {mu:7.1f} us   max|diff| {err:.4f}")
+        if os.environ.get("MLP_BWD", "1") == "1":
+            try:
+                mb, nb = timeit(lambda: Fn.mlp_bwd_raw(x, dy, w1, b1, w2))
+                print(f"mlp bwd T={T} C={C}: fused dgrad {mb:7.1f} us (min {nb:7.1f}; {24.0 * T * C * C / mb / 1e6:6.1f} TFLOP/s)")
+            except Exception as ex:          # noqa: BLE001
+                print("mlp bwd:", ex)
+
+
 def ln():
     for (H, W, C, nH) in STAGES:
         x = torch.randn(2 * H * W, C, device="cuda").bfloat16()
