@@ -16,6 +16,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libswin_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wno-comment"]
+# per-file additions.  ts_mlp.hip: hipcc's SLP vectoriser packs the GELU arithmetic into v_pk_fma_f32 / v_pk_mul_f32, which
+# cost several times two scalar v_fma_f32 next to MFMAs (guide, "packed f32 VALU ... an anti-lever beside MFMAs").
+EXTRA_FLAGS = {"ts_mlp.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -43,7 +46,7 @@ def build_library(force=False, verbose=False):
         o = os.path.join(LIBDIR, "obj", os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -175,8 +175,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_fwd_kernel(const bf16*
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int j = 0; j < G::NCH; ++j) {
-        if (j + 1 < G::NCH) stage(j + 1, (j + 1) & 1);              // lands under this chunk's MFMAs
+    for (int j = 0; j < ((ABL & 16) ? 0 : G::NCH); ++j) {
+        if (j + 1 < G::NCH && !(ABL & 8)) stage(j + 1, (j + 1) & 1);              // lands under this chunk's MFMAs
+        if ((ABL & 32) && wave >= WAVES / 2) __builtin_amdgcn_s_sleep(9);      // stagger the SIMD partners by ~half a tile
         const bf16* W1s = (const bf16*)(smem + (j & 1) * BUF);
         const bf16* W2s = (const bf16*)(smem + (j & 1) * BUF + I1::BYTES);
         // software pipeline over the hidden tiles: the W1 fragments of tile t+1 and the W2 fragments of tile t are read from
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_fwd_kernel(const bf16*
             __builtin_amdgcn_sched_barrier(0);
             // ---- GELU on the accumulators, packed straight into the next product's B fragments ----
 #pragma unroll
-            for (int q = 0; q < 16; ++q) a[q] = (ABL == 1) ? a[q] * 0.5f : gelu_f(a[q]);
+            for (int q = 0; q < 16; ++q) a[q] = (ABL & 1) ? a[q] * 0.5f : gelu_f(a[q]);
             const bf16x8 pf0 = pack8(a, 0), pf1 = pack8(a, 1);
             // ---- Yt += W2 rows (pi order) . gelu(Ht) ----
 #pragma unroll
@@ -264,6 +265,127 @@ int launch_fwd(const void* x, const void* w1, const float* b1, const void* w2, c
     return swin_launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward
+// Per hidden tile (32 hidden units x the wave's 32 tokens), everything transposed as in the forward:
+//   Hpre_t = W1 rows (pi) . Xt + b1          (recomputed: the forward saved nothing of size T x 4C)
+//   dH_t   = W2^T rows (pi) . dYt             A = transposed read of the W2 chunk image [C][CH]
+//   h = gelu(Hpre), dhpre = dH * gelu'(Hpre)  -> both written once, bf16, 16-byte stores (8 contiguous hidden units per lane)
+//   dXt   += W1^T rows (pi) . dhpre           A = transposed read of the W1 chunk image [CH][C]; B = the dhpre accumulators
+template <int C, int WAVES, int CH, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_bwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY,
+                                                               const bf16* __restrict__ W1, const float* __restrict__ b1,
+                                                               const bf16* __restrict__ W2, bf16* __restrict__ dX,
+                                                               bf16* __restrict__ Hout, bf16* __restrict__ dHpre, int64_t T) {
+    using G = TsGeom<C, CH>;
+    using I1 = WImg<CH, C>;
+    using I2 = WImg<C, CH>;
+    constexpr int NT = WAVES * 64;
+    constexpr int BUF = I1::BYTES + I2::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* b1s = (float*)(smem + 2 * BUF);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tok = (int64_t)blockIdx.x * (WAVES * 32) + wave * 32 + r;
+    const int64_t tokc = tok < T ? tok : T - 1;
+    auto stage = [&](int j, int buf) {
+        dma_image<CH, C, WAVES>(W1 + (int64_t)j * CH * C, C, smem + buf * BUF, wave, lane);
+        dma_image<C, CH, WAVES>(W2 + (int64_t)j * CH, G::HID, smem + buf * BUF + I1::BYTES, wave, lane);
+    };
+    stage(0, 0);
+    for (int i = tid; i < G::HID; i += NT) b1s[i] = b1[i];
+    bf16x8 xf[G::KS], df[G::KS];
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+        xf[s] = *(const bf16x8*)(X + tokc * C + 16 * s + 8 * h);
+        df[s] = *(const bf16x8*)(dY + tokc * C + 16 * s + 8 * h);
+    }
+    f32x16 xacc[G::CT];
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xacc[ct][q] = 0.f;
+    const int pr = pi16(r & 15) | (r & 16);
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) { asm volatile("" :: "v"(xf[s])); asm volatile("" :: "v"(df[s])); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int j = 0; j < G::NCH; ++j) {
+        if (j + 1 < G::NCH) stage(j + 1, (j + 1) & 1);
+        const bf16* W1s = (const bf16*)(smem + (j & 1) * BUF);
+        const bf16* W2s = (const bf16*)(smem + (j & 1) * BUF + I1::BYTES);
+#pragma unroll 1
+        for (int t = 0; t < G::HT; ++t) {
+            f32x16 a, d;
+            {
+                const float4* bp = (const float4*)&b1s[j * CH + 32 * t + 8 * h];
+                const float4 v0 = bp[0], v1 = bp[1], v2 = bp[4], v3 = bp[5];
+                a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+                a[8] = v2.x; a[9] = v2.y; a[10] = v2.z; a[11] = v2.w; a[12] = v3.x; a[13] = v3.y; a[14] = v3.z; a[15] = v3.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) d[q] = 0.f;
+            const bf16* w1row = W1s + (32 * t + pr) * I1::RS + 8 * h;
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) a = mfma32(*(const bf16x8*)(w1row + 16 * s), xf[s], a);
+            // dHt: A[row = hidden pi(r)][k = channel 16 s + 8 h + e] = W2s[channel][hidden]
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) d = mfma32(tr_frag_pi(W2s, I2::RS, 16 * s, 32 * t, lane), df[s], d);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float g, dg;
+                gelu_fg(a[q], g, dg);
+                a[q] = g;
+                d[q] *= dg;
+            }
+            const bf16x8 h0 = pack8(a, 0), h1 = pack8(a, 1), p0 = pack8(d, 0), p1 = pack8(d, 1);
+            if (tok < T) {
+                const int64_t o = tok * G::HID + j * CH + 32 * t + 8 * h;        // registers 0..7: hidden 8h.., 8..15: 16+8h..
+                *(bf16x8*)(Hout + o) = h0;
+                *(bf16x8*)(Hout + o + 16) = h1;
+                *(bf16x8*)(dHpre + o) = p0;
+                *(bf16x8*)(dHpre + o + 16) = p1;
+            }
+            // dXt += W1^T rows (pi) . dhpre: A[row = channel pi(r)][k = hidden 16 s2 + 8 h + e] = W1s[hidden][channel]
+#pragma unroll
+            for (int ct = 0; ct < G::CT; ++ct) {
+                xacc[ct] = mfma32(tr_frag_pi(W1s, I1::RS, 32 * t, 32 * ct, lane), p0, xacc[ct]);
+                xacc[ct] = mfma32(tr_frag_pi(W1s, I1::RS, 32 * t + 16, 32 * ct, lane), p1, xacc[ct]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (tok < T) {
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) *(bf16x8*)(dX + tok * C + 32 * ct + 16 * s + 8 * h) = pack8(xacc[ct], s);
+        }
+    }
+}
+
+template <int C, int WAVES, int CH, int OCC>
+int launch_bwd(const void* x, const void* dy, const void* w1, const float* b1, const void* w2, void* dx, void* hout, void* dhpre,
+               int64_t T, hipStream_t s) {
+    using G = TsGeom<C, CH>;
+    const size_t lds = 2 * (size_t)(WImg<CH, C>::BYTES + WImg<C, CH>::BYTES) + G::HID * sizeof(float);
+    static bool attr_set[16] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    auto kern = ts_mlp_bwd_kernel<C, WAVES, CH, OCC>;
+    if (dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SWIN_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    const unsigned blocks = (unsigned)((T + WAVES * 32 - 1) / (WAVES * 32));
+    kern<<<blocks, WAVES * 64, lds, s>>>((const bf16*)x, (const bf16*)dy, (const bf16*)w1, b1, (const bf16*)w2, (bf16*)dx, (bf16*)hout,
+                                         (bf16*)dhpre, T);
+    return swin_launch_status();
+}
+
 }  // namespace
 
 // y (T,C) = fc2(gelu(fc1(x))) : x (T,C) bf16, w1 (4C,C) bf16, b1 (4C) f32, w2 (C,4C) bf16, b2 (C) f32.  C in {96, 192}.
@@ -278,6 +400,13 @@ extern "C" int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1,
             if (abl == 1) return launch_fwd<96, 8, 128, 2, 1>(x, w1, b1, w2, b2, y, T, s);
             if (abl == 2) return launch_fwd<96, 4, 128, 1, 0>(x, w1, b1, w2, b2, y, T, s);
             if (abl == 3) return launch_fwd<96, 4, 64, 1, 0>(x, w1, b1, w2, b2, y, T, s);
+            if (abl == 8) return launch_fwd<96, 8, 128, 2, 8>(x, w1, b1, w2, b2, y, T, s);
+            if (abl == 32) return launch_fwd<96, 8, 128, 2, 32>(x, w1, b1, w2, b2, y, T, s);
+            if (abl == 16) return launch_fwd<96, 8, 128, 2, 16>(x, w1, b1, w2, b2, y, T, s);
+            if (abl == 9) return launch_fwd<96, 8, 128, 2, 9>(x, w1, b1, w2, b2, y, T, s);
+            if (abl == 4) return launch_fwd<96, 4, 32, 3, 0>(x, w1, b1, w2, b2, y, T, s);
+            if (abl == 5) return launch_fwd<96, 4, 32, 4, 0>(x, w1, b1, w2, b2, y, T, s);
+            if (abl == 6) return launch_fwd<96, 4, 32, 2, 0>(x, w1, b1, w2, b2, y, T, s);
             return launch_fwd<96, 8, 128, 2>(x, w1, b1, w2, b2, y, T, s);
         }
         case 192: return launch_fwd<192, 4, 64, 1>(x, w1, b1, w2, b2, y, T, s);
@@ -285,8 +414,16 @@ extern "C" int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1,
     }
 }
 
+
+// x, dy (T,C) bf16 -> dx (T,C), h (T,4C), dhpre (T,4C) bf16 (see include/swin_hip.h).  C in {96, 192}.
 extern "C" int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, const float* b1, const void* w2, void* dx, void* h,
                                  void* dhpre, int64_t T, int C, void* stream) {
-    (void)x; (void)dy; (void)w1; (void)b1; (void)w2; (void)dx; (void)h; (void)dhpre; (void)T; (void)C; (void)stream;
-    return SWIN_ERR_UNSUPPORTED;
+    if (T == 0) return SWIN_OK;
+    if (!x || !dy || !w1 || !b1 || !w2 || !dx || !h || !dhpre || T < 0) return SWIN_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 96: return launch_bwd<96, 8, 128, 2>(x, dy, w1, b1, w2, dx, h, dhpre, T, s);
+        case 192: return launch_bwd<192, 4, 64, 1>(x, dy, w1, b1, w2, dx, h, dhpre, T, s);
+        default: return SWIN_ERR_UNSUPPORTED;
+    }
 }

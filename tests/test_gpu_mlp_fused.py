@@ -57,3 +57,35 @@ def test_mlp_fused_gelu_tails(fn):
     ref = F.linear(F.gelu(F.linear(x.float(), w1.float(), b1)), w2.float(), b2)
     y = fn.mlp_fwd_raw(x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda()).float().cpu()
     np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=2.0 ** -7, atol=1e-6)
+
+
+@pytest.mark.parametrize("T,C", [(1, 96), (70, 96), (1000, 96), (128000, 96), (77, 192), (1024, 192), (32000, 192)])
+def test_mlp_fused_backward_vs_oracle(fn, T, C):
+    """dx, and the two operands handed to the weight-gradient GEMMs (h = gelu(fc1 x + b1), dhpre = (dy W2) * gelu'), against
+    fp32 autograd of the reference's Mlp on the CPU.  The kernel rounds dhpre to bf16 once before the last product (as the
+    unfused chain does), so dx carries ~2 bf16 ulps of its scale."""
+    x, w1, b1, w2, b2 = _case(T, C, 7 * T + C)
+    g = torch.Generator().manual_seed(T)
+    dy = (torch.randn(T, C, generator=g) * 0.5).bfloat16()
+    x0 = x.float().requires_grad_(True)
+    hpre = F.linear(x0, w1.float(), b1)
+    hpre.retain_grad()
+    h = F.gelu(hpre)
+    y = F.linear(h, w2.float(), b2)
+    y.backward(dy.float())
+    dx, hh, dhp = fn.mlp_bwd_raw(x.cuda(), dy.cuda(), w1.cuda(), b1.cuda(), w2.cuda())
+    torch.cuda.synchronize()
+    assert dx.shape == (T, C) and hh.shape == dhp.shape == (T, 4 * C)
+    np.testing.assert_allclose(hh.float().cpu().numpy(), h.detach().numpy(), rtol=0, atol=_tol(h.detach(), 1.01))
+    np.testing.assert_allclose(dhp.float().cpu().numpy(), hpre.grad.numpy(), rtol=0, atol=_tol(hpre.grad, 2))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), x0.grad.numpy(), rtol=0, atol=_tol(x0.grad, 3))
+    assert (dx.float().cpu() - x0.grad).abs().mean().item() < _tol(x0.grad, 0.25)
+    # the weight gradients the step forms from these operands (wgrad_linear_bf16) equal autograd's
+    dw2 = dy.float().t() @ hh.float().cpu()
+    dw1 = dhp.float().cpu().t() @ x.float()
+    w1g, w2g = torch.autograd.grad(F.linear(F.gelu(F.linear(x.float(), w1.float().requires_grad_(True), b1)),
+                                            w2.float().requires_grad_(True), b2), [], allow_unused=True) if False else (None, None)
+    w1f, w2f = w1.float().requires_grad_(True), w2.float().requires_grad_(True)
+    F.linear(F.gelu(F.linear(x.float(), w1f, b1)), w2f, b2).backward(dy.float())
+    np.testing.assert_allclose(dw2.numpy(), w2f.grad.numpy(), rtol=0, atol=2e-2 * float(w2f.grad.abs().max()) + 1e-3)
+    np.testing.assert_allclose(dw1.numpy(), w1f.grad.numpy(), rtol=0, atol=2e-2 * float(w1f.grad.abs().max()) + 1e-3)
