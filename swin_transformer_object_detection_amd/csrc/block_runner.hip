@@ -17,8 +17,10 @@
 //  9 wproj (C,C)  10 bproj16|null 11 n2w f32 12 n2b f32 13 w1 (4C,C) 14 b1 (4C f32) 15 w2 (C,4C) 16 b216|null
 //  17 nnw f32|null 18 nnb f32|null
 //  outputs / saved: 19 qkv (T,3C) 20 lse (f32) 21 o 22 y (tmp) 23 x1 24 n2 25 mean2 26 rstd2 27 hpre (T,4C) 28 h (T,4C)
-//  29 y2 (tmp) 30 x2 31 nn|null 32 mean3|null 33 rstd3|null 34 gemm workspace
-// ints: B, H, W, C, nH, shift;  floats: scale, eps
+//  29 y2 (tmp) 30 x2 31 nn|null 32 mean3|null 33 rstd3|null 34 gemm workspace 35 b2 (C f32; fused MLP only)
+// ints: B, H, W, C, nH, shift, fused_mlp;  floats: scale, eps
+// fused_mlp != 0 (C in {96,192}): fc1 -> GELU -> fc2 is ONE launch (swin_mlp_fwd_bf16, csrc/ts_mlp.hip); hpre / h (27, 28) are
+// neither written nor saved -- the backward recomputes them.
 extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const float* fv, void* stream) {
     if (!p || !iv || !fv) return SWIN_ERR_BAD_ARG;
     const int B = (int)iv[0], H = (int)iv[1], W = (int)iv[2], C = (int)iv[3], nH = (int)iv[4], shift = (int)iv[5];
@@ -32,9 +34,13 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
     CHK(swin_gemm_bf16(p[21], p[9], p[10], const_cast<void*>(p[22]), T, C, C, 0, ws, stream));
     CHK(swin_add_layernorm_fwd(p[0], p[22], (const float*)p[2], L, (const float*)p[11], (const float*)p[12], const_cast<void*>(p[23]),
                                const_cast<void*>(p[24]), (float*)p[25], (float*)p[26], T, C, eps, SWIN_BF16, stream));
-    CHK(swin_gemm_bf16(p[24], p[13], nullptr, const_cast<void*>(p[27]), T, 4 * C, C, 0, ws, stream));
-    CHK(swin_bias_gelu_fwd(p[27], (const float*)p[14], const_cast<void*>(p[28]), T, 4 * C, SWIN_BF16, stream));
-    CHK(swin_gemm_bf16(p[28], p[15], p[16], const_cast<void*>(p[29]), T, C, 4 * C, 0, ws, stream));
+    if (iv[6]) {
+        CHK(swin_mlp_fwd_bf16(p[24], p[13], (const float*)p[14], p[15], (const float*)p[35], const_cast<void*>(p[29]), T, C, stream));
+    } else {
+        CHK(swin_gemm_bf16(p[24], p[13], nullptr, const_cast<void*>(p[27]), T, 4 * C, C, 0, ws, stream));
+        CHK(swin_bias_gelu_fwd(p[27], (const float*)p[14], const_cast<void*>(p[28]), T, 4 * C, SWIN_BF16, stream));
+        CHK(swin_gemm_bf16(p[28], p[15], p[16], const_cast<void*>(p[29]), T, C, 4 * C, 0, ws, stream));
+    }
     if (p[17])
         CHK(swin_add_layernorm_fwd(p[23], p[29], (const float*)p[3], L, (const float*)p[17], (const float*)p[18],
                                    const_cast<void*>(p[30]), const_cast<void*>(p[31]), (float*)p[32], (float*)p[33], T, C, eps,
@@ -56,7 +62,9 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
 //  fp32 gradient accumulators (null = not wanted): 37 dWqkv 38 dbqkv 39 dbqkv_pad 40 dWproj 41 dbproj 42 dW1 43 db1 44 dW2
 //          45 db2 46 dn2w 47 dn2b 48 dnnw 49 dnnb 50 dtable
 //  workspaces: 51 attention backward  52 LayerNorm backward (norm2)  53 LayerNorm backward (next norm)  54 gemm
-// ints: B, H, W, C, nH, shift;  floats: scale
+// ints: B, H, W, C, nH, shift, fused_mlp;  floats: scale
+// fused_mlp != 0: 9 (hpre) and 10 (h) were not saved; swin_mlp_bwd_bf16 recomputes them from n2 (8), writes dn2 (32) and, as
+// temporaries for the two weight-gradient GEMMs, h into 30 and dhpre into 31; db1 (43) then comes from the dW1 launch.
 extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const float* fv, void* stream) {
     if (!p || !iv || !fv) return SWIN_ERR_BAD_ARG;
     const int B = (int)iv[0], H = (int)iv[1], W = (int)iv[2], C = (int)iv[3], nH = (int)iv[4], shift = (int)iv[5];
@@ -76,6 +84,17 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
         if (!p[24]) return SWIN_ERR_BAD_ARG;
         dx1 = p[24];
     }
+    if (iv[6]) {
+        CHK(swin_mlp_bwd_bf16(p[8], dy2, p[18], (const float*)p[22], p[19], M(32), M(30), M(31), T, C, stream));
+        if (p[44] || p[45]) {
+            if (!p[44]) return SWIN_ERR_UNSUPPORTED;
+            CHK(wgrad_linear_bf16(dy2, p[30], (float*)p[44], (float*)p[45], T, C, 4 * C, stream));
+        }
+        if (p[42] || p[43]) {
+            if (!p[42]) return SWIN_ERR_UNSUPPORTED;
+            CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], (float*)p[43], T, 4 * C, C, stream));
+        }
+    } else {
     // fc2: dh = dy2 w2 ; dW2 += dy2^T h ; db2 += colsum dy2
     CHK(swin_gemm_bf16(dy2, p[19], nullptr, M(30), T, 4 * C, C, 1, gws, stream));
     if (p[44] || p[45]) {
@@ -87,6 +106,7 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     // fc1
     CHK(swin_gemm_bf16(p[31], p[18], nullptr, M(32), T, C, 4 * C, 1, gws, stream));
     if (p[42]) CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], nullptr, T, 4 * C, C, stream));
+    }
     // first residual + norm2
     if (!p[46] || !p[47]) return SWIN_ERR_BAD_ARG;
     CHK(swin_layernorm_bwd(p[32], p[5], (const float*)p[20], (const float*)p[6], (const float*)p[7], dx1, M(26), p[14] ? M(33) : nullptr,

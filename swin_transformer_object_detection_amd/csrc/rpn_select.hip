@@ -11,7 +11,7 @@
 // exactly the order a stable sort produces from a level-major, index-ascending list.  At the nms_pre boundary a stable
 // descending sort keeps, among the anchors tied with the threshold score, those with the LOWEST indices: the compaction
 // below admits tied anchors in index order until the level's quota is full.  So the candidate SET and every later
-// tie-break equal the reference's (oracle/callers_oracle.py::rpn_get_bboxes), without sorting anything here.
+// tie-break equal the reference's (checked against the CPU restatement of rpn_get_bboxes in the tests), without sorting here.
 //
 // HBM-bound integer/byte work: the logits are read once (2-4 B each), the 4-byte keys written once and re-read three
 // times from L2 (768 KB per block at level 0); deltas and anchors are read for the selected anchors only.

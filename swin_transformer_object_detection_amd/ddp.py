@@ -28,8 +28,12 @@ Works unchanged on CPU with the gloo backend (tests/test_ddp_gloo.py, world_size
 """
 import time
 
+import os
+
 import torch
 import torch.distributed as dist
+
+_DEBUG = os.environ.get("SWIN_DDP_DEBUG") == "1"     # record where a parameter's gradient first arrived (late-arrival diagnosis)
 
 
 class BucketedGradReducer:
@@ -57,7 +61,11 @@ class BucketedGradReducer:
             self._make_bucket(cur)
         self._hooks = []
         for b in self.buckets:
-            for leaf in b['leaves']:
+            for i, leaf in enumerate(b['leaves']):
+                # the engine runs a leaf's accumulate node (and both hooks) even when a custom Function returned None for it
+                # -- exactly what the sink kernels do.  The tensor hook sees the incoming gradient and records whether it is a
+                # real one, so that a None "arrival" after the bucket was issued is not mistaken for a late gradient.
+                self._hooks.append(leaf.register_hook(lambda g, b=b, i=i: self._pre(b, i, g)))
                 self._hooks.append(leaf.register_post_accumulate_grad_hook(self._on_grad))
         # gradient sinks: weight-gradient kernels may accumulate straight into the fp32 bucket views
         from . import mixed
@@ -77,7 +85,7 @@ class BucketedGradReducer:
             off += p.numel()
         leaves = [self.leaf_of(p) for p in plist]
         b = dict(flat=flat, params=list(plist), leaves=leaves, views=views, pending=len(plist), handle=None,
-                 arrived=[False] * len(plist), direct=[False] * len(plist), launched=False, ready=False,
+                 arrived=[False] * len(plist), direct=[False] * len(plist), real=[False] * len(plist), launched=False, ready=False,
                  no=len(self.buckets), index={id(l): i for i, l in enumerate(leaves)})
         for l in leaves:
             self._l2b[id(l)] = b
@@ -131,9 +139,14 @@ class BucketedGradReducer:
             self._next += 1
 
     def _arrive(self, b, i):
+        if _DEBUG and not b['arrived'][i]:
+            import traceback
+            b.setdefault('first', {})[i] = "".join(traceback.format_stack(limit=10))
         if b['launched']:
+            if _DEBUG:
+                print("first arrival of the parameter:\n" + b.get('first', {}).get(i, '?'), flush=True)
             raise RuntimeError(
-                f"gradient for parameter {i} of bucket {b['no']} arrived after the bucket's all-reduce was issued: more "
+                f"gradient for parameter {i} (shape {tuple(b['params'][i].shape)}) of bucket {b['no']} arrived after the bucket's all-reduce was issued: more "
                 "than one backward() per finish(), or a parameter used both through a gradient-sink kernel and plain "
                 "autograd in different backward passes.  Not supported (it would be dropped or race with the collective).")
         if not b['arrived'][i]:
@@ -143,9 +156,17 @@ class BucketedGradReducer:
                 b['ready'] = True
                 self._issue_ready()
 
+    def _pre(self, b, i, g):
+        b['real'][i] = g is not None
+        return None
+
     def _on_grad(self, leaf):
         b = self._l2b[id(leaf)]
-        self._arrive(b, b['index'][id(leaf)])
+        i = b['index'][id(leaf)]
+        real, b['real'][i] = b['real'][i], False
+        if not real and b['arrived'][i]:
+            return                                      # autograd visited the leaf with no gradient (a sink kernel delivered it)
+        self._arrive(b, i)
 
     def _on_direct(self, b, i):
         """A kernel accumulated parameter i's gradient straight into its bucket view (mixed.grad_sink)."""
@@ -168,6 +189,7 @@ class BucketedGradReducer:
             b['pending'] = len(b['params'])
             b['arrived'] = [False] * len(b['params'])
             b['direct'] = [False] * len(b['params'])
+            b['real'] = [False] * len(b['params'])
             b['launched'] = b['ready'] = False
         self._next = 0
 

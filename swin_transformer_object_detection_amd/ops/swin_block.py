@@ -63,6 +63,8 @@ def _bias16(b):
 
 # ---- native runner (csrc/block_runner.hip): one C call per block and direction ------------------------------------
 _RUNNER = os.environ.get("SWIN_BLOCK_RUNNER", "1") != "0"     # 0: issue the kernels one by one from Python (A/B, debugging)
+_FUSED_MLP = os.environ.get("SWIN_FUSED_MLP", "1") != "0"     # 0: fc1 / GELU / fc2 as three launches everywhere (A/B)
+_FUSED_MLP_C = (96, 192)                                      # widths the token-stationary MLP kernels are built for
 _SCRATCH = {}
 
 
@@ -272,8 +274,14 @@ class _SwinBlockFn(torch.autograd.Function):
         has_next = nnw is not None
         scale = float((C // nH) ** -0.5)
         TC = T * C
-        flat = torch.empty(16 * TC, device=dev, dtype=torch.bfloat16)
-        qkv, o, y, x1, n2, hpre, h, y2 = _carve(flat, [3 * TC, TC, TC, TC, TC, 4 * TC, 4 * TC, TC])
+        fused = _FUSED_MLP and C in _FUSED_MLP_C       # fc1 -> GELU -> fc2 in one launch; hpre / h are recomputed in backward
+        if fused:
+            flat = torch.empty(8 * TC, device=dev, dtype=torch.bfloat16)
+            qkv, o, y, x1, n2, y2 = _carve(flat, [3 * TC, TC, TC, TC, TC, TC])
+            hpre = h = None
+        else:
+            flat = torch.empty(16 * TC, device=dev, dtype=torch.bfloat16)
+            qkv, o, y, x1, n2, hpre, h, y2 = _carve(flat, [3 * TC, TC, TC, TC, TC, 4 * TC, 4 * TC, TC])
         nW = ((H + 6) // 7) * ((W + 6) // 7)
         nl = B * nW * nH * 64
         f32 = torch.empty(nl + 4 * T + nH * 4096, device=dev, dtype=torch.float32)
@@ -286,17 +294,20 @@ class _SwinBlockFn(torch.autograd.Function):
         f_n2w, f_n2b = _f32(n2w), _f32(n2b)
         f_nnw, f_nnb = (_f32(nnw), _f32(nnb)) if has_next else (None, None)
         bq16, bp16, b216 = _bias16(bqkv), _bias16(bproj), _bias16(b2)
-        ptrs = (ctypes.c_void_p * 35)(
+        f_b2 = _f32(b2.detach()) if (fused and b2 is not None) else (torch.zeros(C, device=dev) if fused else None)
+        ptrs = (ctypes.c_void_p * 36)(
             _ptr(x), _ptr(n1), _ptr(dp0), _ptr(dp1), _ptr(wqkv), _ptr(bq16), _ptr(qkv_bias), _ptr(tab), _ptr(bias_exp), _ptr(wproj),
             _ptr(bp16), _ptr(f_n2w), _ptr(f_n2b), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b216), _ptr(f_nnw), _ptr(f_nnb), _ptr(qkv),
             _ptr(lse), _ptr(o), _ptr(y), _ptr(x1), _ptr(n2), _ptr(mean2), _ptr(rstd2), _ptr(hpre), _ptr(h), _ptr(y2), _ptr(x2),
-            _ptr(nn_), _ptr(mean3) if has_next else None, _ptr(rstd3) if has_next else None, _ptr(gws))
-        iv = (ctypes.c_int64 * 6)(B, H, W, C, nH, shift)
+            _ptr(nn_), _ptr(mean3) if has_next else None, _ptr(rstd3) if has_next else None, _ptr(gws), _ptr(f_b2))
+        iv = (ctypes.c_int64 * 7)(B, H, W, C, nH, shift, 1 if fused else 0)
         fv = (ctypes.c_float * 2)(scale, LN_EPS)
         call("swin_block_fwd", ptrs, iv, fv, _s())
         shp = (B, L, C)
+        ctx.fused_mlp = fused
         ctx.save_for_backward(n1, qkv.view(B, L, 3 * C), bias_exp.view(nH, 64, 64), lse, o.view(shp), x1.view(shp), mean2, rstd2,
-                              n2.view(shp), hpre.view(B, L, 4 * C), h.view(B, L, 4 * C), x2, mean3 if has_next else None,
+                              n2.view(shp), None if fused else hpre.view(B, L, 4 * C), None if fused else h.view(B, L, 4 * C), x2,
+                              mean3 if has_next else None,
                               rstd3 if has_next else None, dp0, dp1, wqkv, wproj, w1, w2, n2w, nnw, b1, qkv_bias)
         ctx.geom = (B, H, W, C, nH, shift, scale)
         ctx.masters = masters
@@ -360,7 +371,7 @@ class _SwinBlockFn(torch.autograd.Function):
             _ptr(dn1), _ptr(dx1), _ptr(dy2), _ptr(dh), _ptr(dhpre), _ptr(dn2), _ptr(dy), _ptr(do), _ptr(dqkv), _ptr(dbexp),
             _ptr(a_wqkv), _ptr(a_bqkv), _ptr(a_bpad), _ptr(a_wproj), _ptr(a_bproj), _ptr(a_w1), _ptr(a_b1), _ptr(a_w2), _ptr(a_b2),
             _ptr(a_n2w), _ptr(a_n2b), _ptr(a_nnw), _ptr(a_nnb), _ptr(a_tab), _ptr(ws_attn), _ptr(ws_ln2), _ptr(ws_ln3), _ptr(gws))
-        iv = (ctypes.c_int64 * 6)(B, H, W, C, nH, shift)
+        iv = (ctypes.c_int64 * 7)(B, H, W, C, nH, shift, 1 if getattr(ctx, 'fused_mlp', False) else 0)
         fv = (ctypes.c_float * 1)(scale)
         call("swin_block_bwd", ptrs, iv, fv, _s())
         g_bq = f_bqkv()
