@@ -451,7 +451,10 @@ def test_fused_swin_block_equals_per_op_blocks(fused_mlp, monkeypatch):
         torch.manual_seed(77)                                    # same DropPath draws
         x = img.clone().requires_grad_(True)
         outs = net(x)
-        (sum((o.float() * (i + 1)).square().mean() for i, o in enumerate(outs))).backward()
+        # a seeded random functional of the outputs: sum(o^2) would have a zero analytic gradient through the output
+        # LayerNorms (|LN(x)| is constant at init) and leave nothing but rounding noise to compare
+        gw = torch.Generator(device="cuda").manual_seed(9)
+        (sum((o.float() * torch.randn(o.shape, device="cuda", generator=gw)).sum() for o in outs)).backward()
         res[fused] = ([o.detach().float().clone() for o in outs], x.grad.clone(),
                       {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None})
     (o0, gx0, gp0), (o1, gx1, gp1) = res[False], res[True]
@@ -461,10 +464,12 @@ def test_fused_swin_block_equals_per_op_blocks(fused_mlp, monkeypatch):
         for a, b in zip(o0, o1):
             assert float((a - b).abs().max()) <= 6 * ulp * float(a.abs().max())
             assert float((a - b).abs().mean()) <= 0.5 * ulp * float(a.abs().max())
-        assert float((gx0 - gx1).abs().max()) <= 0.05 * float(gx0.abs().max())
-        for n in gp0:
-            d = float((gp0[n] - gp1[n]).abs().max())
-            assert d <= 0.05 * float(gp0[n].abs().max()) + 1e-9, (n, d)
+        # gradients: every intermediate is bf16 in both paths, so they differ by accumulated bf16 rounding noise --
+        # compared in the L2 norm (the image gradient has passed through all four blocks)
+        rel = lambda a, b: float((a - b).norm() / (a.norm() + 1e-20))        # noqa: E731
+        assert rel(gx0, gx1) <= 0.05, rel(gx0, gx1)
+        bad = {n: round(rel(gp0[n], gp1[n]), 4) for n in gp0 if rel(gp0[n], gp1[n]) > 0.05}
+        assert not bad, bad
         return
     for a, b in zip(o0, o1):
         assert torch.equal(a, b)
