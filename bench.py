@@ -128,6 +128,7 @@ def gemm_rooflines(device, steps=20):
     lx = torch.randn(T, N2, generator=g).to(device=device, dtype=torch.bfloat16)
     ldw = torch.zeros(N1, N2, device=device)
     ldb = torch.zeros(N1, device=device)
+    Fn.ensure_scratch(device if device.index is not None else torch.device("cuda", torch.cuda.current_device()))
     cases = [
         ("gemm_bf16_kernel<ConvA> (3x3 conv fwd/dgrad, P2 2x200x320x256)", 2.0 * B * H * W * C * C * 9,
          lambda: Fn.call("conv3x3_nhwc_bf16", Fn._p(x), Fn._p(w), Fn._p(b), Fn._p(y), B, H, W, C, C, 0, Fn._s())),

@@ -34,6 +34,7 @@ struct PlainX {
 struct ConvX {
     static constexpr int kBlocksManyTiles = 512;
     const bf16* x; int64_t T; int H, W, Cin;
+    int qd, rd;                       // a stage advances every row by dt = WKG * WT pixels: dt / W and dt % W (host-computed)
     struct St { int64_t off; int y, x, dy, dx; bool ok; };
     __device__ __forceinline__ void init(St& s, int64_t t, int n) const {
         const int tap = n / Cin, c = n - tap * Cin;
@@ -42,14 +43,17 @@ struct ConvX {
         s.x = (int)(t % W); s.y = (int)((t / W) % H);
         s.off = (t + (int64_t)s.dy * W + s.dx) * Cin + c;       // the tap's source pixel, this thread's 8 channels
     }
+    // dt is the same for every stage of a launch, so the division is done once on the host: 6 VALU per row instead of an
+    // integer division in a divergent branch (the first form spent 14 VALU per MFMA on this, PMC profiles/r02_pmc_wgrad*)
     __device__ __forceinline__ void advance(St& s, int dt) const {
         s.off += (int64_t)dt * Cin;
-        s.x += dt;
-        if (s.x >= W) { const int q = s.x / W; s.x -= q * W; s.y += q; if (s.y >= H) s.y %= H; }
+        s.x += rd; s.y += qd;
+        if (s.x >= W) { s.x -= W; s.y += 1; }
+        if (s.y >= H) { s.y -= H; if (s.y >= H) s.y %= H; }
     }
     __device__ __forceinline__ int64_t offset(const St& s) const {
-        const int yy = s.y + s.dy, xx = s.x + s.dx;
-        return (s.ok && yy >= 0 && yy < H && xx >= 0 && xx < W) ? s.off : -1;
+        const unsigned yy = (unsigned)(s.y + s.dy), xx = (unsigned)(s.x + s.dx);
+        return (s.ok && yy < (unsigned)H && xx < (unsigned)W) ? s.off : -1;
     }
 };
 
@@ -73,7 +77,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t0, int col0, in
 template <typename XLoader, int WKG>
 __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(const bf16* __restrict__ dy, XLoader X, float* __restrict__ dw,
                                                          float* __restrict__ dbias, int64_t T, int N1, int N2,
-                                                         int64_t t_per_split, int use_atomic) {
+                                                         int64_t t_per_split, int mode, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) bf16 lds_all[];         // [WKG][dY|X][WT * WROW]: 40 KB per group
     const int n1_0 = blockIdx.y * WN, n2_0 = blockIdx.x * WN;
     const int64_t t_begin = (int64_t)blockIdx.z * t_per_split;
@@ -222,7 +226,22 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
         }
     }
     if (grp != 0) return;
-    // D[row n1][col n2]: lane = n2 column, registers = n1 rows -> 32 consecutive n2 per half-wave: 128-B segments
+    // D[row n1][col n2]: lane = n2 column, registers = n1 rows -> 32 consecutive n2 per half-wave: 128-B segments.
+    // mode 0: this block owns the tile (one split): plain read-modify-write.  mode 1: contiguous fp32 atomics.
+    // mode 2: the whole 128x128 partial tile goes to this split's slab with plain stores; wgrad_reduce_kernel adds the slabs
+    // into dw (float atomics run at ~1.3 TB/s chip-wide against ~6 TB/s for stores: blocks x 64 KB of atomics were 20 of the
+    // 38 us of a stage-3 Linear weight gradient and 33 of 275 us of the P2 conv weight gradient).
+    if (mode == 2) {
+        float* tile = slab + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (WN * WN);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    tile[(w1 * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h) * WN + w2 * 64 + 32 * j + c] = acc[i][j][reg];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -234,21 +253,54 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
                 int n1 = n1_0 + w1 * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 if (n1 >= N1) continue;
                 float* p = dw + (int64_t)n1 * N2 + n2;
-                if (use_atomic) atomicAdd(p, acc[i][j][reg]);
-                else *p = acc[i][j][reg];
+                if (mode == 1) atomicAdd(p, acc[i][j][reg]);
+                else *p += acc[i][j][reg];
             }
         }
 }
 
+// dw[n1][n2] += sum over splits of the slab tiles written by wgrad_kernel (mode 2).  grid (g2, g1, 8): a block takes 16 rows
+// of a 128x128 tile; consecutive threads read consecutive columns of every slab (coalesced) and own their dw elements.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int N1, int N2,
+                                                           int splits) {
+    const int64_t tiles = (int64_t)gridDim.x * gridDim.y;
+    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int n1_0 = blockIdx.y * WN, n2_0 = blockIdx.x * WN;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = blockIdx.z * 2048 + k * 256 + threadIdx.x;
+        const int r = idx >> 7, cc = idx & 127;
+        const int n1 = n1_0 + r, n2 = n2_0 + cc;
+        if (n1 >= N1 || n2 >= N2) continue;
+        const float* sp = slab + tile * (WN * WN) + idx;
+        float a = 0.f;
+        for (int z = 0; z < splits; ++z) a += sp[(int64_t)z * tiles * (WN * WN)];
+        dw[(int64_t)n1 * N2 + n2] += a;
+    }
+}
+
+// Scratch for the split partials, registered once per device by the host (swin_set_scratch): no allocation in the launch path.
+static void* g_scratch[16] = {};
+static int64_t g_scratch_bytes[16] = {};
+
+template <typename XLoader> static inline void set_stage_step(XLoader&, int) {}
+template <> inline void set_stage_step<ConvX>(ConvX& X, int dt) { X.qd = dt / X.W; X.rd = dt % X.W; }
+
 template <typename XLoader, int WKG>
 static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, int64_t T, int N1, int N2, hipStream_t s) {
+    set_stage_step(X, WKG * WT);
     const size_t lds_bytes = (size_t)WKG * 2 * WT * WROW * sizeof(bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wgrad_kernel<XLoader, WKG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess)
-            return SWIN_ERR_LAUNCH;
-        attr_set = true;
+    static bool attr_set[16] = {};
+    {
+        int dev0 = 0;
+        hipGetDevice(&dev0);
+        if (dev0 < 0 || dev0 >= 16) return SWIN_ERR_UNSUPPORTED;
+        if (!attr_set[dev0]) {
+            if (hipFuncSetAttribute((const void*)wgrad_kernel<XLoader, WKG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes) != hipSuccess)
+                return SWIN_ERR_LAUNCH;
+            attr_set[dev0] = true;
+        }
     }
     int g1 = (N1 + WN - 1) / WN, g2 = (N2 + WN - 1) / WN;
     // enough splits to fill the chip with 8 waves per CU (2 blocks of 4 waves or 1 block of 8), each split a multiple
@@ -271,7 +323,20 @@ static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, i
     per = ((per + WKG - 1) / WKG) * WKG * WT;
     splits = (int)((T + per - 1) / per);
     dim3 grid(g2, g1, splits);
-    wgrad_kernel<XLoader, WKG><<<grid, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, 1);
+    int dev = 0;
+    hipGetDevice(&dev);
+    static const int force_mode = getenv("SWIN_WGRAD_MODE") ? atoi(getenv("SWIN_WGRAD_MODE")) : -1;      // development A/B
+    const int64_t slab_bytes = (int64_t)splits * g1 * g2 * WN * WN * (int64_t)sizeof(float);
+    // Measured on MI355X (tools/microbench.py wgrad, profiles/r02_wgrad_modes.txt): the fp32 atomics of the split partials are
+    // fire-and-forget and overlap the other blocks' MFMAs -- 36-40 us per backbone Linear and 272 us for the P2 conv against
+    // 54-195 us / 295 us with slabs + reduce launch, and 80 vs 88 us for the one-split read-modify-write.  The byte-rate model
+    // (1.3 TB/s of atomics) overstates their cost here, so atomics stay the default; SWIN_WGRAD_MODE=2 selects the slab form.
+    int mode = 1;
+    if (force_mode == 2 && dev >= 0 && dev < 16 && g_scratch[dev] && g_scratch_bytes[dev] >= slab_bytes) mode = 2;
+    if (force_mode == 0 && splits == 1) mode = 0;
+    float* slab = mode == 2 ? (float*)g_scratch[dev] : nullptr;
+    wgrad_kernel<XLoader, WKG><<<grid, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, mode, slab);
+    if (mode == 2) wgrad_reduce_kernel<<<dim3(g2, g1, 8), 256, 0, s>>>(slab, dw, N1, N2, splits);
     return swin_launch_status();
 }
 
@@ -300,6 +365,17 @@ extern "C" int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw,
     if (!dy || !x || !dw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SWIN_ERR_BAD_ARG;
     if (Cin % 8 || Cout % 8) return SWIN_ERR_UNSUPPORTED;
     int64_t T = (int64_t)N * H * W;
-    ConvX X{(const bf16*)x, T, H, W, Cin};
+    ConvX X{(const bf16*)x, T, H, W, Cin, 0, 0};
     return wgrad_launch((const bf16*)dy, X, dw, dbias, T, Cout, 9 * Cin, (hipStream_t)stream);
+}
+
+// Register a device scratch buffer (>= a few tens of MB) for the current device: the weight-gradient kernels then write
+// their split-T partial tiles there with plain stores and reduce them in a second launch instead of using float atomics.
+// The buffer must outlive every later call; contents never outlive one call on one stream.  NULL / 0 unregisters.
+extern "C" int swin_set_scratch(void* ptr, int64_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    g_scratch[dev] = ptr;
+    g_scratch_bytes[dev] = ptr ? bytes : 0;
+    return SWIN_OK;
 }

@@ -13,7 +13,7 @@ import torch
 
 from .. import _lib, mixed
 from .._lib import SWIN_BF16, call
-from .functional import LN_EPS, _f32, _ln_ws, _p, _s, gemm_bf16, rel_bias_expand
+from .functional import LN_EPS, _f32, _ln_ws, _p, _s, ensure_scratch, gemm_bf16, rel_bias_expand
 
 
 def _weight_grads(dy2, x2, w, w_master, b_master, need_w, need_b):
@@ -30,6 +30,7 @@ def _weight_grads(dy2, x2, w, w_master, b_master, need_w, need_b):
     dbf = None
     if need_b:
         dbf = bs[0] if bs is not None else torch.zeros(N1, device=x2.device, dtype=torch.float32)
+    ensure_scratch(x2.device)
     call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2, _s())
     dw = db = None
     if ws is not None:
@@ -373,6 +374,7 @@ class _SwinBlockFn(torch.autograd.Function):
             _ptr(a_n2w), _ptr(a_n2b), _ptr(a_nnw), _ptr(a_nnb), _ptr(a_tab), _ptr(ws_attn), _ptr(ws_ln2), _ptr(ws_ln3), _ptr(gws))
         iv = (ctypes.c_int64 * 7)(B, H, W, C, nH, shift, 1 if getattr(ctx, 'fused_mlp', False) else 0)
         fv = (ctypes.c_float * 1)(scale)
+        ensure_scratch(dev)
         call("swin_block_bwd", ptrs, iv, fv, _s())
         g_bq = f_bqkv()
         g_pad = f_bpad()

@@ -124,6 +124,29 @@ def wgrad():
         print(f"wgrad_conv {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
 
 
+def wgradp():
+    """the step's dominant weight-gradient shapes, few launches each (counter passes)"""
+    for (T, N1, N2) in [(128000, 384, 96), (128000, 96, 384), (8000, 1536, 384)]:
+        dy = torch.randn(T, N1, device="cuda").bfloat16()
+        x = torch.randn(T, N2, device="cuda").bfloat16()
+        dw = torch.zeros(N1, N2, device="cuda")
+        db = torch.zeros(N1, device="cuda")
+        med, _ = timeit(lambda: Fn.call("wgrad_linear_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), T, N1, N2, Fn._s()), n=5, warm=1)
+        print(f"wgrad_linear T={T} {N1}x{N2}: {med:7.1f} us")
+    for (N, H, W) in [(2, 200, 320), (256, 14, 14)]:
+        dy = torch.randn(N, H, W, 256, device="cuda").bfloat16()
+        x = torch.randn(N, H, W, 256, device="cuda").bfloat16()
+        dw = torch.zeros(256, 3, 3, 256, device="cuda")
+        db = torch.zeros(256, device="cuda")
+        med, _ = timeit(lambda: Fn.call("wgrad_conv3x3_nhwc_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), N, H, W, 256, 256, Fn._s()), n=5, warm=1)
+        fl = 2.0 * N * H * W * 256 * 256 * 9
+        print(f"wgrad_conv {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
+        xx = x.permute(0, 3, 1, 2)
+        w = torch.randn(256, 3, 3, 256, device="cuda").bfloat16() * 0.02
+        med, _ = timeit(lambda: Fn._conv3x3_raw(xx, w, db, False), n=5, warm=1)
+        print(f"conv3x3 fwd {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
+
+
 def mlp():
     """fused MLP (ts_mlp.hip) against the unfused chain fc1 (library) -> bias+GELU kernel -> fc2 (library)"""
     B = 2
@@ -253,5 +276,7 @@ def roiml():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "conv", "ln", "nms", "roi"]
+    if os.environ.get("SWIN_NO_SCRATCH") != "1":
+        Fn.ensure_scratch(torch.device("cuda", torch.cuda.current_device()))
     for w in which:
         globals()[w]()
