@@ -147,6 +147,20 @@ def wgradp():
         print(f"conv3x3 fwd {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
 
 
+def rpn():
+    """RPN proposal selection + decode (rpn_select.hip) at the five FPN shapes of 2x800x1280"""
+    sizes = [(200, 320), (100, 160), (50, 80), (25, 40), (13, 20)]
+    ls = [3 * h * w for h, w in sizes]
+    tot = sum(ls)
+    for dt in (torch.bfloat16, torch.float32):
+        cls = (torch.randn(2, tot, device="cuda") * 0.05).to(dt)
+        reg = (torch.randn(2, tot, 4, device="cuda") * 0.1).to(dt)
+        anchors = torch.rand(tot, 4, device="cuda") * 500
+        anchors[:, 2:] += anchors[:, :2]
+        med, mn = timeit(lambda: ops.rpn_topk_decode(cls, reg, anchors, ls, 2000, (0., 0., 0., 0.), (1., 1., 1., 1.), (800, 1280)))
+        print(f"rpn_topk_decode {dt}: {med:7.1f} us (min {mn:7.1f})")
+
+
 def mlp():
     """fused MLP (ts_mlp.hip) against the unfused chain fc1 (library) -> bias+GELU kernel -> fc2 (library)"""
     B = 2

@@ -18,6 +18,8 @@ def cat(n):
     if 'gelu' in n: return 'bias_gelu'
     if 'roi_align' in n: return 'roi_align'
     if 'nms' in n: return 'nms'
+    if 'rpn_topk' in n: return 'rpn select (mine)'
+    if 'ts_mlp' in n: return 'fused mlp (mine)'
     if 'assign_' in n or 'sample_' in n: return 'targets'
     if 'upsample' in n or 'im2row' in n: return 'fpn/embed (mine)'
     if 'bn_' in n: return 'batchnorm'
