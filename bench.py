@@ -42,8 +42,9 @@ def parse():
     ap.add_argument("--workload", default="mask_rcnn_swin_t", choices=sorted(WORKLOADS),
                     help="default: BASELINE.json configs[1] (the headline metric); the others are the BASELINE parity configurations, "
                          "timed for DESIGN.md only")
-    ap.add_argument("--check-sync", action="store_true",
-                    help="after the timed steps, verify that all ranks hold bit-identical parameters (N > 1)")
+    ap.add_argument("--no-check-sync", action="store_true",
+                    help="skip the replica check that runs by default on N > 1 (all ranks must hold bit-identical parameters "
+                         "after the timed steps)")
     return ap.parse_args()
 
 
@@ -75,10 +76,14 @@ def attention_roofline(device, steps=30):
     out = torch.empty(B, H * W, C, device=device, dtype=torch.bfloat16)
     lse = torch.empty(B * ((H + 6) // 7) * ((W + 6) // 7) * nH, 64, device=device, dtype=torch.float32)
     scale = 32 ** -0.5
+    # cache-cold: the launches rotate over four input / output sets (4 x 98 MB > the 256 MB Infinity Cache), so every launch
+    # reads its qkv from HBM as it does inside the step (where ~100 MB of other tensors pass between two attention launches)
+    sets = [(qkv, out, lse)] + [(qkv.clone(), torch.empty_like(out), torch.empty_like(lse)) for _ in range(3)]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    for s, e in ev:
+    for i, (s, e) in enumerate(ev):
+        q_, o_, l_ = sets[i % 4]
         s.record()
-        Fn.call("swin_window_attn_fwd", Fn._p(qkv), Fn._p(qb), Fn._p(bias_exp), Fn._p(out), Fn._p(lse), B, H, W, C, nH, 3,
+        Fn.call("swin_window_attn_fwd", Fn._p(q_), Fn._p(qb), Fn._p(bias_exp), Fn._p(o_), Fn._p(l_), B, H, W, C, nH, 3,
                 scale, Fn.SWIN_BF16, Fn._s())
         e.record()
     torch.cuda.synchronize()
@@ -102,10 +107,31 @@ def attention_roofline(device, steps=30):
     return {"kernel": "win_attn_fwd_bf16_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(avg_ms, 5), "median_launch_ms": round(ms[len(ms) // 2], 5),
-            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes_per_launch": alg_bytes, "cache": "cold (launches rotate over 4 x 98 MB of inputs/outputs)",
+            "step_share_profiled": step_shares({"a": "win_attn_fwd"}).get("a"),
             "mfma_util": {"useful_tflops": round(useful_tflops, 1), "issued_tflops": round(issued_tflops, 1),
                           "issued_frac_of_dense_bf16_peak": round(issued_tflops / MFMA_PEAK_TFLOPS, 4)},
             "shape": {"B": B, "H": H, "W": W, "C": C, "heads": nH, "shift": 3, "windows": B * 29 * 46}}
+
+
+PROFILE_STATS = os.path.join(ROOT, "profiles", "r02_step_kernel_stats.csv")     # rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3`
+PROFILE_STEPS = 13
+
+
+def step_shares(patterns):
+    """share of the profiled step's kernel time taken by the kernels whose name contains each pattern (committed rocprofv3
+    summary; the roofline launches bench.py itself makes inside that trace are subtracted: 23 per MFMA case, 35 attention)."""
+    import csv
+    try:
+        rows = list(csv.DictReader(open(PROFILE_STATS)))
+    except OSError:
+        return {}
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    out = {}
+    for key, pat in patterns.items():
+        ns = sum(float(r["TotalDurationNs"]) for r in rows if pat in r["Name"])
+        out[key] = round(ns / total, 4) if total > 0 else None
+    return out
 
 
 def gemm_rooflines(device, steps=20):
@@ -129,7 +155,21 @@ def gemm_rooflines(device, steps=20):
     ldw = torch.zeros(N1, N2, device=device)
     ldb = torch.zeros(N1, device=device)
     Fn.ensure_scratch(device if device.index is not None else torch.device("cuda", torch.cuda.current_device()))
+    Tm, Cm = PER_GPU_BATCH * (IMG_H // 4) * (IMG_W // 4), 96
+    mx = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=torch.bfloat16)
+    mdy = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=torch.bfloat16)
+    mw1 = (torch.randn(4 * Cm, Cm, generator=g) * 0.05).to(device=device, dtype=torch.bfloat16)
+    mw2 = (torch.randn(Cm, 4 * Cm, generator=g) * 0.05).to(device=device, dtype=torch.bfloat16)
+    mb1, mb2 = torch.zeros(4 * Cm, device=device), torch.zeros(Cm, device=device)
+    my = torch.empty_like(mx)
+    mh = torch.empty(Tm, 4 * Cm, device=device, dtype=torch.bfloat16)
+    mdh = torch.empty_like(mh)
     cases = [
+        (f"ts_mlp_fwd_kernel (fused fc1+GELU+fc2, stage 1: T={Tm}, C={Cm})", 16.0 * Tm * Cm * Cm,
+         lambda: Fn.call("swin_mlp_fwd_bf16", Fn._p(mx), Fn._p(mw1), Fn._p(mb1), Fn._p(mw2), Fn._p(mb2), Fn._p(my), Tm, Cm, Fn._s())),
+        (f"ts_mlp_bwd_kernel (fused MLP data gradient with fc1 recompute, stage 1: T={Tm}, C={Cm})", 24.0 * Tm * Cm * Cm,
+         lambda: Fn.call("swin_mlp_bwd_bf16", Fn._p(mx), Fn._p(mdy), Fn._p(mw1), Fn._p(mb1), Fn._p(mw2), Fn._p(my), Fn._p(mh),
+                         Fn._p(mdh), Tm, Cm, Fn._s())),
         ("gemm_bf16_kernel<ConvA> (3x3 conv fwd/dgrad, P2 2x200x320x256)", 2.0 * B * H * W * C * C * 9,
          lambda: Fn.call("conv3x3_nhwc_bf16", Fn._p(x), Fn._p(w), Fn._p(b), Fn._p(y), B, H, W, C, C, 0, Fn._s())),
         ("wgrad_kernel<ConvX> (3x3 conv weight gradient, P2)", 2.0 * B * H * W * C * C * 9,
@@ -151,6 +191,11 @@ def gemm_rooflines(device, steps=20):
         out.append({"kernel": name, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg, 5),
                     "algorithmic_flops_per_launch": flops})
+    shares = step_shares({0: "ts_mlp_fwd_kernel", 1: "ts_mlp_bwd_kernel", 2: "gemm_bf16_kernel<ConvA", 3: "wgrad_kernelI5ConvX",
+                          4: "wgrad_kernelI6PlainX"})
+    for i, o in enumerate(out):
+        o["step_share_profiled"] = shares.get(i)          # all launches of this kernel family in the profiled step
+    out.sort(key=lambda o: -(o["step_share_profiled"] or 0.0))
     return out
 
 
@@ -250,12 +295,19 @@ def main():
     batch = data.synthetic_batch(PER_GPU_BATCH, img_h, img_w, device, seed=rank)     # per-rank data
     torch.manual_seed(1000 + rank)             # per-rank sampling / DropPath randomness
 
+    comm = {}
+
     def step():
         reducer.zero_grad()
         losses = model.forward_train(**batch)
         loss, log_vars = model.parse_losses(losses)
+        reducer.mark_backward_start()
         loss.backward()
+        comm["backward_issued_ms"] = round(reducer._now() * 1e3, 3)     # host time: every backward kernel has been issued
         reducer.finish()
+        comm["finish_ms"] = round(reducer._now() * 1e3, 3)
+        comm["buckets"] = [dict(bucket=b, bytes=n, issued_ms=round(t0_ * 1e3, 3), done_ms=None if t1_ is None else round(t1_ * 1e3, 3))
+                           for b, t0_, t1_, n in reducer.timeline]
         optim.step()                            # AdamW + bf16 shadow refresh, one HIP launch
         return log_vars
 
@@ -281,7 +333,7 @@ def main():
         raise SystemExit(f"non-finite loss in the timed region: {logs}")
 
     sync_check = None
-    if args.check_sync and world > 1:
+    if world > 1 and not args.no_check_sync:
         # replicas start identical (broadcast) and apply the same averaged gradients: any rank-dependent gradient that
         # slipped past the all-reduce (a missed bucket, a kernel writing after its bucket was launched) shows up here
         with torch.no_grad():
@@ -310,6 +362,9 @@ def main():
                        "global_batch": gb, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
             "losses": {k: round(v, 4) for k, v in logs.items()},
             "roofline": roof, "roofline_mfma_kernels": roof_gemm, "cpu_baseline": cpu, "sync_check": sync_check,
+            # host-side timeline of the last step's gradient exchange, relative to the start of backward (N > 1 only has
+            # entries): a bucket issued before backward_issued_ms overlapped the rest of backward
+            "comm_timeline": comm if world > 1 else None,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -150,12 +150,9 @@ int fpn_upsample_add_bwd(const void* dfine, void* dcoarse, int N, int C, int Hf,
  *   bias (Cout) f32 or NULL;  y (N,H,W,Cout) bf16 = conv(x,w)+bias, ReLU if relu != 0.
  *   Cin % 64 == 0, Cout % 4 == 0.  The data gradient is the same call on dy with the 180-degree rotated,
  *   in/out-transposed weight.
- * gemm_nt_bf16: c (M,N) = a (M,K) w(N,K)^T + bias, same core with a plain A loader (K % 64 == 0).
  * ---------------------------------------------------------------------------------- */
 int conv3x3_nhwc_bf16(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin,
                       int Cout, int relu, void* stream);
-int gemm_nt_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int relu,
-                 void* stream);
 
 /* Weight gradients (contraction over the token / pixel index, split over the grid, fp32 atomics):
  *   wgrad_linear_bf16      : dw (N1,N2) f32 += dy (T,N1)^T x (T,N2)   -- autograd of nn.Linear

@@ -26,17 +26,6 @@ struct ConvGeom { int N, H, W, Cin; };
 // ---- A-operand loaders: element offset of 16-byte piece `piece` (0..7) of row `m` for K-tile `kt`, or -1 when
 // the piece is zero padding.  (The load itself is done by the kernel from a CLAMPED address and masked by value:
 // selecting between a global pointer and a local zero makes hipcc emit flat loads with a full wait after each.)
-struct PlainA {
-    const bf16* a; int64_t M; int K;
-    __device__ __forceinline__ void prep(int64_t m, int64_t& base, int& y, int& x) const { base = m < M ? m * K : -1; y = x = 0; }
-    __device__ __forceinline__ int64_t offset(int64_t base, int y, int x, int kt, int piece) const {
-        return base < 0 ? -1 : base + kt * BK + piece * 8;
-    }
-    // K-tile kt = wave-uniform element offset from the row's base + the "tap" whose validity bit applies
-    __device__ __forceinline__ unsigned tapmask(int64_t base, int y, int x) const { return base < 0 ? 0u : 1u; }
-    __device__ __forceinline__ void kinfo(int kt, int64_t& koff, int& tap) const { koff = (int64_t)kt * BK; tap = 0; }
-};
-
 struct ConvA {
     const bf16* a; int64_t M; ConvGeom g; int cpt;   // cpt = Cin / BK (K-tiles per filter tap)
     __device__ __forceinline__ void prep(int64_t m, int64_t& base, int& y, int& x) const {
@@ -344,11 +333,3 @@ extern "C" int conv3x3_nhwc_bf16(const void* x, const void* w, const float* bias
     return gemm_launch(A, (const bf16*)w, bias, (bf16*)y, M, Cout, 9 * Cin, relu, (hipStream_t)stream);
 }
 
-// a (M,K) bf16 row-major; w (N,K) bf16 (nn.Linear weight layout); c (M,N) bf16 = a w^T + bias.
-extern "C" int gemm_nt_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int relu,
-                            void* stream) {
-    if (!a || !w || !c || M <= 0 || N <= 0 || K <= 0) return SWIN_ERR_BAD_ARG;
-    if (K % BK != 0 || N % 4 != 0) return SWIN_ERR_UNSUPPORTED;
-    PlainA A{(const bf16*)a, M, K};
-    return gemm_launch(A, (const bf16*)w, bias, (bf16*)c, M, N, K, relu, (hipStream_t)stream);
-}

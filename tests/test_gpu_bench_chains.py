@@ -295,3 +295,31 @@ def test_window_attention_bwd_stage1_full(pkg, shift):
             _close(q1.grad, q0.grad, _bf16_tol(q0.grad, 4), "dqkv bf16")
             _close(t1.grad, t0.grad, 2e-2 * float(t0.grad.abs().max()), "dtable bf16")
             _close(b1.grad, b0.grad, 2e-2 * float(b0.grad.abs().max()) + 1e-3, "dbias(pad) bf16")
+
+
+def test_fpn_bf16_hip_conv_vs_oracle(pkg):
+    """FPN (fpn.py:169-221) in the configuration of the swin configs (in_channels 96..768 -> 256, five outputs) on the bf16
+    path: 1x1 laterals as GEMMs, upsample+add kernel, the HAND-WRITTEN MFMA 3x3 conv (not torch's conv, which the fp32 golden test
+    of the reference fixture runs) -- against the pinned fp32 oracle on the same bf16-rounded inputs and parameters."""
+    from oracle import fpn_oracle
+    p = fpn_oracle.make_params((96, 192, 384, 768), 256, seed=3)
+    p = {k: v.bfloat16().float() for k, v in p.items()}
+    m = pkg.fpn.FPN([96, 192, 384, 768], 256, 5, compute_dtype=torch.bfloat16)
+    m.init_weights()
+    m.load_state_dict(p, strict=True)
+    m.cuda()
+    g = torch.Generator().manual_seed(4)
+    shapes = [(50, 80), (25, 40), (13, 20), (7, 10)]
+    xs = [torch.randn(2, c, h, w, generator=g).bfloat16().float() for c, (h, w) in zip((96, 192, 384, 768), shapes)]
+    x0 = [x.clone().requires_grad_(True) for x in xs]
+    ref = fpn_oracle.fpn_forward(tuple(x0), p, 5)
+    ws = [torch.randn(o.shape, generator=g) for o in ref]
+    sum((o * w).sum() for o, w in zip(ref, ws)).backward()
+    x1 = [x.cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in xs]
+    outs = m(tuple(x1))
+    assert len(outs) == 5 and all(o.dtype == torch.bfloat16 for o in outs)
+    sum((o.float() * w.cuda()).sum() for o, w in zip(outs, ws)).backward()
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        _close(o, r, _bf16_tol(r, 4), f"out{i}")              # two chained bf16 roundings (lateral sum, conv output)
+    for i in range(4):
+        _close(x1[i].grad, x0[i].grad, _bf16_tol(x0[i].grad, 6), f"gin{i}")

@@ -73,20 +73,8 @@ def conv():
         print(f"conv3x3 {N}x{H}x{W}x256->256: {med:8.1f} us  {fl / med / 1e6:7.1f} TFLOP/s")
 
 
-def gemm():
-    for (M, N, K) in [(128000, 256, 2304), (32000, 256, 2304), (128000, 384, 128), (128000, 256, 256)]:
-        a = torch.randn(M, K, device="cuda").bfloat16()
-        w = torch.randn(N, K, device="cuda").bfloat16() * 0.02
-        b = torch.zeros(N, device="cuda")
-        c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        med, _ = timeit(lambda: Fn.call("gemm_nt_bf16", Fn._p(a), Fn._p(w), Fn._p(b), Fn._p(c), M, N, K, 0, Fn._s()))
-        medt, _ = timeit(lambda: torch.nn.functional.linear(a, w))
-        fl = 2.0 * M * N * K
-        print(f"gemm_nt {M}x{N}x{K}: mine {med:8.1f} us {fl / med / 1e6:7.1f} TF   hipBLASLt {medt:8.1f} us {fl / medt / 1e6:7.1f} TF")
-
-
 def gemmbb():
-    """forward (x W^T + b) and data-gradient (dy W) GEMMs of the backbone linears: library vs gemm_nt_bf16"""
+    """forward (x W^T + b) and data-gradient (dy W) GEMMs of the backbone linears on the library (hipBLASLt)"""
     for (T, C) in [(128000, 96), (32000, 192), (8000, 384), (2000, 768)]:
         for (N, K, name) in [(3 * C, C, "qkv"), (C, C, "proj"), (4 * C, C, "fc1"), (C, 4 * C, "fc2")]:
             a = torch.randn(T, K, device="cuda").bfloat16()
@@ -94,14 +82,11 @@ def gemmbb():
             bf = torch.zeros(N, device="cuda"); bb = bf.bfloat16()
             c = torch.empty(T, N, device="cuda", dtype=torch.bfloat16)
             dy = torch.randn(T, N, device="cuda").bfloat16()
-            mine = float("nan")
-            if N % 64 == 0 and K % 64 == 0:
-                mine, _ = timeit(lambda: Fn.call("gemm_nt_bf16", Fn._p(a), Fn._p(w), Fn._p(bf), Fn._p(c), T, N, K, 0, Fn._s()))
             lib, _ = timeit(lambda: torch.nn.functional.linear(a, w, bb))
             dg, _ = timeit(lambda: dy @ w)
             byts = 2.0 * (T * K + T * N)
             print(f"T={T:6d} {name:5s} N={N:5d} K={K:5d}: fwd lib {lib:6.1f} us ({byts / lib / 1e3:6.0f} GB/s, {2.0 * T * N * K / lib / 1e6:5.0f} TF)"
-                  f"  mine {mine:6.1f} us   dgrad lib {dg:6.1f} us")
+                  f"   dgrad lib {dg:6.1f} us")
 
 
 def wgrad():

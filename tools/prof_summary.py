@@ -36,7 +36,7 @@ tot = cnt = 0
 for r in rows:
     ns = float(r['TotalDurationNs']); k = cat(r['Name'])
     d[k][0] += ns; d[k][1] += int(r['Calls']); tot += ns; cnt += int(r['Calls'])
-print("# note: bench.py's live roofline measurements (30 attention + 3 x 23 GEMM-class launches per run) are inside this trace")
+print("# note: bench.py's live roofline measurements (35 attention + 5 x 23 GEMM-class launches per run) are inside this trace")
 print(f"{'category':26s} {'ms/step':>8s} {'launches/step':>14s}")
 for k, v in sorted(d.items(), key=lambda kv: -kv[1][0]):
     print(f"{k:26s} {v[0] / steps / 1e6:8.3f} {v[1] / steps:14.1f}")
