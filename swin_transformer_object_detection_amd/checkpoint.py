@@ -49,6 +49,8 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=No
     if mismatched and not strict:
         sd = {k: v for k, v in sd.items() if k not in mismatched}
     missing, unexpected = model.load_state_dict(sd, strict=strict)
+    from . import mixed
+    mixed.refresh_all()            # bf16 shadows / constants / re-laid-out weights of a live training setup follow the new masters
     if logger is not None and (missing or unexpected or mismatched):
         logger.warning(f'missing keys: {missing}; unexpected keys: {unexpected}; size mismatch (skipped): {mismatched}')
     return ckpt

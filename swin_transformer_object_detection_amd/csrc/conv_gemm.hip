@@ -283,12 +283,14 @@ template <typename ALoader, bool RELU, int WM, int NBUF>
 static int gemm_launch_wm(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, hipStream_t s) {
     constexpr int TM = 64 * WM;
     const size_t lds_bytes = NBUF * (size_t)(TM + BN) * 8 * sizeof(uint4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};                           // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    if (!attr_set[dev]) {
         if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<ALoader, RELU, WM, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess)
             return SWIN_ERR_LAUNCH;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     int mtiles = (int)((M + TM - 1) / TM), ntiles = (Nn + BN - 1) / BN;
     gemm_bf16_kernel<ALoader, RELU, WM, NBUF><<<mtiles * ntiles, 128 * WM, lds_bytes, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles);

@@ -20,18 +20,21 @@ struct Plan {
     bool ok = false;
 };
 struct Key {
-    int64_t M; int N, K, layout, bias;
-    bool operator==(const Key& o) const { return M == o.M && N == o.N && K == o.K && layout == o.layout && bias == o.bias; }
+    int64_t M; int N, K, layout, bias, dev;                // plans (and their tuned algorithm) belong to a device
+    bool operator==(const Key& o) const {
+        return M == o.M && N == o.N && K == o.K && layout == o.layout && bias == o.bias && dev == o.dev;
+    }
 };
 struct KeyHash {
     size_t operator()(const Key& k) const {
         size_t h = (size_t)k.M * 1000003u;
-        h ^= (size_t)k.N * 7919u + ((size_t)k.K << 20) + (size_t)k.layout * 31u + (size_t)k.bias;
+        h ^= (size_t)k.N * 7919u + ((size_t)k.K << 20) + (size_t)k.layout * 31u + (size_t)k.bias + (size_t)k.dev * 131071u;
         return h;
     }
 };
 std::mutex g_mu;
-hipblasLtHandle_t g_handle = nullptr;
+hipblasLtHandle_t g_handles[16] = {};                    // one per device
+thread_local hipblasLtHandle_t g_handle = nullptr;       // the current call's handle (set by get_plan)
 std::unordered_map<Key, Plan, KeyHash> g_plans;
 const size_t kWorkspace = 32u << 20;
 
@@ -69,8 +72,11 @@ static float time_algo(Plan& p, const hipblasLtMatmulHeuristicResult_t& h, const
 Plan* get_plan(int64_t M, int N, int K, int layout, int bias, const void* a = nullptr, const void* b = nullptr,
                const void* bias_ptr = nullptr, void* c = nullptr, void* workspace = nullptr, hipStream_t stream = nullptr) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return nullptr;
-    Key key{M, N, K, layout, bias};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!g_handles[dev] && hipblasLtCreate(&g_handles[dev]) != HIPBLAS_STATUS_SUCCESS) return nullptr;
+    g_handle = g_handles[dev];
+    Key key{M, N, K, layout, bias, dev};
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second.ok ? &it->second : nullptr;
     Plan& p = g_plans[key];

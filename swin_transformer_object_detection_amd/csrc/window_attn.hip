@@ -1042,12 +1042,14 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
     if (dtype == SWIN_BF16) {
         if (!workspace) return SWIN_ERR_BAD_ARG;
         int blocks = attn_bwd_blocks(n_tasks, nH);
-        static bool attr_set = false;
+        static bool attr_set[16] = {};                       // per device: the attribute belongs to the device's code object
         size_t shm = 4 * sizeof(BwdLds);
-        if (!attr_set) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+        if (!attr_set[dev]) {
             if (hipFuncSetAttribute((const void*)win_attn_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)shm) != hipSuccess) return SWIN_ERR_LAUNCH;
-            attr_set = true;
+            attr_set[dev] = true;
         }
         win_attn_bwd_bf16_kernel<<<blocks, 256, shm, s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
                                                           (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks);

@@ -128,6 +128,21 @@ def const(p, dtype):
     return c if c is not None and c.dtype == dtype else None
 
 
+_LIVE = []            # weak references to the ShadowParams objects alive (refresh_all)
+
+
+def refresh_all():
+    """Re-copy every live ShadowParams' bf16 shadows / constants from the fp32 masters and drop the derived per-step tensors:
+    for code that rewrites the masters behind the optimizer's back (checkpoint loading after the shadows exist)."""
+    for r in list(_LIVE):
+        sp = r()
+        if sp is None:
+            _LIVE.remove(r)
+        else:
+            sp.refresh()
+    _DERIVED.clear()
+
+
 class ShadowParams:
     def __init__(self, module, dtype=torch.bfloat16, min_numel=1024):
         """Shadows are created for the ``weight`` (>= min_numel elements) and ``bias`` of Linear / Conv2d /
@@ -166,6 +181,8 @@ class ShadowParams:
             self.consts.append(v)
             _CONST[id(p)] = v
             off += pad(p.numel())
+        import weakref
+        _LIVE.append(weakref.ref(self))
         self.refresh()
 
     @torch.no_grad()

@@ -65,6 +65,7 @@ class FusedAdamW:
                 chunks += [(si, c) for c in range((n + chunk - 1) // chunk)]
         if not segs:
             self._tables = (None, None, 0)
+            self._sig = self._signature()
             return
         seg_t = torch.frombuffer(bytearray(b"".join(segs)), dtype=torch.uint8).to(dev)
         ck_t = torch.tensor(chunks, dtype=torch.int32).to(dev)

@@ -415,15 +415,23 @@ def test_two_rank_replicas_stay_identical(workload):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
     env = dict(os.environ, BENCH_REHEARSAL_GLOO="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--check-sync", "--workload", workload]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--workload", workload]          # the replica check runs by default on N > 1
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["sync_check"].startswith("replicas bit-identical")
+    tl = out["comm_timeline"]
+    assert [b["bucket"] for b in tl["buckets"]] == sorted(b["bucket"] for b in tl["buckets"]) and len(tl["buckets"]) >= 2
+    assert all(b["done_ms"] is not None and b["done_ms"] >= b["issued_ms"] for b in tl["buckets"])
 
 
 @pytest.mark.gpu
