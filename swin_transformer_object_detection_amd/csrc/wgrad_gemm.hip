@@ -77,10 +77,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t0, int col0, in
 template <typename XLoader, int WKG>
 __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(const bf16* __restrict__ dy, XLoader X, float* __restrict__ dw,
                                                          float* __restrict__ dbias, int64_t T, int N1, int N2,
-                                                         int64_t t_per_split, int mode, float* __restrict__ slab) {
+                                                         int64_t t_per_split, int mode, float* __restrict__ slab, int g2, int g1,
+                                                         int splits) {
     extern __shared__ __attribute__((aligned(16))) bf16 lds_all[];         // [WKG][dY|X][WT * WROW]: 40 KB per group
-    const int n1_0 = blockIdx.y * WN, n2_0 = blockIdx.x * WN;
-    const int64_t t_begin = (int64_t)blockIdx.z * t_per_split;
+    // XCD-aware block -> (tile, split) map.  Hardware deals consecutive block ids round-robin over the 8 XCDs (private L2s).
+    // Every output tile of one split reads the SAME token range, so a split's tiles belong on ONE XCD: there its dY / X rows
+    // are fetched into that L2 once and hit by the other tiles.  The plain (x, y, z) order put the tiles of a split on all
+    // eight XCDs: each L2 fetched nearly every operand byte (PMC, round 2: 43 % L2 hit rate, 3-6x the unique bytes fetched).
+    int bx, by, bz;
+    if (g2 > 0) {
+        const int L = blockIdx.x, xcd = L & 7, q = L >> 3, tiles = g1 * g2;
+        bz = (q / tiles) * 8 + xcd;
+        if (bz >= splits) return;
+        const int tile = q % tiles;
+        bx = tile % g2; by = tile / g2;
+    } else { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; }
+    const int n1_0 = by * WN, n2_0 = bx * WN;
+    const int64_t t_begin = (int64_t)bz * t_per_split;
     const int64_t t_end = min(T, t_begin + t_per_split);
     const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     bf16* ldsA = lds_all + (size_t)grp * 2 * WT * WROW;
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
     // bias gradient = column sums of dY: taken by the n2-tile-0 blocks from the pieces they stage anyway
-    const bool do_bias = dbias != nullptr && blockIdx.x == 0;
+    const bool do_bias = dbias != nullptr && bx == 0;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto bias_acc = [&]() {
 #pragma unroll
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
     // into dw (float atomics run at ~1.3 TB/s chip-wide against ~6 TB/s for stores: blocks x 64 KB of atomics were 20 of the
     // 38 us of a stage-3 Linear weight gradient and 33 of 275 us of the P2 conv weight gradient).
     if (mode == 2) {
-        float* tile = slab + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (WN * WN);
+        float* tile = slab + (((int64_t)bz * (g2 > 0 ? g1 : (int)gridDim.y) + by) * (g2 > 0 ? g2 : (int)gridDim.x) + bx) * (WN * WN);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -319,6 +332,17 @@ static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, i
     if (splits > max_splits) splits = (int)max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
+    static const int xcd_map = getenv("SWIN_WGRAD_XCD") ? atoi(getenv("SWIN_WGRAD_XCD")) : 1;           // development A/B
+    // the XCD-aware map below keeps a split's tiles on one XCD: it needs the splits to spread evenly over the 8 XCDs
+    // measured (profiles/r02_wgrad_modes.txt): +7 % on the P2 conv weight gradient (36 tiles x 16 splits), neutral to negative on the
+    // Linear shapes (few tiles or short t ranges: there balance over the CUs matters more than L2 reuse) -> conv, long t only
+    bool use_xcd = xcd_map && XLoader::kBlocksManyTiles == 512 && T >= 24000 && g1 * g2 > 1 && splits >= 8;
+    if (use_xcd) {
+        int s8 = (splits + 4) / 8 * 8;
+        if (s8 < 8) s8 = 8;
+        if (s8 > max_splits) s8 = (int)(max_splits / 8 * 8);
+        if (s8 >= 8) splits = s8; else use_xcd = false;
+    }
     int64_t per = ((stages + splits - 1) / splits);
     per = ((per + WKG - 1) / WKG) * WKG * WT;
     splits = (int)((T + per - 1) / per);
@@ -335,7 +359,12 @@ static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, i
     if (force_mode == 2 && dev >= 0 && dev < 16 && g_scratch[dev] && g_scratch_bytes[dev] >= slab_bytes) mode = 2;
     if (force_mode == 0 && splits == 1) mode = 0;
     float* slab = mode == 2 ? (float*)g_scratch[dev] : nullptr;
-    wgrad_kernel<XLoader, WKG><<<grid, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, mode, slab);
+    if (use_xcd && splits % 8 == 0) {
+        const unsigned nblk = 8u * (unsigned)(g1 * g2) * (unsigned)((splits + 7) / 8);
+        wgrad_kernel<XLoader, WKG><<<nblk, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, mode, slab, g2, g1, splits);
+    } else {
+        wgrad_kernel<XLoader, WKG><<<grid, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, mode, slab, 0, g1, splits);
+    }
     if (mode == 2) wgrad_reduce_kernel<<<dim3(g2, g1, 8), 256, 0, s>>>(slab, dw, N1, N2, splits);
     return swin_launch_status();
 }
