@@ -141,6 +141,12 @@ int fpn_upsample_add_fwd(void* fine, const void* coarse, int N, int C, int Hf, i
 /* dcoarse += sum of dfine over each coarse cell's footprint */
 int fpn_upsample_add_bwd(const void* dfine, void* dcoarse, int N, int C, int Hf, int Wf, int Hc, int Wc,
                          int channels_last, int dtype, void* stream);
+/* out-of-place forms (round 2): out = fine + nearest_upsample(coarse) leaves `fine` untouched (the caller needs no clone);
+ * the backward writes dcoarse from scratch (the caller needs no memset). */
+int fpn_upsample_add_out_fwd(const void* fine, const void* coarse, void* out, int N, int C, int Hf, int Wf, int Hc, int Wc,
+                             int channels_last, int dtype, void* stream);
+int fpn_upsample_add_out_bwd(const void* dfine, void* dcoarse, int N, int C, int Hf, int Wf, int Hc, int Wc,
+                             int channels_last, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16 MFMA implicit-GEMM convolution, 3x3 / pad 1 / stride 1, channels-last.  Replaces the conv
@@ -338,6 +344,11 @@ int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1, const void
                       int C, void* stream);
 int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, const float* b1, const void* w2, void* dx, void* h,
                       void* dhpre, int64_t T, int C, void* stream);
+
+/* det_map_roi_levels: SingleRoIExtractor.map_roi_levels (single_level_roi_extractor.py:32-51): rois (K,5) f32 -> out (K) i32 =
+ *   clamp(floor(log2(sqrt(w h) / finest_scale + 1e-6)), 0, num_levels-1); rows with valid[k] == 0 (valid may be NULL) get -1. */
+int det_map_roi_levels(const float* rois, const uint8_t* valid, int64_t K, int num_levels, float finest_scale, int* out,
+                       void* stream);
 
 /* det_rpn_topk_decode: RPNHead._get_bboxes proposal selection (rpn_head.py:126-187) for all images and levels in one
  *   launch -- sigmoid, per-level top-`nms_pre` by (score descending, anchor index ascending: what a stable sort keeps,

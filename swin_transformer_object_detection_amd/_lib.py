@@ -30,6 +30,8 @@ SIGNATURES = {
     "swin_patch_im2row": [_p, _p, _i, _i, _i, _i, _p],
     "fpn_upsample_add_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "fpn_upsample_add_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "fpn_upsample_add_out_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "fpn_upsample_add_out_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "roi_align_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _p],
     "roi_align_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p],
     "conv3x3_nhwc_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -70,6 +72,7 @@ SIGNATURES = {
     "det_rpn_flatten_bwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
     "swin_mlp_fwd_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i, _p],
     "swin_mlp_bwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p],
+    "det_map_roi_levels": [_p, _p, _i64, _i, _f, _p, _p],
     "det_rpn_topk_decode_workspace_bytes": [_i64, _i64],
     "det_rpn_topk_decode": [_p, _p, _p, _p, _i, _i64, _i, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p],
     "det_paste_masks": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p],

@@ -406,6 +406,28 @@ extern "C" int det_bbox_targets(const float* bboxes, const int64_t* inds, const 
     return swin_launch_status();
 }
 
+// SingleRoIExtractor.map_roi_levels (single_level_roi_extractor.py:32-51) in one launch: scale = sqrt(w h),
+// lvl = clamp(floor(log2(scale / finest_scale + 1e-6)), 0, L-1) in fp32 as the reference computes it; rows whose `valid`
+// byte is 0 get -1 (the multi-level RoIAlign skips them).  Replaces ten elementwise launches per call.
+__global__ __launch_bounds__(256) void map_roi_levels_kernel(const float* __restrict__ rois, const uint8_t* __restrict__ valid, int64_t K,
+                                                             int num_levels, float finest_scale, int* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= K) return;
+    const float* r = rois + i * 5;
+    const float scale = sqrtf((r[3] - r[1]) * (r[4] - r[2]));
+    float lv = floorf(log2f(scale / finest_scale + 1e-6f));
+    lv = fminf(fmaxf(lv, 0.f), (float)(num_levels - 1));
+    out[i] = (valid && !valid[i]) ? -1 : (int)lv;
+}
+
+extern "C" int det_map_roi_levels(const float* rois, const uint8_t* valid, int64_t K, int num_levels, float finest_scale, int* out,
+                                  void* stream) {
+    if (K == 0) return SWIN_OK;
+    if (!rois || !out || K < 0 || num_levels <= 0 || finest_scale <= 0.f) return SWIN_ERR_BAD_ARG;
+    map_roi_levels_kernel<<<(unsigned)((K + 255) / 256), 256, 0, (hipStream_t)stream>>>(rois, valid, K, num_levels, finest_scale, out);
+    return swin_launch_status();
+}
+
 // DeltaXYWHBBoxCoder.decode: rois, deltas (n,4) f32 -> out (n,4); clipped to [0,max_w] x [0,max_h] when max_w > 0.
 extern "C" int det_delta2bbox(const float* rois, const float* deltas, int64_t n, const float* means, const float* stds,
                               float max_h, float max_w, float wh_ratio_clip, float* out, void* stream) {

@@ -221,7 +221,7 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
 
 // channels-last memory (N,H,W,C): one thread per 16-byte channel vector
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_add_nhwc_kernel(T* __restrict__ fine, const T* __restrict__ coarse, int N, int C,
+__global__ __launch_bounds__(256) void upsample_add_nhwc_kernel(const T* fine, T* out, const T* __restrict__ coarse, int N, int C,
                                                                 int Hf, int Wf, int Hc, int Wc, float sh, float sw) {
     constexpr int VEC = Vec16<T>::N;
     const int vpc = C / VEC;
@@ -238,13 +238,13 @@ __global__ __launch_bounds__(256) void upsample_add_nhwc_kernel(T* __restrict__ 
         c.load(coarse + ((((int64_t)b * Hc + ys) * Wc + xs) * vpc + cv) * VEC);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) f.set(e, f.get(e) + c.get(e));
-        f.store(fine + i * VEC);
+        f.store(out + i * VEC);
     }
 }
 
 // contiguous NCHW memory: one thread per element
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_add_nchw_kernel(T* __restrict__ fine, const T* __restrict__ coarse, int64_t NC,
+__global__ __launch_bounds__(256) void upsample_add_nchw_kernel(const T* fine, T* out, const T* __restrict__ coarse, int64_t NC,
                                                                 int Hf, int Wf, int Hc, int Wc, float sh, float sw) {
     int64_t n = NC * Hf * Wf;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void upsample_add_nchw_kernel(T* __restrict__ 
         int y = (int)(t % Hf);
         int64_t nc = t / Hf;
         int ys = nearest_src(y, sh, Hc), xs = nearest_src(x, sw, Wc);
-        Elt<T>::st(fine + i, Elt<T>::ld(fine + i) + Elt<T>::ld(coarse + (nc * Hc + ys) * Wc + xs));
+        Elt<T>::st(out + i, Elt<T>::ld(fine + i) + Elt<T>::ld(coarse + (nc * Hc + ys) * Wc + xs));
     }
 }
 
@@ -267,7 +267,7 @@ __device__ __forceinline__ void footprint(int c, float scale, int fine_size, int
 
 template <typename T, bool NHWC>
 __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const T* __restrict__ dfine, T* __restrict__ dcoarse, int N, int C,
-                                                               int Hf, int Wf, int Hc, int Wc, float sh, float sw) {
+                                                               int Hf, int Wf, int Hc, int Wc, float sh, float sw, int fresh) {
     constexpr int VEC = NHWC ? Vec16<T>::N : 1;
     const int vpc = NHWC ? C / VEC : 1;
     int64_t n = NHWC ? (int64_t)N * Hc * Wc * vpc : (int64_t)N * C * Hc * Wc;
@@ -284,12 +284,14 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const T* __restri
         float acc[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-        if (NHWC) {
-            Vec16<T> cur; cur.load(dcoarse + i * Vec16<T>::N);
+        if (!fresh) {                      // fresh: dcoarse is an uninitialised output, nothing to add to
+            if (NHWC) {
+                Vec16<T> cur; cur.load(dcoarse + i * Vec16<T>::N);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = cur.get(e);
-        } else {
-            acc[0] = Elt<T>::ld(dcoarse + i);
+                for (int e = 0; e < VEC; ++e) acc[e] = cur.get(e);
+            } else {
+                acc[0] = Elt<T>::ld(dcoarse + i);
+            }
         }
         for (int y = y0; y < y1; ++y) {
             if (nearest_src(y, sh, Hc) != yc) continue;
@@ -317,27 +319,28 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const T* __restri
 
 template <typename T>
 static int upsample_launch(void* fine, const void* coarse, int N, int C, int Hf, int Wf, int Hc, int Wc,
-                           int channels_last, bool bwd, hipStream_t s) {
+                           int channels_last, bool bwd, hipStream_t s, void* out = nullptr, bool fresh = false) {
+    if (!out) out = fine;
     float sh = (float)Hc / (float)Hf, sw = (float)Wc / (float)Wf;
     if (channels_last && C % Vec16<T>::N) return SWIN_ERR_UNSUPPORTED;
     if (!bwd) {
         if (channels_last) {
             int64_t n = (int64_t)N * Hf * Wf * (C / Vec16<T>::N);
-            upsample_add_nhwc_kernel<T><<<ew_blocks(n), 256, 0, s>>>((T*)fine, (const T*)coarse, N, C, Hf, Wf, Hc, Wc, sh, sw);
+            upsample_add_nhwc_kernel<T><<<ew_blocks(n), 256, 0, s>>>((const T*)fine, (T*)out, (const T*)coarse, N, C, Hf, Wf, Hc, Wc, sh, sw);
         } else {
             int64_t n = (int64_t)N * C * Hf * Wf;
-            upsample_add_nchw_kernel<T><<<ew_blocks(n), 256, 0, s>>>((T*)fine, (const T*)coarse, (int64_t)N * C, Hf, Wf, Hc, Wc,
-                                                                    sh, sw);
+            upsample_add_nchw_kernel<T><<<ew_blocks(n), 256, 0, s>>>((const T*)fine, (T*)out, (const T*)coarse, (int64_t)N * C, Hf, Wf, Hc,
+                                                                    Wc, sh, sw);
         }
     } else {
         // here `fine` is dfine (read) and `coarse` is dcoarse (read-modify-write)
         if (channels_last) {
             int64_t n = (int64_t)N * Hc * Wc * (C / Vec16<T>::N);
-            upsample_add_bwd_kernel<T, true><<<ew_blocks(n), 256, 0, s>>>((const T*)fine, (T*)coarse, N, C, Hf, Wf, Hc, Wc, sh, sw);
+            upsample_add_bwd_kernel<T, true><<<ew_blocks(n), 256, 0, s>>>((const T*)fine, (T*)coarse, N, C, Hf, Wf, Hc, Wc, sh, sw, fresh ? 1 : 0);
         } else {
             int64_t n = (int64_t)N * C * Hc * Wc;
             upsample_add_bwd_kernel<T, false><<<ew_blocks(n), 256, 0, s>>>((const T*)fine, (T*)coarse, N, C, Hf, Wf, Hc, Wc, sh,
-                                                                          sw);
+                                                                          sw, fresh ? 1 : 0);
         }
     }
     return swin_launch_status();
@@ -348,6 +351,23 @@ extern "C" int fpn_upsample_add_fwd(void* fine, const void* coarse, int N, int C
     if (!fine || !coarse || N <= 0 || C <= 0 || Hf <= 0 || Wf <= 0 || Hc <= 0 || Wc <= 0) return SWIN_ERR_BAD_ARG;
     if (dtype == SWIN_BF16) return upsample_launch<bf16>(fine, coarse, N, C, Hf, Wf, Hc, Wc, channels_last, false, (hipStream_t)stream);
     if (dtype == SWIN_F32) return upsample_launch<float>(fine, coarse, N, C, Hf, Wf, Hc, Wc, channels_last, false, (hipStream_t)stream);
+    return SWIN_ERR_UNSUPPORTED;
+}
+
+// out = fine + nearest_upsample(coarse) without touching `fine` (no clone in the caller); dcoarse = footprint sums of dfine
+// written from scratch (no memset in the caller).
+extern "C" int fpn_upsample_add_out_fwd(const void* fine, const void* coarse, void* out, int N, int C, int Hf, int Wf, int Hc, int Wc,
+                                        int channels_last, int dtype, void* stream) {
+    if (!fine || !coarse || !out || N <= 0 || C <= 0 || Hf <= 0 || Wf <= 0 || Hc <= 0 || Wc <= 0) return SWIN_ERR_BAD_ARG;
+    if (dtype == SWIN_BF16) return upsample_launch<bf16>((void*)fine, coarse, N, C, Hf, Wf, Hc, Wc, channels_last, false, (hipStream_t)stream, out);
+    if (dtype == SWIN_F32) return upsample_launch<float>((void*)fine, coarse, N, C, Hf, Wf, Hc, Wc, channels_last, false, (hipStream_t)stream, out);
+    return SWIN_ERR_UNSUPPORTED;
+}
+extern "C" int fpn_upsample_add_out_bwd(const void* dfine, void* dcoarse, int N, int C, int Hf, int Wf, int Hc, int Wc,
+                                        int channels_last, int dtype, void* stream) {
+    if (!dfine || !dcoarse || N <= 0 || C <= 0 || Hf <= 0 || Wf <= 0 || Hc <= 0 || Wc <= 0) return SWIN_ERR_BAD_ARG;
+    if (dtype == SWIN_BF16) return upsample_launch<bf16>((void*)dfine, dcoarse, N, C, Hf, Wf, Hc, Wc, channels_last, true, (hipStream_t)stream, nullptr, true);
+    if (dtype == SWIN_F32) return upsample_launch<float>((void*)dfine, dcoarse, N, C, Hf, Wf, Hc, Wc, channels_last, true, (hipStream_t)stream, nullptr, true);
     return SWIN_ERR_UNSUPPORTED;
 }
 

@@ -84,15 +84,25 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     return b
 
 
+_ROI_IDX = {}        # (sizes, device) -> constant batch-index column: fixed-size samples repeat the same sizes every step
+
+
 def bbox2roi(bbox_list):
-    """mmdet/core/bbox/transforms.py:69-77."""
-    out = []
-    for i, b in enumerate(bbox_list):
-        if b.size(0) > 0:
-            out.append(torch.cat([b.new_full((b.size(0), 1), i), b[:, :4]], dim=-1))
-        else:
-            out.append(b.new_zeros((0, 5)))
-    return torch.cat(out, 0)
+    """mmdet/core/bbox/transforms.py:69-77: rois = [batch index as float, x1, y1, x2, y2], images concatenated in order.
+    The index column depends only on the per-image counts, which are fixed in training (512 / 128 slots per image): it is built
+    once and cached, so a call is two concatenations instead of two per image plus one."""
+    if not bbox_list:
+        return torch.zeros((0, 5))
+    sizes = tuple(int(b.size(0)) for b in bbox_list)
+    b0 = bbox_list[0]
+    key = (sizes, b0.device, b0.dtype)
+    col = _ROI_IDX.get(key)
+    if col is None:
+        col = torch.cat([torch.full((n, 1), float(i)) for i, n in enumerate(sizes)], 0).to(device=b0.device, dtype=b0.dtype)
+        if len(_ROI_IDX) < 64:
+            _ROI_IDX[key] = col
+    boxes = torch.cat([b[:, :4] for b in bbox_list], 0) if len(bbox_list) > 1 else b0[:, :4]
+    return torch.cat([col, boxes], dim=1)
 
 
 class AnchorGenerator:
@@ -374,6 +384,58 @@ def bbox2result(bboxes, labels, num_classes):
 # ------------------------------------------------------------------------------------------
 # RPN
 # ------------------------------------------------------------------------------------------
+class _RpnHeads(torch.autograd.Function):
+    """rpn_cls and rpn_reg (rpn_head.py:41-47) as ONE GEMM per level on a concatenated bf16 weight, with the weight / bias
+    gradients of ALL five levels accumulated in one fp32 step buffer by the split-T kernel and split into the two layers'
+    gradients once, after the last level's backward.  (Through plain autograd every level cost two zero fills, two casts and the
+    running sums of the concatenation's backward: ~30 small launches per step.)
+    Inputs: tokens (T,C) bf16; w_cat (5A+pad, C) / b_cat bf16 constants; head; then the four real leaves (bf16 shadows or fp32
+    masters) only so that autograd routes gradients to them."""
+
+    @staticmethod
+    def forward(ctx, tok, w_cat, b_cat, head, wc_leaf, wr_leaf, bc_leaf, br_leaf):
+        from .ops.functional import gemm_bf16
+        ctx.save_for_backward(tok, w_cat)
+        ctx.head = head
+        ctx.dts = (wc_leaf.dtype, wr_leaf.dtype, bc_leaf.dtype, br_leaf.dtype)
+        ctx.counted = any(ctx.needs_input_grad)
+        if ctx.counted:
+            mixed.use_begin(head.rpn_cls.weight)
+        return gemm_bf16(tok.contiguous(), w_cat, b_cat)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ._lib import call
+        from .ops.functional import _p, _s, ensure_scratch, gemm_bf16
+        tok, w_cat = ctx.saved_tensors
+        head = ctx.head
+        A = head.num_anchors
+        dy = dy.contiguous()
+        dx = gemm_bf16(dy, w_cat, None, b_is_kn=True) if ctx.needs_input_grad[0] else None
+        key = head.rpn_cls.weight
+        N1, C = w_cat.shape
+        dwb = mixed.step_buffer(key, 'rpn_dw', (N1, C), tok.device)
+        dbb = mixed.step_buffer(key, 'rpn_db', (N1,), tok.device)
+        ensure_scratch(tok.device)
+        call("wgrad_linear_bf16", _p(dy), _p(tok.contiguous()), _p(dwb), _p(dbb), dy.shape[0], N1, C, _s())
+        if mixed.use_end(key) > 0:
+            return dx, None, None, None, None, None, None, None
+        # last level: hand the accumulated gradients to the four parameters
+        mixed.step_buffer_done(key, 'rpn_dw'); mixed.step_buffer_done(key, 'rpn_db')
+        parts = ((head.rpn_cls.weight, dwb[:A].view(A, C, 1, 1)), (head.rpn_reg.weight, dwb[A:5 * A].view(4 * A, C, 1, 1)),
+                 (head.rpn_cls.bias, dbb[:A]), (head.rpn_reg.bias, dbb[A:5 * A]))
+        outs = []
+        for (p, g), dt_ in zip(parts, ctx.dts):
+            sk = mixed.grad_sink(p)
+            if sk is not None and sk[0].shape == g.shape:
+                sk[0].add_(g)
+                sk[1]()
+                outs.append(None)
+            else:
+                outs.append(g.to(dt_).clone())
+        return (dx, None, None, None) + tuple(outs)
+
+
 @HEADS.register_module()
 class RPNHead(nn.Module):
     def __init__(self, in_channels, feat_channels=256, anchor_generator=None, bbox_coder=None, loss_cls=None,
@@ -407,19 +469,37 @@ class RPNHead(nn.Module):
         dt = self.compute_dtype
         cls, reg = [], []
         A = self.num_anchors
+        fused = dt == torch.bfloat16 and feats[0].is_cuda
         if dt == torch.bfloat16:
-            # rpn_cls (A) and rpn_reg (4A) as ONE GEMM over the tokens, rows padded to a multiple of 8 for the kernels
+            # rpn_cls (A) and rpn_reg (4A) as ONE GEMM over the tokens, rows padded to a multiple of 8 for the kernels; the
+            # concatenated bf16 weight / bias are built once per step (mixed.derived: constant until the next shadow refresh)
             C = self.rpn_cls.in_channels
             pad = (-5 * A) % 8
-            w = torch.cat([_cast(self.rpn_cls.weight, dt).view(A, C), _cast(self.rpn_reg.weight, dt).view(4 * A, C),
-                           torch.zeros(pad, C, device=self.rpn_cls.weight.device, dtype=dt)], 0)
-            b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias, torch.zeros(pad, device=w.device)], 0).to(dt)
+
+            def _wcat():
+                return torch.cat([_cast(self.rpn_cls.weight, dt).detach().view(A, C), _cast(self.rpn_reg.weight, dt).detach().view(4 * A, C),
+                                  torch.zeros(pad, C, device=self.rpn_cls.weight.device, dtype=dt)], 0)
+
+            def _bcat():
+                return torch.cat([self.rpn_cls.bias.detach(), self.rpn_reg.bias.detach(),
+                                  torch.zeros(pad, device=self.rpn_cls.bias.device)], 0).to(dt)
+            if fused:
+                w, b = mixed.derived(self.rpn_cls.weight, 'rpn_wcat', _wcat), mixed.derived(self.rpn_cls.weight, 'rpn_bcat', _bcat)
+            else:
+                w = torch.cat([_cast(self.rpn_cls.weight, dt).view(A, C), _cast(self.rpn_reg.weight, dt).view(4 * A, C),
+                               torch.zeros(pad, C, device=self.rpn_cls.weight.device, dtype=dt)], 0)
+                b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias, torch.zeros(pad, device=w.device)], 0).to(dt)
         ys = []
         for x in feats:
             x = _conv(x, self.rpn_conv, dt, padding=1, relu=True)
             if dt == torch.bfloat16:
                 N, C, H, W = x.shape
-                y = ops.linear(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w, b, dt).view(N, H, W, -1)
+                tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
+                if fused:
+                    y = _RpnHeads.apply(tok, w, b, self, _cast(self.rpn_cls.weight, dt), _cast(self.rpn_reg.weight, dt),
+                                        self.rpn_cls.bias, self.rpn_reg.bias).view(N, H, W, -1)
+                else:
+                    y = ops.linear(tok, w, b, dt).view(N, H, W, -1)
                 cls.append(y[..., :A].permute(0, 3, 1, 2))
                 reg.append(y[..., A:5 * A].permute(0, 3, 1, 2))
                 ys.append(y.view(N, H * W, -1))
@@ -599,9 +679,7 @@ class SingleRoIExtractor(nn.Module):
         n = len(feats)
         groups = []
         for ext, r, v in ((self, rois, valid), (other, other_rois, other_valid)):
-            lv = ext.map_roi_levels(r, n)
-            if v is not None:
-                lv = torch.where(v, lv, torch.full_like(lv, -1))
+            lv = ops.map_roi_levels(r, n, ext.finest_scale, v)           # one launch: levels, -1 for unused slots
             groups.append((r, lv, ext.roi_layers[0].output_size))
         return tuple(ops.roi_align_multilevel_group(list(feats), groups, self.featmap_strides[:n], a.sampling_ratio, a.aligned,
                                                     out_dtype=feats[0].dtype))
@@ -615,9 +693,7 @@ class SingleRoIExtractor(nn.Module):
             # one launch over the pyramid, level chosen per RoI on the device: no per-level nonzero / gather /
             # scatter and no host sync; every level receives a gradient tensor, so the reference's dummy-gradient
             # trick (:98-107) is not needed.  `valid` marks the used slots of a fixed-size sample.
-            lvls = self.map_roi_levels(rois, num_levels)
-            if valid is not None:
-                lvls = torch.where(valid, lvls, torch.full_like(lvls, -1))
+            lvls = ops.map_roi_levels(rois, num_levels, self.finest_scale, valid)
             rl = self.roi_layers[0]
             return ops.roi_align_multilevel(list(feats), rois, lvls, out_size, self.featmap_strides[:num_levels],
                                             rl.sampling_ratio, rl.aligned, out_dtype=f0.dtype)   # bf16 in -> bf16 out: no cast pass
@@ -709,8 +785,12 @@ class ConvFCBBoxHead(nn.Module):
                 if cm.with_norm:
                     x = _bn_act(x, cm, self.training, relu=True)
         x = _cast(x.flatten(1), dt)                 # (K, C*7*7) in the reference's (C,7,7) order
+        fast = dt == torch.bfloat16 and x.is_cuda
         for fc in self.shared_fcs:
-            x = F.relu(F.linear(x, _cast(fc.weight, dt), _cast(fc.bias, dt)), inplace=True)
+            y = ops.linear(x, fc.weight, fc.bias, dt) if fast else F.linear(x, _cast(fc.weight, dt), _cast(fc.bias, dt))
+            x = F.relu(y, inplace=True)
+        if fast:
+            return ops.linear(x, self.fc_cls.weight, self.fc_cls.bias, dt), ops.linear(x, self.fc_reg.weight, self.fc_reg.bias, dt)
         cls = F.linear(x, _cast(self.fc_cls.weight, dt), _cast(self.fc_cls.bias, dt))
         reg = F.linear(x, _cast(self.fc_reg.weight, dt), _cast(self.fc_reg.bias, dt))
         return cls, reg
@@ -1237,7 +1317,8 @@ class MaskRCNN(nn.Module):
     @staticmethod
     def parse_losses(losses):
         """base.py:185-218 without the per-scalar all-reduce/.item(): returns (loss tensor, dict of tensors)."""
-        total = sum(v for k, v in losses.items() if 'loss' in k)
+        terms = [v.float().reshape(()) for k, v in losses.items() if 'loss' in k]
+        total = torch.stack(terms).sum() if len(terms) > 1 else terms[0]      # one stack + one sum, not a chain of adds
         return total, losses
 
 

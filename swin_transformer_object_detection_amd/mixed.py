@@ -53,11 +53,13 @@ def derived(master, tag, fn):
 
 
 def step_buffer(master, tag, shape, device):
-    """A persistent fp32 scratch accumulator for ``master``; zeroed on its first request of an accumulation round."""
+    """A persistent fp32 scratch accumulator for ``master``; zero at its first request of an accumulation round (all known
+    buffers are zeroed together by ONE multi-tensor launch in reset_step(); a buffer created later zeroes itself)."""
     k = (id(master), tag)
     b = _STEPBUF.get(k)
     if b is None or tuple(b.shape) != tuple(shape) or b.device != device:
         b = _STEPBUF[k] = torch.empty(shape, device=device, dtype=torch.float32)
+        _STEPLIVE.discard(k)
     if k not in _STEPLIVE:
         b.zero_()
         _STEPLIVE.add(k)
@@ -96,6 +98,11 @@ def reset_step():
     _USES.clear()
     _PENDING.clear()
     _STEPLIVE.clear()
+    if _STEPBUF:                                  # one launch for all of them instead of one memset per layer
+        bufs = [b for b in _STEPBUF.values() if b.is_cuda]
+        if bufs:
+            torch._foreach_zero_(bufs)
+            _STEPLIVE.update(k for k, b in _STEPBUF.items() if b.is_cuda)
 
 
 def weight(p, dtype):

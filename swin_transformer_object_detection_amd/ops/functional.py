@@ -361,8 +361,8 @@ class _UpsampleAdd(torch.autograd.Function):
         cl2, _, _, Hc, Wc = _nchw_layout(coarse)
         if cl != cl2 or not fine.is_cuda:
             raise SwinHipError("fine/coarse must share a memory layout and live on the GPU")
-        out = fine.clone(memory_format=torch.preserve_format)
-        call("fpn_upsample_add_fwd", _p(out), _p(coarse), N, C, Hf, Wf, Hc, Wc, cl, _dt(fine), _s())
+        out = torch.empty_like(fine, memory_format=torch.preserve_format)
+        call("fpn_upsample_add_out_fwd", _p(fine), _p(coarse), _p(out), N, C, Hf, Wf, Hc, Wc, cl, _dt(fine), _s())
         ctx.geom = (cl, N, C, Hf, Wf, Hc, Wc)
         return out
 
@@ -371,8 +371,8 @@ class _UpsampleAdd(torch.autograd.Function):
         cl, N, C, Hf, Wf, Hc, Wc = ctx.geom
         dout = dout.contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
         dcoarse = torch.empty((N, C, Hc, Wc), device=dout.device, dtype=dout.dtype,
-                              memory_format=torch.channels_last if cl else torch.contiguous_format).zero_()
-        call("fpn_upsample_add_bwd", _p(dout), _p(dcoarse), N, C, Hf, Wf, Hc, Wc, cl, _dt(dout), _s())
+                              memory_format=torch.channels_last if cl else torch.contiguous_format)
+        call("fpn_upsample_add_out_bwd", _p(dout), _p(dcoarse), N, C, Hf, Wf, Hc, Wc, cl, _dt(dout), _s())
         return dout, dcoarse
 
 

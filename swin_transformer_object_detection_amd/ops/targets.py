@@ -108,6 +108,21 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     return out
 
 
+def map_roi_levels(rois, num_levels, finest_scale=56, valid=None):
+    """SingleRoIExtractor.map_roi_levels (single_level_roi_extractor.py:32-51) for (K,5) float32 rois on the GPU -> (K,) int32
+    levels; rows where ``valid`` (K,) bool is False get -1 (skipped by roi_align_multilevel).  One launch."""
+    if not rois.is_cuda:
+        raise SwinHipError("map_roi_levels: GPU tensors only")
+    r = rois.detach().float().contiguous()
+    K = r.size(0)
+    out = torch.empty(K, device=r.device, dtype=torch.int32)
+    v = None
+    if valid is not None:
+        v = valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8).contiguous()
+    call("det_map_roi_levels", _p(r), _p(v), K, int(num_levels), float(finest_scale), _p(out), _s())
+    return out
+
+
 def rpn_topk_decode(cls_all, reg_all, anchors, level_sizes, nms_pre, means, stds, max_shape):
     """RPNHead._get_bboxes up to batched_nms (rpn_head.py:126-187) in one launch: cls_all (B,total) logits, reg_all
     (B,total,4) deltas (float32 or bfloat16, anchors flattened (level,h,w,a)), anchors (total,4) float32 ->
