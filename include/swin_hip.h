@@ -345,6 +345,16 @@ int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1, const void
 int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, const float* b1, const void* w2, void* dx, void* h,
                       void* dhpre, int64_t T, int C, void* stream);
 
+/* nms_prepare_sorted_batch / nms_gather_dets: the front and back end of mmcv.ops.batched_nms (rpn_head.py:233) around
+ *   nms_sorted_batch for `batch` images of n candidates each (n <= 16384), one launch each: boxes (batch,n,4) f32, scores
+ *   (batch,n) f32, idxs (batch,n) i64 -> boxes_sorted = boxes + idxs * (max coordinate of the image + 1) in stable
+ *   descending-score order, order (batch,n) i32 = source index of every sorted slot; then dets (batch,kept_cap,5) =
+ *   [box, score] of kept_pos's entries (-1: zero row), valid (batch,kept_cap) u8. */
+int nms_prepare_sorted_batch(const float* boxes, const float* scores, const int64_t* idxs, int batch, int64_t n,
+                             float* boxes_sorted, int32_t* order, void* stream);
+int nms_gather_dets(const float* boxes, const float* scores, const int32_t* order, const int32_t* kept_pos, int batch,
+                    int64_t n, int kept_cap, float* dets, uint8_t* valid, void* stream);
+
 /* det_map_roi_levels: SingleRoIExtractor.map_roi_levels (single_level_roi_extractor.py:32-51): rois (K,5) f32 -> out (K) i32 =
  *   clamp(floor(log2(sqrt(w h) / finest_scale + 1e-6)), 0, num_levels-1); rows with valid[k] == 0 (valid may be NULL) get -1. */
 int det_map_roi_levels(const float* rois, const uint8_t* valid, int64_t K, int num_levels, float finest_scale, int* out,

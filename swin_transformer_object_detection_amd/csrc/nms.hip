@@ -163,3 +163,111 @@ extern "C" int nms_sorted_batch(const float* boxes_sorted, int batch, int64_t n,
                                                                    num_kept, max_num, kept_pos, kept_cap);
     return swin_launch_status();
 }
+
+// ---- batched_nms front / back end on the device (round 2) -----------------------------------------------------------------
+// mmcv's batched_nms (bbox_nms / rpn_head.py:233) offsets every box by idx * (max_coordinate + 1), nms() then sorts by score
+// (descending; here: stable, ties -> lower index first) before the suppression scan.  One block per image does all of that:
+// max over the image's coordinates, a bitonic sort of 64-bit keys (~orderable(score) << 32 | index: ascending order of the key
+// = descending score, ascending index) in LDS, and the gather of the offset boxes into sorted order.  Replaces amax, two
+// casts, mul, add, a segmented radix sort (8 launches) and a gather.  n <= 16384 (RPN: 8780).
+constexpr int NP_MAX = 16384;
+
+__global__ __launch_bounds__(1024) void nms_prepare_kernel(const float4* __restrict__ boxes, const float* __restrict__ scores,
+                                                           const int64_t* __restrict__ idxs, int n, int np, float4* __restrict__ boxes_sorted,
+                                                           int32_t* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float4* bx = boxes + (size_t)b * n;
+    const float* sc = scores + (size_t)b * n;
+    float m = -INFINITY;
+    for (int i = tid; i < np; i += 1024) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            const float4 v = bx[i];
+            m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            unsigned u = __float_as_uint(sc[i]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // ascending unsigned order == ascending float order
+            k = ((unsigned long long)(~u) << 32) | (unsigned)i;
+        }
+        keys[i] = k;
+    }
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    float maxc = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) maxc = fmaxf(maxc, red[w]);
+    for (int k = 2; k <= np; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (np >> 1); t += 1024) {
+                const int i = 2 * t - (t & (j - 1)), l = i + j;
+                const unsigned long long a = keys[i], c = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > c) == up) { keys[i] = c; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const float scale = maxc + 1.0f;
+    const int64_t* id = idxs + (size_t)b * n;
+    for (int i = tid; i < n; i += 1024) {
+        const int src = (int)(unsigned)keys[i];
+        const float off = (float)id[src] * scale;
+        float4 v = bx[src];
+        v.x += off; v.y += off; v.z += off; v.w += off;
+        boxes_sorted[(size_t)b * n + i] = v;
+        order[(size_t)b * n + i] = src;
+    }
+}
+
+// dets (batch, cap, 5) = [original box | score] of the kept boxes in kept order, zero rows and valid = 0 after the last one
+__global__ __launch_bounds__(256) void nms_gather_kernel(const float4* __restrict__ boxes, const float* __restrict__ scores,
+                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ kept_pos, int n,
+                                                         int cap, int total, float* __restrict__ dets, uint8_t* __restrict__ valid) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int b = t / cap;
+    const int pos = kept_pos[t];
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    float s = 0.f;
+    if (pos >= 0) {
+        const int src = order[(size_t)b * n + pos];
+        v = boxes[(size_t)b * n + src];
+        s = scores[(size_t)b * n + src];
+    }
+    float* d = dets + (size_t)t * 5;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = s;
+    valid[t] = pos >= 0 ? 1 : 0;
+}
+
+extern "C" int nms_prepare_sorted_batch(const float* boxes, const float* scores, const int64_t* idxs, int batch, int64_t n,
+                                        float* boxes_sorted, int32_t* order, void* stream) {
+    if (batch <= 0 || n <= 0) return SWIN_OK;
+    if (!boxes || !scores || !idxs || !boxes_sorted || !order) return SWIN_ERR_BAD_ARG;
+    if (n > NP_MAX || batch > 65535) return SWIN_ERR_UNSUPPORTED;
+    int np = 1024;
+    while (np < n) np <<= 1;
+    const size_t lds = (size_t)np * sizeof(unsigned long long);
+    static bool attr_set[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)nms_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(NP_MAX * sizeof(unsigned long long))) != hipSuccess) return SWIN_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    nms_prepare_kernel<<<batch, 1024, lds, (hipStream_t)stream>>>((const float4*)boxes, scores, idxs, (int)n, np, (float4*)boxes_sorted,
+                                                                 order);
+    return swin_launch_status();
+}
+
+extern "C" int nms_gather_dets(const float* boxes, const float* scores, const int32_t* order, const int32_t* kept_pos, int batch,
+                               int64_t n, int kept_cap, float* dets, uint8_t* valid, void* stream) {
+    if (batch <= 0 || kept_cap <= 0) return SWIN_OK;
+    if (!boxes || !scores || !order || !kept_pos || !dets || !valid || n <= 0) return SWIN_ERR_BAD_ARG;
+    const int total = batch * kept_cap;
+    nms_gather_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>((const float4*)boxes, scores, order, kept_pos, (int)n, kept_cap,
+                                                                            total, dets, valid);
+    return swin_launch_status();
+}

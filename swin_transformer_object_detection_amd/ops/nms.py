@@ -125,14 +125,28 @@ def batched_nms_static_multi(boxes, scores, idxs, iou_threshold, max_num):
     B, n = scores.shape
     if n == 0:
         return boxes.new_zeros((B, max_num, 5)), torch.zeros((B, max_num), dtype=torch.bool, device=boxes.device)
+    boxes, scores, idxs = boxes.contiguous(), scores.contiguous(), idxs.contiguous()
+    dev = boxes.device
+    ws = torch.empty(B * lib().swin_nms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    flags = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    pos = torch.empty((B, max_num), dtype=torch.int32, device=dev)
+    if n <= 16384 and idxs.dtype == torch.int64:
+        # the whole front end (per-image max coordinate, class offsets, stable descending sort, gather) and the back end (kept
+        # boxes + scores, validity) are one launch each (csrc/nms.hip): 5 launches per call instead of ~27
+        bs = torch.empty((B, n, 4), dtype=torch.float32, device=dev)
+        order = torch.empty((B, n), dtype=torch.int32, device=dev)
+        call("nms_prepare_sorted_batch", _p(boxes), _p(scores), _p(idxs), B, n, _p(bs), _p(order), _s())
+        call("nms_sorted_batch", _p(bs), B, n, float(iou_threshold), 0, int(max_num), _p(flags), _p(cnt), _p(pos), int(max_num), _p(ws),
+             _s())
+        dets = torch.empty((B, max_num, 5), dtype=torch.float32, device=dev)
+        valid = torch.empty((B, max_num), dtype=torch.bool, device=dev)
+        call("nms_gather_dets", _p(boxes), _p(scores), _p(order), _p(pos), B, n, int(max_num), _p(dets), _p(valid), _s())
+        return dets, valid
     max_coordinate = boxes.amax(dim=(1, 2))                                        # per image, as one call per image would
     offsets = idxs.to(boxes) * (max_coordinate + 1.0)[:, None]
     order = torch.sort(scores, dim=1, descending=True, stable=True)[1]
     bs = torch.gather(boxes + offsets[..., None], 1, order[..., None].expand(B, n, 4)).contiguous()
-    ws = torch.empty(B * lib().swin_nms_workspace_bytes(n), dtype=torch.uint8, device=boxes.device)
-    flags = torch.empty((B, n), dtype=torch.uint8, device=boxes.device)
-    cnt = torch.empty(B, dtype=torch.int32, device=boxes.device)
-    pos = torch.empty((B, max_num), dtype=torch.int32, device=boxes.device)
     call("nms_sorted_batch", _p(bs), B, n, float(iou_threshold), 0, int(max_num), _p(flags), _p(cnt), _p(pos), int(max_num), _p(ws),
          _s())
     valid = pos >= 0
