@@ -349,9 +349,10 @@ int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, const float
  *   nms_sorted_batch for `batch` images of n candidates each (n <= 16384), one launch each: boxes (batch,n,4) f32, scores
  *   (batch,n) f32, idxs (batch,n) i64 -> boxes_sorted = boxes + idxs * (max coordinate of the image + 1) in stable
  *   descending-score order, order (batch,n) i32 = source index of every sorted slot; then dets (batch,kept_cap,5) =
- *   [box, score] of kept_pos's entries (-1: zero row), valid (batch,kept_cap) u8. */
+ *   [box, score] of kept_pos's entries (-1: zero row), valid (batch,kept_cap) u8.  workspace: nms_prepare_workspace_bytes. */
+int64_t nms_prepare_workspace_bytes(int batch, int64_t n);
 int nms_prepare_sorted_batch(const float* boxes, const float* scores, const int64_t* idxs, int batch, int64_t n,
-                             float* boxes_sorted, int32_t* order, void* stream);
+                             float* boxes_sorted, int32_t* order, void* workspace, void* stream);
 int nms_gather_dets(const float* boxes, const float* scores, const int32_t* order, const int32_t* kept_pos, int batch,
                     int64_t n, int kept_cap, float* dets, uint8_t* valid, void* stream);
 

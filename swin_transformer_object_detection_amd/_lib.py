@@ -72,7 +72,8 @@ SIGNATURES = {
     "det_rpn_flatten_bwd": [_p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
     "swin_mlp_fwd_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i, _p],
     "swin_mlp_bwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p],
-    "nms_prepare_sorted_batch": [_p, _p, _p, _i, _i64, _p, _p, _p],
+    "nms_prepare_workspace_bytes": [_i, _i64],
+    "nms_prepare_sorted_batch": [_p, _p, _p, _i, _i64, _p, _p, _p, _p],
     "nms_gather_dets": [_p, _p, _p, _p, _i, _i64, _i, _p, _p, _p],
     "det_map_roi_levels": [_p, _p, _i64, _i, _f, _p, _p],
     "det_rpn_topk_decode_workspace_bytes": [_i64, _i64],
@@ -81,7 +82,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_gemm_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
             "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64, "det_bn_workspace_bytes": _i64,
-            "det_rpn_topk_decode_workspace_bytes": _i64}
+            "det_rpn_topk_decode_workspace_bytes": _i64, "nms_prepare_workspace_bytes": _i64}
 
 _lib = None
 

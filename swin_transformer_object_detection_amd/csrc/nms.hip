@@ -171,54 +171,88 @@ extern "C" int nms_sorted_batch(const float* boxes_sorted, int batch, int64_t n,
 // = descending score, ascending index) in LDS, and the gather of the offset boxes into sorted order.  Replaces amax, two
 // casts, mul, add, a segmented radix sort (8 launches) and a gather.  n <= 16384 (RPN: 8780).
 constexpr int NP_MAX = 16384;
+constexpr int SEG = 2048;                       // candidates per sorting block
+constexpr int MAX_SEGS = NP_MAX / SEG;
 
-__global__ __launch_bounds__(1024) void nms_prepare_kernel(const float4* __restrict__ boxes, const float* __restrict__ scores,
-                                                           const int64_t* __restrict__ idxs, int n, int np, float4* __restrict__ boxes_sorted,
-                                                           int32_t* __restrict__ order) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+__device__ __forceinline__ unsigned f2ord(float f) {             // ascending unsigned order == ascending float order
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// pass 1: block (segment, image) sorts its <= 2048 keys in LDS (bitonic: 66 passes over 16 KB; one block sorting all 8780
+// candidates of an image moved 262 KB of LDS per pass x 105 passes = 150 us) and folds its coordinate maximum into maxc[image]
+__global__ __launch_bounds__(1024) void nms_segsort_kernel(const float4* __restrict__ boxes, const float* __restrict__ scores, int n,
+                                                           unsigned long long* __restrict__ skeys, unsigned* __restrict__ maxc) {
+    __shared__ unsigned long long keys[SEG];
     __shared__ float red[16];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float4* bx = boxes + (size_t)b * n;
-    const float* sc = scores + (size_t)b * n;
+    const int seg = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lo = seg * SEG;
     float m = -INFINITY;
-    for (int i = tid; i < np; i += 1024) {
+    for (int t = tid; t < SEG; t += 1024) {
+        const int i = lo + t;
         unsigned long long k = ~0ull;
         if (i < n) {
-            const float4 v = bx[i];
+            const float4 v = boxes[(size_t)b * n + i];
             m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-            unsigned u = __float_as_uint(sc[i]);
-            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // ascending unsigned order == ascending float order
-            k = ((unsigned long long)(~u) << 32) | (unsigned)i;
+            k = ((unsigned long long)(~f2ord(scores[(size_t)b * n + i])) << 32) | (unsigned)i;
         }
-        keys[i] = k;
+        keys[t] = k;
     }
     m = wave_max(m);
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    float maxc = red[0];
+    if (tid == 0) {
+        float mm = red[0];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) maxc = fmaxf(maxc, red[w]);
-    for (int k = 2; k <= np; k <<= 1) {
+        for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
+        atomicMax(maxc + b, f2ord(mm));
+    }
+    for (int k = 2; k <= SEG; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (np >> 1); t += 1024) {
-                const int i = 2 * t - (t & (j - 1)), l = i + j;
-                const unsigned long long a = keys[i], c = keys[l];
-                const bool up = (i & k) == 0;
-                if ((a > c) == up) { keys[i] = c; keys[l] = a; }
-            }
+            const int t = tid;                                   // SEG / 2 == 1024 compare-exchanges per pass
+            const int i = 2 * t - (t & (j - 1)), l = i + j;
+            const unsigned long long a = keys[i], c = keys[l];
+            const bool up = (i & k) == 0;
+            if ((a > c) == up) { keys[i] = c; keys[l] = a; }
             __syncthreads();
         }
     }
-    const float scale = maxc + 1.0f;
-    const int64_t* id = idxs + (size_t)b * n;
-    for (int i = tid; i < n; i += 1024) {
-        const int src = (int)(unsigned)keys[i];
-        const float off = (float)id[src] * scale;
-        float4 v = bx[src];
-        v.x += off; v.y += off; v.z += off; v.w += off;
-        boxes_sorted[(size_t)b * n + i] = v;
-        order[(size_t)b * n + i] = src;
+    for (int t = tid; t < SEG; t += 1024) skeys[((size_t)b * gridDim.x + seg) * SEG + t] = keys[t];
+}
+
+// pass 2: a key's final position = its rank in its own segment + the number of smaller keys in every other segment (binary
+// searches; keys are unique, so the merge is exact and stable); writes the offset box and the source index there
+__global__ __launch_bounds__(256) void nms_merge_kernel(const float4* __restrict__ boxes, const int64_t* __restrict__ idxs, int n, int nseg,
+                                                        const unsigned long long* __restrict__ skeys, const unsigned* __restrict__ maxc,
+                                                        float4* __restrict__ boxes_sorted, int32_t* __restrict__ order) {
+    const int b = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;               // (segment, rank) flattened
+    if (g >= nseg * SEG) return;
+    const int seg = g / SEG, r = g - seg * SEG;
+    const unsigned long long* base = skeys + (size_t)b * nseg * SEG;
+    const unsigned long long key = base[(size_t)seg * SEG + r];
+    if (key == ~0ull) return;                                    // padding
+    int pos = r;
+    for (int s2 = 0; s2 < nseg; ++s2) {
+        if (s2 == seg) continue;
+        const unsigned long long* p = base + (size_t)s2 * SEG;
+        int lo = 0, hi = SEG;                                    // first index with p[idx] >= key (padding ~0 is larger)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (p[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        pos += lo;
     }
+    const int src = (int)(unsigned)key;
+    const float scale = ord2f(maxc[b]) + 1.0f;
+    const float off = (float)idxs[(size_t)b * n + src] * scale;
+    float4 v = boxes[(size_t)b * n + src];
+    v.x += off; v.y += off; v.z += off; v.w += off;
+    boxes_sorted[(size_t)b * n + pos] = v;
+    order[(size_t)b * n + pos] = src;
 }
 
 // dets (batch, cap, 5) = [original box | score] of the kept boxes in kept order, zero rows and valid = 0 after the last one
@@ -241,24 +275,24 @@ __global__ __launch_bounds__(256) void nms_gather_kernel(const float4* __restric
     valid[t] = pos >= 0 ? 1 : 0;
 }
 
+extern "C" int64_t nms_prepare_workspace_bytes(int batch, int64_t n) {
+    const int64_t nseg = (n + SEG - 1) / SEG;
+    return (int64_t)batch * nseg * SEG * (int64_t)sizeof(unsigned long long) + (int64_t)batch * (int64_t)sizeof(unsigned) + 16;
+}
+
 extern "C" int nms_prepare_sorted_batch(const float* boxes, const float* scores, const int64_t* idxs, int batch, int64_t n,
-                                        float* boxes_sorted, int32_t* order, void* stream) {
+                                        float* boxes_sorted, int32_t* order, void* workspace, void* stream) {
     if (batch <= 0 || n <= 0) return SWIN_OK;
-    if (!boxes || !scores || !idxs || !boxes_sorted || !order) return SWIN_ERR_BAD_ARG;
+    if (!boxes || !scores || !idxs || !boxes_sorted || !order || !workspace) return SWIN_ERR_BAD_ARG;
     if (n > NP_MAX || batch > 65535) return SWIN_ERR_UNSUPPORTED;
-    int np = 1024;
-    while (np < n) np <<= 1;
-    const size_t lds = (size_t)np * sizeof(unsigned long long);
-    static bool attr_set[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
-    if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)nms_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(NP_MAX * sizeof(unsigned long long))) != hipSuccess) return SWIN_ERR_LAUNCH;
-        attr_set[dev] = true;
-    }
-    nms_prepare_kernel<<<batch, 1024, lds, (hipStream_t)stream>>>((const float4*)boxes, scores, idxs, (int)n, np, (float4*)boxes_sorted,
-                                                                 order);
+    const int nseg = (int)((n + SEG - 1) / SEG);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* skeys = (unsigned long long*)workspace;
+    unsigned* maxc = (unsigned*)(skeys + (size_t)batch * nseg * SEG);
+    if (hipMemsetAsync(maxc, 0, (size_t)batch * sizeof(unsigned), s) != hipSuccess) return SWIN_ERR_LAUNCH;
+    nms_segsort_kernel<<<dim3(nseg, batch), 1024, 0, s>>>((const float4*)boxes, scores, (int)n, skeys, maxc);
+    nms_merge_kernel<<<dim3((nseg * SEG + 255) / 256, batch), 256, 0, s>>>((const float4*)boxes, idxs, (int)n, nseg, skeys, maxc,
+                                                                          (float4*)boxes_sorted, order);
     return swin_launch_status();
 }
 

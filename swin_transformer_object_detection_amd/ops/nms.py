@@ -136,7 +136,8 @@ def batched_nms_static_multi(boxes, scores, idxs, iou_threshold, max_num):
         # boxes + scores, validity) are one launch each (csrc/nms.hip): 5 launches per call instead of ~27
         bs = torch.empty((B, n, 4), dtype=torch.float32, device=dev)
         order = torch.empty((B, n), dtype=torch.int32, device=dev)
-        call("nms_prepare_sorted_batch", _p(boxes), _p(scores), _p(idxs), B, n, _p(bs), _p(order), _s())
+        pws = torch.empty(lib().nms_prepare_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
+        call("nms_prepare_sorted_batch", _p(boxes), _p(scores), _p(idxs), B, n, _p(bs), _p(order), _p(pws), _s())
         call("nms_sorted_batch", _p(bs), B, n, float(iou_threshold), 0, int(max_num), _p(flags), _p(cnt), _p(pos), int(max_num), _p(ws),
              _s())
         dets = torch.empty((B, max_num, 5), dtype=torch.float32, device=dev)
