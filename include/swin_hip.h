@@ -251,6 +251,19 @@ int det_bbox_targets(const float* bboxes, const int64_t* inds, const uint8_t* fl
 int det_delta2bbox(const float* rois, const float* deltas, int64_t n, const float* means, const float* stds,
                    float max_h, float max_w, float wh_ratio_clip, float* out, void* stream);
 
+/* det_roi_targets_pack: one image's rows of an R-CNN stage's batch-level training tensors from its fixed-size sample --
+ *   standard_roi_head.py:83-93 (SamplingResult: boxes, pos_is_gt), bbox_head.py:140-186 (get_targets: labels, encoded or
+ *   decoded regression targets), bbox2roi (transforms.py:117-137: the image index column) and, for the first km slots,
+ *   mask_target.py:95-107 + structures.py:343-350 (rows [gt index + gt_offset, box clipped to (mask_h, mask_w)] for
+ *   crop_and_resize), the mask head's labels (clamped below the background label) and validity.  Every out_* pointer
+ *   addresses THIS image's first row; pos / valid / is_gt / mvalid are 0/1 bytes (torch.bool storage). */
+int det_roi_targets_pack(const float* bboxes, const int64_t* inds, const uint8_t* flags, const int64_t* assigned_gt_inds,
+                         const float* gt_bboxes, int num_gts, const int64_t* assigned_labels, int64_t bg_label,
+                         const float* means, const float* stds, int k, int img, int num_leading_gt, int reg_decoded,
+                         float* out_rois5, float* out_targets, int64_t* out_labels, uint8_t* out_pos, uint8_t* out_valid,
+                         uint8_t* out_is_gt, int km, int gt_offset, float mask_h, float mask_w, float* out_feat_rois5,
+                         float* out_mask_rois5, int64_t* out_mlabels, uint8_t* out_mvalid, void* stream);
+
 /* det_paste_masks: test-time FCNMaskHead.get_seg_masks / _do_paste_mask (fcn_mask_head.py:169-300, :303-377):
  *   mask_logits (N, num_classes, mh, mw) f32|bf16, labels (N) i64, boxes (N,4) f32 in output-image coordinates ->
  *   out (N, img_h, img_w) u8 = (bilinear resample of sigmoid(logits[n, labels[n]]) into the box) >= thr.  is_prob != 0:
@@ -314,7 +327,10 @@ int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, int decon
 /* swin_block_fwd / swin_block_bwd: the whole SwinTransformerBlock (swin_transformer.py:204-255) and its backward as ONE
  * call each -- the library's own kernels launched in sequence from native code (csrc/block_runner.hip lists the
  * pointer-table layouts).  p: HOST array of device pointers, iv: {B,H,W,C,nH,shift}, fv: {scale[, eps]}.  No allocation,
- * no synchronisation; every buffer (saved activations, temporaries, gradient accumulators, workspaces) is the caller's. */
+ * no synchronisation; every buffer (saved activations, temporaries, gradient accumulators, workspaces) is the caller's.
+ * swin_block_bwd's table entry 55 may name a second hipStream_t for the four weight-gradient GEMMs (null: `stream`): they are
+ * enqueued there behind events recorded on `stream`, so they overlap the data-gradient chain; the caller joins the streams
+ * before the accumulators are read and keeps the operands alive until then. */
 int swin_block_fwd(const void* const* p, const int64_t* iv, const float* fv, void* stream);
 int swin_block_bwd(const void* const* p, const int64_t* iv, const float* fv, void* stream);
 

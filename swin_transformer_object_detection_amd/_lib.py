@@ -48,6 +48,8 @@ SIGNATURES = {
     "det_random_sample_workspace_bytes": [],
     "det_random_sample": [_p, _i64, _i, _i, ctypes.c_uint64, _p, _p, _p, _p],
     "det_bbox_targets": [_p, _p, _p, _p, _p, _i, _p, _i64, _p, _p, _i, _p, _p, _p, _p, _p],
+    "det_roi_targets_pack": [_p, _p, _p, _p, _p, _i, _p, _i64, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f,
+                             _p, _p, _p, _p, _p],
     "det_delta2bbox": [_p, _p, _i64, _p, _p, _f, _f, _f, _p, _p],
     "swin_block_fwd": [_p, _p, _p, _p],
     "swin_block_bwd": [_p, _p, _p, _p],

@@ -406,6 +406,87 @@ extern "C" int det_bbox_targets(const float* bboxes, const int64_t* inds, const 
     return swin_launch_status();
 }
 
+// One image's part of an R-CNN stage's training targets, written straight into the BATCH-level tensors (the caller passes
+// this image's rows): what standard_roi_head.py:83-93 (sampling results), bbox_head.py:140-186 (get_targets) and
+// mask_target.py:95-107 (clipped [gt index, box] rows for crop_and_resize) build with ~20 gathers, comparisons, clamps and
+// concatenations per image.  Slot i of the fixed-size sample (det_random_sample's inds / flags):
+//   rois5[i] = (img, box)   targets[i] = encoded deltas (zero unless positive) or, reg_decoded, the matched gt box
+//   labels[i] = class or bg_label   pos / valid / is_gt[i] = positive / used / positive AND one of the leading gt boxes
+// and for the first km slots (the positives come first): feat_rois5[i] = (img, box) for the mask RoI extractor,
+//   mask_rois5[i] = (gt index + gt_offset, box clipped to the mask's extent), mlabels[i] = min(label, bg_label - 1),
+//   mvalid[i] = positive.
+struct RoiPackOut {
+    float* rois5; float4* targets; int64_t* labels; uint8_t* pos; uint8_t* valid; uint8_t* is_gt;
+    float* feat_rois5; float* mask_rois5; int64_t* mlabels; uint8_t* mvalid;
+};
+__global__ __launch_bounds__(256) void roi_targets_pack_kernel(const float4* __restrict__ boxes, const int64_t* __restrict__ inds,
+                                                               const uint8_t* __restrict__ flags, const int64_t* __restrict__ assigned,
+                                                               const float4* __restrict__ gts, int G,
+                                                               const int64_t* __restrict__ assigned_labels, int64_t bg_label, F4 means,
+                                                               F4 stds, int k, float img, int lead, int reg_decoded, int km,
+                                                               float gt_offset, float mask_h, float mask_w, RoiPackOut o) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= k) return;
+    const uint8_t f = flags[i];
+    const bool valid = f & 1, is_pos = (f & 2) != 0, pos = is_pos && G > 0;
+    const int64_t idx = valid ? inds[i] : 0;
+    const float4 b = valid ? boxes[idx] : float4{0.f, 0.f, 1.f, 1.f};
+    const int64_t a = valid ? assigned[idx] : 0;
+    const int64_t gi = a > 0 ? a - 1 : 0;
+    float4 d = {0.f, 0.f, 0.f, 0.f};
+    if (reg_decoded) {
+        if (G > 0) d = gts[gi];
+    } else if (pos) {
+        const float4 g = gts[gi];
+        const float px = (b.x + b.z) * 0.5f, py = (b.y + b.w) * 0.5f, pw = b.z - b.x, ph = b.w - b.y;
+        const float gx = (g.x + g.z) * 0.5f, gy = (g.y + g.w) * 0.5f, gw = g.z - g.x, gh = g.w - g.y;
+        d.x = ((gx - px) / pw - means.v[0]) / stds.v[0];
+        d.y = ((gy - py) / ph - means.v[1]) / stds.v[1];
+        d.z = (logf(gw / pw) - means.v[2]) / stds.v[2];
+        d.w = (logf(gh / ph) - means.v[3]) / stds.v[3];
+    }
+    const int64_t lab = (pos && assigned_labels) ? assigned_labels[idx] : bg_label;
+    float* r = o.rois5 + (size_t)i * 5;
+    r[0] = img; r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+    o.targets[i] = d;
+    o.labels[i] = lab;
+    o.pos[i] = is_pos;
+    o.valid[i] = valid;
+    o.is_gt[i] = is_pos && idx < lead;
+    if (i < km) {
+        float* fr = o.feat_rois5 + (size_t)i * 5;
+        fr[0] = img; fr[1] = b.x; fr[2] = b.y; fr[3] = b.z; fr[4] = b.w;
+        float* mr = o.mask_rois5 + (size_t)i * 5;
+        mr[0] = (float)gi + gt_offset;
+        mr[1] = fminf(fmaxf(b.x, 0.f), mask_w); mr[2] = fminf(fmaxf(b.y, 0.f), mask_h);
+        mr[3] = fminf(fmaxf(b.z, 0.f), mask_w); mr[4] = fminf(fmaxf(b.w, 0.f), mask_h);
+        o.mlabels[i] = lab < bg_label - 1 ? lab : bg_label - 1;
+        o.mvalid[i] = is_pos;
+    }
+}
+
+extern "C" int det_roi_targets_pack(const float* bboxes, const int64_t* inds, const uint8_t* flags, const int64_t* assigned_gt_inds,
+                                    const float* gt_bboxes, int num_gts, const int64_t* assigned_labels, int64_t bg_label,
+                                    const float* means, const float* stds, int k, int img, int num_leading_gt, int reg_decoded,
+                                    float* out_rois5, float* out_targets, int64_t* out_labels, uint8_t* out_pos,
+                                    uint8_t* out_valid, uint8_t* out_is_gt, int km, int gt_offset, float mask_h, float mask_w,
+                                    float* out_feat_rois5, float* out_mask_rois5, int64_t* out_mlabels, uint8_t* out_mvalid,
+                                    void* stream) {
+    if (k == 0) return SWIN_OK;
+    if (!bboxes || !inds || !flags || !assigned_gt_inds || !means || !stds || k < 0 || km < 0 || km > k || !out_rois5 ||
+        !out_targets || !out_labels || !out_pos || !out_valid || !out_is_gt || (num_gts > 0 && !gt_bboxes) ||
+        (km > 0 && (!out_feat_rois5 || !out_mask_rois5 || !out_mlabels || !out_mvalid)))
+        return SWIN_ERR_BAD_ARG;
+    F4 m, sd;
+    for (int q = 0; q < 4; ++q) { m.v[q] = means[q]; sd.v[q] = stds[q]; }
+    RoiPackOut o{out_rois5, (float4*)out_targets, out_labels, out_pos, out_valid, out_is_gt, out_feat_rois5, out_mask_rois5,
+                 out_mlabels, out_mvalid};
+    roi_targets_pack_kernel<<<(k + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+        (const float4*)bboxes, inds, flags, assigned_gt_inds, (const float4*)gt_bboxes, num_gts, assigned_labels, bg_label, m, sd, k,
+        (float)img, num_leading_gt, reg_decoded, km, (float)gt_offset, mask_h, mask_w, o);
+    return swin_launch_status();
+}
+
 // SingleRoIExtractor.map_roi_levels (single_level_roi_extractor.py:32-51) in one launch: scale = sqrt(w h),
 // lvl = clamp(floor(log2(scale / finest_scale + 1e-6)), 0, L-1) in fp32 as the reference computes it; rows whose `valid`
 // byte is 0 get -1 (the multi-level RoIAlign skips them).  Replaces ten elementwise launches per call.

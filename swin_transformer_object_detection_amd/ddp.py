@@ -121,6 +121,8 @@ class BucketedGradReducer:
         return time.perf_counter() - (self._t0 if self._t0 is not None else time.perf_counter())
 
     def _launch(self, b):
+        from . import mixed
+        mixed.side_join()           # weight-gradient kernels on the second stream may still be writing this bucket's views
         self._gather(b)
         b['launched'] = True
         if self.world > 1:
@@ -179,6 +181,7 @@ class BucketedGradReducer:
         from . import mixed
         mixed.flush_pending()
         self._issue_ready(force=True)
+        mixed.side_join()
         for b in self.buckets:
             if b['handle'] is not None:
                 b['handle'].wait()

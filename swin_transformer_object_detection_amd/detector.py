@@ -1043,6 +1043,9 @@ def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox
     nimg = len(proposal_list)
     nc = bbox_head.num_classes
     num, npos_max = s['num'], int(s['num'] * s['pos_fraction'])
+    if _PACKED_STAGE and nimg > 0 and x[0].is_cuda and all(gb.size(0) > 0 for gb in gt_bboxes):
+        return _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox_roi_extractor, bbox_head,
+                                       mask_roi_extractor, mask_head)
     roi_l, lab_l, tgt_l, pos_l, val_l, isgt_l = [], [], [], [], [], []
     m_roi, m_gt, m_lab, m_val = [], [], [], []
     for i in range(nimg):
@@ -1088,6 +1091,86 @@ def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox
         else:
             losses.update(mask_head.loss(mask_pred, torch.cat(tg), torch.cat(m_lab), mvalid))
     return losses, state
+
+
+def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox_roi_extractor, bbox_head,
+                            mask_roi_extractor, mask_head):
+    """_roi_stage_train on the GPU: per image assign -> sample -> ONE pack launch (ops.roi_targets_pack) that writes the
+    image's rows of every batch-level tensor of the stage -- RoIs with their image column, targets, labels, flags, the mask
+    slots' feature RoIs and crop_and_resize rows -- instead of ~20 gathers / comparisons / clamps / concatenations."""
+    a, s = cfg['assigner'], cfg['sampler']
+    nimg = len(proposal_list)
+    nc = bbox_head.num_classes
+    num = s['num']
+    dev = x[0].device
+    with_mask = mask_head is not None
+    km = min(int(s['num'] * s['pos_fraction']), num) if with_mask else 0          # positives come first in the sample
+    buf = ops.RoiStageBuffers(nimg, num, km, dev)
+    add_gt = s.get('add_gt_as_proposals', True)
+    # every image's masks of one size: ONE crop_and_resize launch over the stacked masks (mask_target)
+    stacked = with_mask and all(m_.size(0) > 0 and m_.shape[1:] == gt_masks[0].shape[1:] for m_ in gt_masks)
+    off = 0
+    for i in range(nimg):
+        p = proposal_list[i]
+        dets, pvalid = p if isinstance(p, tuple) else (p, None)
+        props = dets[:, :4]
+        g = gt_bboxes[i].size(0)
+        if add_gt:
+            props = torch.cat([gt_bboxes[i], props], 0)
+            if pvalid is not None:
+                pvalid = torch.cat([_ones_bool(g, dev), pvalid], 0)
+        lead = g if add_gt else 0
+        assigned, _, lab = ops.max_iou_assign(props, gt_bboxes[i], a['pos_iou_thr'], a['neg_iou_thr'], a['min_pos_iou'],
+                                              a.get('match_low_quality', True), gt_labels[i], lead, pvalid)
+        inds, flags = ops.random_sample_raw(assigned, num, s['pos_fraction'])
+        mh, mw = (gt_masks[i].shape[1:] if with_mask else (0, 0))
+        ops.roi_targets_pack(buf, i, props, inds, flags, assigned, gt_bboxes[i], bbox_head.means, bbox_head.stds, lab, nc, lead,
+                             bbox_head.reg_decoded_bbox, off if stacked else 0, (mh, mw))
+        if with_mask:
+            off += gt_masks[i].size(0)
+    losses = {}
+    rois, valid, labels = buf.rois, buf.valid, buf.labels
+    feats = x[:bbox_roi_extractor.num_inputs]
+    mask_feats = None
+    if with_mask and isinstance(bbox_roi_extractor, SingleRoIExtractor) and isinstance(mask_roi_extractor, SingleRoIExtractor):
+        bbox_feats, mask_feats = bbox_roi_extractor.forward_with(mask_roi_extractor, feats, rois, valid, buf.feat_rois, buf.mvalid)
+    else:
+        bbox_feats = bbox_roi_extractor(feats, rois, valid=valid)
+    cls_score, bbox_pred = bbox_head(bbox_feats)
+    losses.update(bbox_head.loss(cls_score, bbox_pred, labels, buf.targets, buf.pos, valid, rois=rois))
+    rv = rois.view(nimg, num, 5)
+    state = dict(rois=[rv[i, :, 1:] for i in range(nimg)], labels=labels, cls_score=cls_score, bbox_pred=bbox_pred,
+                 valid=list(valid.view(nimg, num).unbind(0)), pos_is_gt=list(buf.is_gt.view(nimg, num).unbind(0)))
+    if with_mask:
+        if mask_feats is None:
+            mask_feats = mask_roi_extractor(x[:mask_roi_extractor.num_inputs], buf.feat_rois, valid=buf.mvalid)
+        rows_path = hasattr(mask_head, 'forward_rows') and mask_feats.size(0) > 0
+        mask_pred = mask_head.forward_rows(mask_feats) if rows_path else mask_head(mask_feats)
+        size = cfg.get('mask_size', 28)
+        size = (size, size) if isinstance(size, int) else tuple(size)
+        if stacked:
+            m = (gt_masks[0] if nimg == 1 else torch.cat(list(gt_masks), 0)).to(torch.bfloat16)[:, None]     # 0/1 exact in bf16
+            tg = (ops.roi_align(m, buf.mask_rois, size, 1.0, 0, 'avg', True)[:, 0] >= 0.5).float()
+        else:
+            mr = buf.mask_rois.view(nimg, km, 5)
+            tg = torch.cat([(ops.roi_align(gt_masks[i].to(torch.bfloat16)[:, None].contiguous(), mr[i], size, 1.0, 0, 'avg',
+                                           True)[:, 0] >= 0.5).float() for i in range(nimg)])
+        loss_fn = mask_head.loss_rows if rows_path else mask_head.loss
+        losses.update(loss_fn(mask_pred, tg, buf.mlabels, buf.mvalid))
+    return losses, state
+
+
+_ONES_BOOL = {}
+_PACKED_STAGE = True          # False: _roi_stage_train's per-op body also on the GPU (A/B, tests)
+
+
+def _ones_bool(n, device):
+    """a cached all-True (n,) mask (constant: read only)"""
+    k = (str(device), )
+    t = _ONES_BOOL.get(k)
+    if t is None or t.numel() < n:
+        t = _ONES_BOOL[k] = torch.ones(max(n, 256), dtype=torch.bool, device=device)
+    return t[:n]
 
 
 @HEADS.register_module()

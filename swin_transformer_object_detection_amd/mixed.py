@@ -6,6 +6,9 @@ per step (cast, cast-backward, gradient accumulate); here all shadows live in ON
 refreshed from the masters with a single multi-tensor copy after the optimizer step, and the shadows are
 the autograd leaves (their bf16 gradients are gathered into the flat fp32 gradient buckets by ``ddp.py``).
 """
+import contextlib
+import os
+
 import torch
 
 _SHADOW = {}          # id(master parameter) -> bf16 leaf tensor (a view of the flat shadow buffer)
@@ -30,6 +33,78 @@ def clear_sinks(ids=None):
     else:
         for i in ids:
             _SINK.pop(i, None)
+
+
+# ---- second HIP stream for the weight-gradient kernels -------------------------------------------------------------
+# Weight gradients are leaves of the backward dependency graph: nothing on the device consumes them before the
+# all-reduce / optimizer.  Most backward kernels of this model are latency-bound (one block per CU, 20-40 us), so the
+# weight-gradient launches go to a second stream where they fill the idle issue slots of the data-gradient chain
+# (DESIGN section 5 "two streams").  Ordering: the side stream waits for an event recorded on the main stream after
+# the producing kernel (fork); the main stream waits for the side stream before a bucket is reduced and at
+# reducer.finish() (join).  Tensors the side stream reads are protected from reuse with Tensor.record_stream.
+_SIDE_ON = os.environ.get("SWIN_WGRAD_STREAM", "1") != "0"      # 0: everything on one stream (A/B)
+_SIDE = {}            # device index -> torch.cuda.Stream
+_SIDE_DIRTY = set()   # device indices with side-stream work since the last join
+
+
+def side_enabled():
+    return _SIDE_ON
+
+
+def set_side_enabled(on):
+    global _SIDE_ON
+    side_join()
+    _SIDE_ON = bool(on)
+
+
+def side_stream(device):
+    """The weight-gradient stream of ``device`` (created on first use), or None when the feature is off."""
+    if not _SIDE_ON or device.type != 'cuda':
+        return None
+    i = device.index if device.index is not None else torch.cuda.current_device()
+    s = _SIDE.get(i)
+    if s is None:
+        s = _SIDE[i] = torch.cuda.Stream(device=i)
+    return s
+
+
+def side_protect(device, *tensors):
+    """Tell the caching allocator that the side stream reads these tensors (their memory is not handed out again until
+    the side stream has passed the point of their release)."""
+    s = side_stream(device)
+    if s is None:
+        return
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(s)
+
+
+def side_mark(device):
+    i = device.index if device.index is not None else torch.cuda.current_device()
+    _SIDE_DIRTY.add(i)
+
+
+@contextlib.contextmanager
+def on_side(device, *tensors):
+    """Run the enclosed launches on the weight-gradient stream, after everything enqueued so far on the current
+    stream; ``tensors`` = what they read.  No-op (current stream) when the feature is off.  Reducer callbacks must be
+    made OUTSIDE this context (they may enqueue collectives relative to the current stream)."""
+    s = side_stream(device)
+    if s is None:
+        yield None
+        return
+    s.wait_stream(torch.cuda.current_stream(device))
+    side_protect(device, *tensors)
+    side_mark(device)
+    with torch.cuda.stream(s):
+        yield s
+
+
+def side_join():
+    """The current stream of every device with outstanding side-stream work waits for it."""
+    for i in list(_SIDE_DIRTY):
+        torch.cuda.current_stream(i).wait_stream(_SIDE[i])
+    _SIDE_DIRTY.clear()
 
 
 # ---- per-step caches and use counts ------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ current stream.  torch only provides device memory, streams and autograd
 bookkeeping.  There is deliberately no CPU / eager fallback: a tensor that is
 not on a GPU, or a missing library, raises.
 """
+import contextlib
 import ctypes
 import os
 
@@ -457,21 +458,33 @@ class _Conv3x3(torch.autograd.Function):
             if need_b:
                 dbf = bs[0] if bs is not None else torch.zeros(Cout, device=x.device, dtype=torch.float32)
             ensure_scratch(x.device)
-            call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), _p(dbf), N, H, W, Cin, Cout, _s())   # implicit im2col
             if ws is not None:
-                def finalize(ws=ws, bs=bs, dwf=dwf, w_master=w_master):
-                    ws[0].add_(dwf.permute(0, 3, 1, 2))
+                # sink mode: nothing on the main stream reads the result before the reducer -> weight-gradient stream
+                last = mixed.use_end(w_master) == 0
+                side_ok = bs is not None or not need_b        # a bias gradient returned through autograd is read on the main stream
+                with (mixed.on_side(x.device, dy, x) if side_ok else contextlib.nullcontext()):
+                    call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), _p(dbf), N, H, W, Cin, Cout, _s())
+                    if last:
+                        ws[0].add_(dwf.permute(0, 3, 1, 2))
+
+                def notify(ws=ws, bs=bs, w_master=w_master):
                     mixed.step_buffer_done(w_master, 'dw_khwc')
                     mixed.set_pending(w_master, None)
                     ws[1]()
                     if bs is not None:
                         bs[1]()
-                if mixed.use_end(w_master) == 0:
-                    finalize()
+                if last:
+                    notify()
                 else:
+                    def finalize(ws=ws, dwf=dwf, dev=x.device, notify=notify):     # a use whose backward never came
+                        with mixed.on_side(dev):
+                            ws[0].add_(dwf.permute(0, 3, 1, 2))
+                        notify()
                     mixed.set_pending(w_master, finalize)
-            elif need_w:
-                dw = dwf.permute(0, 3, 1, 2).to(weight.dtype)
+            else:
+                call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), _p(dbf), N, H, W, Cin, Cout, _s())   # implicit im2col
+                if need_w:
+                    dw = dwf.permute(0, 3, 1, 2).to(weight.dtype)
             if need_b and bs is None:
                 db = dbf
         elif ctx.counted:
@@ -557,7 +570,9 @@ class _LinearBf16(torch.autograd.Function):
             if need_b:
                 dbf = bs[0] if bs is not None else torch.zeros(N1, device=x.device, dtype=torch.float32)
             ensure_scratch(x2.device)
-            call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2, _s())
+            with (mixed.on_side(x2.device, dy2, x2) if ws is not None and (bs is not None or not need_b)
+                  else contextlib.nullcontext()):
+                call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2, _s())
             if ws is not None:
                 def finalize(ws=ws, bs=bs, w_master=w_master):
                     mixed.set_pending(w_master, None)

@@ -365,13 +365,25 @@ class _SwinBlockFn(torch.autograd.Function):
         ws_ln2 = _scratch(dev, 'ln2', ln_bytes)
         ws_ln3 = _scratch(dev, 'ln3', ln_bytes)
         gws = _scratch(dev, 'gemm', lib.swin_gemm_workspace_bytes())
-        ptrs = (ctypes.c_void_p * 55)(
+        # weight-gradient stream: only when every weight / bias accumulator of the four GEMMs is a reducer sink (a fresh
+        # buffer returned through autograd would be read on the main stream)
+        side = mixed.side_stream(dev)
+        if side is not None:
+            for q_ in (m_wqkv, m_wproj, m_w1, m_w2, bqkv, bproj, b1, b2):
+                if q_ is not None and q_.requires_grad and mixed.grad_sink(q_) is None:
+                    side = None
+                    break
+        if side is not None:
+            mixed.side_protect(dev, flat, qkv, n1, dx2, dnn if has_next else None)
+            mixed.side_mark(dev)
+        ptrs = (ctypes.c_void_p * 56)(
             _ptr(n1), _ptr(qkv), _ptr(bias_exp), _ptr(lse), _ptr(o), _ptr(x1), _ptr(mean2), _ptr(rstd2), _ptr(n2), _ptr(hpre),
             _ptr(h), _ptr(x2), _ptr(mean3), _ptr(rstd3), _ptr(dp0), _ptr(dp1), _ptr(wqkv), _ptr(wproj), _ptr(w1), _ptr(w2),
             _ptr(n2w), _ptr(nnw) if has_next else None, _ptr(b1), _ptr(qkv_bias), _ptr(dx2), _ptr(dnn) if has_next else None, _ptr(dx),
             _ptr(dn1), _ptr(dx1), _ptr(dy2), _ptr(dh), _ptr(dhpre), _ptr(dn2), _ptr(dy), _ptr(do), _ptr(dqkv), _ptr(dbexp),
             _ptr(a_wqkv), _ptr(a_bqkv), _ptr(a_bpad), _ptr(a_wproj), _ptr(a_bproj), _ptr(a_w1), _ptr(a_b1), _ptr(a_w2), _ptr(a_b2),
-            _ptr(a_n2w), _ptr(a_n2b), _ptr(a_nnw), _ptr(a_nnb), _ptr(a_tab), _ptr(ws_attn), _ptr(ws_ln2), _ptr(ws_ln3), _ptr(gws))
+            _ptr(a_n2w), _ptr(a_n2b), _ptr(a_nnw), _ptr(a_nnb), _ptr(a_tab), _ptr(ws_attn), _ptr(ws_ln2), _ptr(ws_ln3), _ptr(gws),
+            side.cuda_stream if side is not None else None)
         iv = (ctypes.c_int64 * 7)(B, H, W, C, nH, shift, 1 if getattr(ctx, 'fused_mlp', False) else 0)
         fv = (ctypes.c_float * 1)(scale)
         ensure_scratch(dev)

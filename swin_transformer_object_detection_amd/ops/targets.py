@@ -32,7 +32,9 @@ def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0,
         return assigned, max_ov, labels
     ws = torch.empty(_lib.lib().det_assign_workspace_bytes(n, g), dtype=torch.uint8, device=bboxes.device)
     gl = gt_labels.long().contiguous() if gt_labels is not None else None
-    vm = valid.to(torch.uint8).contiguous() if valid is not None else None
+    vm = None
+    if valid is not None:
+        vm = valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8).contiguous()
     call("det_max_iou_assign", _p(bboxes), n, _p(gt_bboxes) if g else None, g, _p(gl) if gl is not None and g else None,
          float(pos_iou_thr), float(neg_iou_thr), float(min_pos_iou), int(bool(match_low_quality)), int(num_leading_gt),
          _p(vm) if vm is not None else None, _p(assigned), _p(max_ov), _p(labels) if labels is not None else None, _p(ws), _s())
@@ -95,6 +97,45 @@ def bbox_targets(bboxes, inds, flags, assigned_gt_inds, gt_bboxes, means, stds, 
          _p(assigned_labels) if assigned_labels is not None else None, int(bg_label), _f4(means), _f4(stds), k, _p(boxes), _p(deltas),
          _p(gt_inds), _p(labels) if labels is not None else None, _s())
     return boxes, deltas, gt_inds, labels
+
+
+class RoiStageBuffers:
+    """Batch-level tensors of one R-CNN training stage (nimg images x ``num`` sample slots, the first ``km`` of each image
+    being its mask slots); ``roi_targets_pack`` fills one image's rows per launch."""
+
+    def __init__(self, nimg, num, km, device):
+        e = lambda *sh, dt=torch.float32: torch.empty(*sh, dtype=dt, device=device)      # noqa: E731
+        self.nimg, self.num, self.km = nimg, num, km
+        self.rois = e(nimg * num, 5)
+        self.targets = e(nimg * num, 4)
+        self.labels = e(nimg * num, dt=torch.long)
+        self.pos = e(nimg * num, dt=torch.bool)
+        self.valid = e(nimg * num, dt=torch.bool)
+        self.is_gt = e(nimg * num, dt=torch.bool)
+        self.feat_rois = e(nimg * km, 5)          # bbox2roi of the mask slots (RoI extractor input)
+        self.mask_rois = e(nimg * km, 5)          # [gt mask index (+ offset), clipped box] (crop_and_resize input)
+        self.mlabels = e(nimg * km, dt=torch.long)
+        self.mvalid = e(nimg * km, dt=torch.bool)
+
+
+def roi_targets_pack(buf, img, bboxes, inds, flags, assigned_gt_inds, gt_bboxes, means, stds, assigned_labels, bg_label,
+                     num_leading_gt, reg_decoded, gt_offset, mask_hw):
+    """Image ``img``'s rows of ``buf`` (RoiStageBuffers) from its fixed-size sample, one launch: the sampled boxes with the
+    image index column (bbox2roi), regression targets (bbox_head.py:140-186), labels, positive / used / pos_is_gt flags,
+    and for the mask slots the feature RoIs, the rows mask_target.py:95-107 hands to crop_and_resize (gt index + gt_offset,
+    box clipped to mask_hw = (h, w)), the labels clamped below the background label and the validity."""
+    k, km = buf.num, buf.km
+    if inds.numel() != k:
+        raise SwinHipError("roi_targets_pack: sample size differs from the buffers'")
+    g = gt_bboxes.size(0)
+    bb, gb = bboxes.detach().float().contiguous(), gt_bboxes.detach().float().contiguous()
+    r0, m0 = img * k, img * km
+    call("det_roi_targets_pack", _p(bb), _p(inds), _p(flags), _p(assigned_gt_inds), _p(gb) if g else None, g,
+         _p(assigned_labels) if assigned_labels is not None else None, int(bg_label), _f4(means), _f4(stds), k, int(img),
+         int(num_leading_gt), int(bool(reg_decoded)), _p(buf.rois[r0:]), _p(buf.targets[r0:]), _p(buf.labels[r0:]), _p(buf.pos[r0:]),
+         _p(buf.valid[r0:]), _p(buf.is_gt[r0:]), km, int(gt_offset), float(mask_hw[0]), float(mask_hw[1]),
+         _p(buf.feat_rois[m0:]) if km else None, _p(buf.mask_rois[m0:]) if km else None, _p(buf.mlabels[m0:]) if km else None,
+         _p(buf.mvalid[m0:]) if km else None, _s())
 
 
 def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None, wh_ratio_clip=16 / 1000):

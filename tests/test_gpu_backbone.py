@@ -276,6 +276,49 @@ def test_gradient_sinks_match_autograd(pkg):
         sh.release()
 
 
+def test_weight_gradient_stream_gives_the_same_gradients(pkg):
+    """mixed.on_side / swin_block_bwd table entry 55: with the weight-gradient kernels on the second HIP stream every
+    parameter's fp32 bucket gradient equals the one-stream run (same seeds; three steps, so a buffer handed out again
+    while the side stream still read it, or a bucket reduced before the side stream finished, would show)."""
+    from swin_transformer_object_detection_amd import data, ddp, detector, mixed, presets
+    cfg = presets.mask_rcnn_swin("tiny")
+    cfg["backbone"]["drop_path_rate"] = 0.0
+    torch.manual_seed(0)
+    model = detector.build_detector(cfg, compute_dtype=torch.bfloat16).cuda().train()
+    batch = data.synthetic_batch(2, 384, 512, torch.device("cuda"), seed=5, num_boxes=6)
+    sh = mixed.ShadowParams(model, torch.bfloat16)
+    red = ddp.BucketedGradReducer(model.parameters(), leaf_of=sh.leaf_of)
+    was = mixed.side_enabled()
+
+    def run(on):
+        mixed.set_side_enabled(on)
+        outs = []
+        for it in range(3):
+            torch.manual_seed(100 + it)
+            red.zero_grad()
+            loss, _ = model.parse_losses(model.forward_train(**batch))
+            loss.backward()
+            red.finish()
+            outs.append([b['flat'].clone() for b in red.buckets])
+        torch.cuda.synchronize()
+        return outs
+    try:
+        ref = run(False)
+        again = run(False)              # the run-to-run noise of the float atomics (RoIAlign backward feeds bf16 chains)
+        got = run(True)
+        assert mixed.side_stream(torch.device("cuda", 0)) is not None
+        for it in range(3):
+            for fr, fa, fg in zip(ref[it], again[it], got[it]):
+                scale = float(fr.abs().max())
+                noise = float((fr - fa).abs().max())
+                err = float((fr - fg).abs().max())
+                assert err <= 4 * noise + 2e-3 * scale + 1e-7, (it, err, noise, scale)
+    finally:
+        mixed.set_side_enabled(was)
+        red.release()
+        sh.release()
+
+
 # ------------------------------------------------------------------------------------------
 # test-time path (two_stage.py:187-204): kernels vs the oracle's callers on the model's own head outputs
 # ------------------------------------------------------------------------------------------

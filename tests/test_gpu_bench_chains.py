@@ -191,6 +191,95 @@ def test_mask_target_matches_reference_code_fixture(pkg):
     np.testing.assert_array_equal(out.cpu().numpy(), w["mt_out"][:props[0].size(0)])
 
 
+def test_roi_targets_pack_vs_oracle(pkg):
+    """ops.roi_targets_pack (one launch per image) == the reference's composition on the same sample: bbox2roi
+    (transforms.py:117-137), bbox2delta on the positives (delta_xywh_bbox_coder.py:82-130), labels / background
+    (bbox_head.py:158-186), pos_is_gt (sampling_result.py), the clipped crop_and_resize rows (mask_target.py:95-107),
+    the mask labels and validity; rows of the other image stay untouched."""
+    from swin_transformer_object_detection_amd import ops
+    rng = np.random.RandomState(11)
+    g, n, num, km, nc = 7, 1000, 512, 128, 80
+    W, H = 1280.0, 800.0
+    xy = rng.rand(g, 2) * [W * 0.6, H * 0.6]
+    gts = np.concatenate([xy, xy + rng.rand(g, 2) * [W * 0.35, H * 0.35] + 8], 1).astype(np.float32)
+    jit = gts[rng.randint(0, g, 300)] + rng.randn(300, 4).astype(np.float32) * 6        # boxes near the gts -> positives
+    xy = rng.rand(n - 300, 2) * [W, H] - 30
+    rnd = np.concatenate([xy, xy + rng.rand(n - 300, 2) * 300 + 2], 1).astype(np.float32)
+    props = np.concatenate([gts, jit, rnd], 0).astype(np.float32)
+    gl = rng.randint(0, nc, g).astype(np.int64)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()          # noqa: E731
+    assigned, _, lab = ops.max_iou_assign(t(props), t(gts), 0.5, 0.5, 0.5, False, t(gl), g, None)
+    inds, flags = ops.random_sample_raw(assigned, num, 0.25, seed=1234)
+    means, stds = (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2)
+    for reg_decoded in (False, True):
+        buf = ops.RoiStageBuffers(2, num, km, torch.device("cuda"))
+        for q in (buf.rois, buf.targets, buf.feat_rois, buf.mask_rois):
+            q.fill_(-7.0)
+        ops.roi_targets_pack(buf, 1, t(props), inds, flags, assigned, t(gts), means, stds, lab, nc, g, reg_decoded, 5, (H - 100, W - 200))
+        torch.cuda.synchronize()
+        i_, f_, a_ = inds.cpu().numpy(), flags.cpu().numpy(), assigned.cpu().numpy()
+        used, pos = (f_ & 1) > 0, (f_ & 2) > 0
+        assert pos.sum() > 20 and (~pos & used).sum() > 100
+        boxes = np.where(used[:, None], props[np.where(used, i_, 0)], np.array([[0, 0, 1, 1]], np.float32))
+        gi = np.where(used & (a_[np.where(used, i_, 0)] > 0), a_[np.where(used, i_, 0)] - 1, 0)
+        want_t = np.zeros((num, 4), np.float32)
+        if reg_decoded:
+            want_t = gts[gi]
+        else:
+            want_t[pos] = CO.bbox2delta(boxes[pos], gts[gi[pos]], means, stds)
+        want_lab = np.where(pos, gl[gi], nc)
+        r = buf.rois.cpu().numpy()
+        assert (r[:num] == -7.0).all(), "image 0's rows were written"
+        np.testing.assert_array_equal(r[num:, 0], 1.0)
+        np.testing.assert_array_equal(r[num:, 1:], boxes)
+        np.testing.assert_allclose(buf.targets.cpu().numpy()[num:], want_t, atol=1e-5, rtol=1e-5)
+        np.testing.assert_array_equal(buf.labels.cpu().numpy()[num:], want_lab)
+        np.testing.assert_array_equal(buf.pos.cpu().numpy()[num:], pos)
+        np.testing.assert_array_equal(buf.valid.cpu().numpy()[num:], used)
+        np.testing.assert_array_equal(buf.is_gt.cpu().numpy()[num:], pos & (i_ < g))
+        fr, mr = buf.feat_rois.cpu().numpy(), buf.mask_rois.cpu().numpy()
+        assert (fr[:km] == -7.0).all() and (mr[:km] == -7.0).all()
+        np.testing.assert_array_equal(fr[km:, 0], 1.0)
+        np.testing.assert_array_equal(fr[km:, 1:], boxes[:km])
+        np.testing.assert_array_equal(mr[km:, 0], gi[:km] + 5.0)
+        clip = boxes[:km].copy()
+        clip[:, 0::2] = np.clip(clip[:, 0::2], 0, W - 200)
+        clip[:, 1::2] = np.clip(clip[:, 1::2], 0, H - 100)
+        np.testing.assert_array_equal(mr[km:, 1:], clip)
+        np.testing.assert_array_equal(buf.mlabels.cpu().numpy()[km:], np.minimum(want_lab[:km], nc - 1))
+        np.testing.assert_array_equal(buf.mvalid.cpu().numpy()[km:], pos[:km])
+
+
+def test_roi_stage_packed_equals_per_op_stage(pkg):
+    """_roi_stage_train through the pack kernel gives the losses of the per-op composition (same sampler seeds)."""
+    from swin_transformer_object_detection_amd import data, detector, presets
+    torch.manual_seed(0)
+    model = detector.build_detector(presets.mask_rcnn_swin("tiny"), compute_dtype=torch.bfloat16).cuda().train()
+    batch = data.synthetic_batch(2, 384, 512, torch.device("cuda"), seed=5, num_boxes=6)
+    with torch.no_grad():
+        x = model.extract_feat(batch['img'])
+        props = [torch.cat([b_, b_ + 3.0, b_ * 0.9, torch.rand(300, 4, device="cuda") * 200 + torch.tensor([0., 0., 210., 170.], device="cuda")], 0)
+                 for b_ in batch['gt_bboxes']]
+        rh = model.roi_head
+        args = (x, props, batch['gt_bboxes'], batch['gt_labels'], batch['gt_masks'], rh.train_cfg, rh.bbox_roi_extractor, rh.bbox_head,
+                rh.mask_roi_extractor, rh.mask_head)
+        torch.manual_seed(77)
+        l_new, st_new = detector._roi_stage_train(*args)
+        try:
+            detector._PACKED_STAGE = False                 # the per-op body (what CPU tensors / images without gt boxes run)
+            torch.manual_seed(77)
+            l_old, st_old = detector._roi_stage_train(*args)
+        finally:
+            detector._PACKED_STAGE = True
+    assert set(l_new) == set(l_old)
+    for k in l_new:
+        np.testing.assert_allclose(float(l_new[k]), float(l_old[k]), rtol=1e-5, atol=1e-6, err_msg=k)
+    for a_, b_ in zip(st_new['rois'], st_old['rois']):
+        np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+    for a_, b_ in zip(st_new['pos_is_gt'], st_old['pos_is_gt']):
+        np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+
+
 # ------------------------------------------------------------------------------------- kernels at the bench's own sizes
 def oracle_attention_natural(qkv, qkv_bias, table, B, H, W, nH, shift):
     """Reference semantics on the natural grid: pad (padded tokens are 0 before the qkv Linear, so their q|k|v equal

@@ -132,6 +132,64 @@ def wgradp():
         print(f"conv3x3 fwd {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
 
 
+def overlap():
+    """would a second stream for the weight-gradient kernels pay?  A backward-like chain (data-gradient kernel, then the
+    weight-gradient kernel of the same layer) run in one stream vs with the weight gradients on a side stream."""
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+
+    def chain(pairs, reps, two):
+        ev = torch.cuda.Event()
+        for _ in range(reps):
+            for dg, wg in pairs:
+                dg()
+                if two:
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        wg()
+                else:
+                    wg()
+        if two:
+            main.wait_stream(side)
+
+    def report(name, pairs, reps=8):
+        a, _ = timeit(lambda: chain(pairs, reps, False), n=10)
+        b, _ = timeit(lambda: chain(pairs, reps, True), n=10)
+        print(f"{name:34s} one stream {a / reps:8.1f} us   two streams {b / reps:8.1f} us   ({a / b:4.2f}x)")
+
+    # stage-1 Swin linears (T = 128000): dgrad on the library, wgrad mine
+    T = 128000
+    pairs = []
+    for (N, K) in [(288, 96), (96, 96), (384, 96), (96, 384)]:
+        dy = torch.randn(T, N, device="cuda").bfloat16(); x = torch.randn(T, K, device="cuda").bfloat16()
+        w = torch.randn(N, K, device="cuda").bfloat16() * 0.02
+        dx = torch.empty(T, K, device="cuda", dtype=torch.bfloat16)
+        dw = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+        pairs.append((lambda dy=dy, w=w, dx=dx: torch.mm(dy, w, out=dx),
+                      lambda dy=dy, x=x, dw=dw, db=db, N=N, K=K: Fn.call("wgrad_linear_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), T, N, K, Fn._s())))
+    report("stage-1 linears dgrad + wgrad", pairs)
+    T = 8000
+    pairs = []
+    for (N, K) in [(1152, 384), (384, 384), (1536, 384), (384, 1536)]:
+        dy = torch.randn(T, N, device="cuda").bfloat16(); x = torch.randn(T, K, device="cuda").bfloat16()
+        w = torch.randn(N, K, device="cuda").bfloat16() * 0.02
+        dx = torch.empty(T, K, device="cuda", dtype=torch.bfloat16)
+        dw = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+        pairs.append((lambda dy=dy, w=w, dx=dx: torch.mm(dy, w, out=dx),
+                      lambda dy=dy, x=x, dw=dw, db=db, N=N, K=K: Fn.call("wgrad_linear_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), T, N, K, Fn._s())))
+    report("stage-3 linears dgrad + wgrad", pairs)
+    for (N, H, W) in [(2, 200, 320), (2, 100, 160), (2, 50, 80), (200, 14, 14)]:
+        dy = torch.randn(N, H, W, 256, device="cuda").bfloat16()
+        x = torch.randn(N, H, W, 256, device="cuda").bfloat16()
+        dw = torch.zeros(256, 3, 3, 256, device="cuda"); db = torch.zeros(256, device="cuda")
+        w = torch.randn(256, 3, 3, 256, device="cuda").bfloat16() * 0.02
+        dyv = dy.permute(0, 3, 1, 2)
+        pairs = [(lambda: Fn._conv3x3_raw(dyv, w, None, False),
+                  lambda: Fn.call("wgrad_conv3x3_nhwc_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), N, H, W, 256, 256, Fn._s()))]
+        report(f"conv3x3 {N}x{H}x{W} dgrad + wgrad", pairs)
+
+
 def rpn():
     """RPN proposal selection + decode (rpn_select.hip) at the five FPN shapes of 2x800x1280"""
     sizes = [(200, 320), (100, 160), (50, 80), (25, 40), (13, 20)]
