@@ -324,6 +324,20 @@ int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, int decon
                       const int64_t* labels, const uint8_t* valid, const float* out2, const float* grad_out, void* dpred,
                       int dtype, void* stream);
 
+/* conv3x3_nhwc_bf16_gated: conv3x3_nhwc_bf16 whose output is zeroed where gate (N,H,W,Cout) bf16 is not positive -- a data
+ *   gradient that already includes the ReLU backward (torch.ops.aten.threshold_backward) of the layer below, whose output
+ *   `gate` is (the conv -> ReLU -> conv chains of fcn_mask_head.py:73-104).
+ * narrow_dgrad_gated_bf16: dx (T,C) = [gate > 0] * dy (T,K) w (K,C) for K <= 64: data gradient of the RPN's 1x1 cls / reg
+ *   heads (rpn_head.py:41-47) fused with the ReLU backward of rpn_conv. */
+int conv3x3_nhwc_bf16_gated(const void* x, const void* w, const float* bias, const void* gate, void* y, int N, int H, int W,
+                            int Cin, int Cout, void* stream);
+int narrow_dgrad_gated_bf16(const void* dy, const void* w, const void* gate, void* dx, int64_t T, int K, int C, void* stream);
+
+/* conv_dgrad_layout_multi: for n 3x3 conv weights resident as (Cout,3,3,Cin) bf16, the (Cin,3,3,Cout) weights of their
+ *   data-gradient convolutions (rot180, in/out swapped: what conv_transpose / the reference's cudnn backward-data use
+ *   implicitly), all in one launch.  srcs / dsts / couts / cins are HOST arrays of n entries. */
+int conv_dgrad_layout_multi(const void* const* srcs, void* const* dsts, const int* couts, const int* cins, int n, void* stream);
+
 /* swin_block_fwd / swin_block_bwd: the whole SwinTransformerBlock (swin_transformer.py:204-255) and its backward as ONE
  * call each -- the library's own kernels launched in sequence from native code (csrc/block_runner.hip lists the
  * pointer-table layouts).  p: HOST array of device pointers, iv: {B,H,W,C,nH,shift}, fv: {scale[, eps]}.  No allocation,

@@ -233,12 +233,14 @@ class SwinTransformer(nn.Module):
                     probs += [blk.drop_path_prob, blk.drop_path_prob]
         if not probs:
             return
-        ck = (tuple(probs), str(device))
+        ck = (tuple(probs), str(device), B)
         if getattr(self, '_dp_keep_key', None) != ck:            # constant over training: one host->device copy, ever
-            self._dp_keep = 1.0 - torch.tensor(probs, device=device, dtype=torch.float32)[:, None]
+            keep = 1.0 - torch.tensor(probs, device=device, dtype=torch.float32)[:, None]
+            self._dp_keep = keep.expand(len(probs), B).contiguous()
+            self._dp_inv = 1.0 / keep
             self._dp_keep_key = ck
-        keep = self._dp_keep
-        f = torch.floor(keep + torch.rand(len(probs), B, device=device, dtype=torch.float32)) / keep
+        # floor(keep + U[0,1)) / keep of the reference (swin_transformer.py drop_path) == Bernoulli(keep) / keep: two launches
+        f = torch.bernoulli(self._dp_keep).mul_(self._dp_inv)
         self._dp_pool = list(f.unbind(0))
 
     def _block(self, x, n1, blk, B, H, W, next_norm, dp):

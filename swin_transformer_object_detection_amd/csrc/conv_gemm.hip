@@ -68,7 +68,8 @@ __device__ uint4 g_zero16[4];      // zero-initialised: source of padded 16-byte
 template <typename ALoader, bool RELU, int WM, int NBUF>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2 : 1)) : 1) void gemm_bf16_kernel(ALoader A, const bf16* __restrict__ Wt,
                                                                               const float* __restrict__ bias, bf16* __restrict__ C,
-                                                                              int64_t M, int Nn, int K, int mtiles, int ntiles) {
+                                                                              int64_t M, int Nn, int K, int mtiles, int ntiles,
+                                                                              const bf16* __restrict__ gate) {
     constexpr int TM = 64 * WM;                                          // tile rows (pixels)
     extern __shared__ __attribute__((aligned(16))) uint4 lds_raw[];      // [buf][A: TM*8 | W: BN*8]
     auto ldsA = [&](int buf) { return lds_raw + (size_t)buf * (TM + BN) * 8; };
@@ -251,6 +252,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
                     if (RELU) v = fmaxf(v, 0.f);
                     o[e] = (bf16)v;
                 }
+                if (gate) {                       // ReLU backward of the layer below: zero where its output was not positive
+                    const bf16x4 gt = *(const bf16x4*)(gate + m * Nn + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (!((float)gt[e] > 0.f)) o[e] = (bf16)0.f;
+                }
                 *(bf16x4*)(crow + n) = o;
             }
         }
@@ -274,13 +280,18 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
                     if (RELU) v = fmaxf(v, 0.f);
                     o[e] = (bf16)v;
                 }
+                if (gate) {
+                    const bf16x4 gt = *(const bf16x4*)(gate + m * Nn + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (!((float)gt[e] > 0.f)) o[e] = (bf16)0.f;
+                }
                 *(bf16x4*)(crow + n) = o;
             }
     }
 }
 
 template <typename ALoader, bool RELU, int WM, int NBUF>
-static int gemm_launch_wm(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, hipStream_t s) {
+static int gemm_launch_wm(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, hipStream_t s, const bf16* gate) {
     constexpr int TM = 64 * WM;
     const size_t lds_bytes = NBUF * (size_t)(TM + BN) * 8 * sizeof(uint4);
     static bool attr_set[16] = {};                           // per device
@@ -293,36 +304,37 @@ static int gemm_launch_wm(ALoader A, const bf16* Wt, const float* bias, bf16* C,
         attr_set[dev] = true;
     }
     int mtiles = (int)((M + TM - 1) / TM), ntiles = (Nn + BN - 1) / BN;
-    gemm_bf16_kernel<ALoader, RELU, WM, NBUF><<<mtiles * ntiles, 128 * WM, lds_bytes, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles);
+    gemm_bf16_kernel<ALoader, RELU, WM, NBUF><<<mtiles * ntiles, 128 * WM, lds_bytes, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles, gate);
     return swin_launch_status();
 }
 
 static int g_conv_wm = 0;     // 0: choose by size; 2 / 4: forced (A/B experiments through SWIN_CONV_WM)
 
 template <typename ALoader>
-static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, int relu, hipStream_t s) {
+static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, int relu, hipStream_t s,
+                       const bf16* gate = nullptr) {
     static bool env_read = false;
     if (!env_read) { const char* e = getenv("SWIN_CONV_WM"); if (e) g_conv_wm = atoi(e); env_read = true; }
     // large pixel counts: the 256-row tile (one 8-wave block per CU); otherwise the 128-row tile keeps the grid full
     const int64_t blocks128 = ((M + 127) / 128) * ((Nn + BN - 1) / BN);
     const bool big = g_conv_wm == 4;   // (measured: no gain over the 128-row tile, kept for experiments)
     if (big) {
-        if (relu) return gemm_launch_wm<ALoader, true, 4, 2>(A, Wt, bias, C, M, Nn, K, s);
-        return gemm_launch_wm<ALoader, false, 4, 2>(A, Wt, bias, C, M, Nn, K, s);
+        if (relu) return gemm_launch_wm<ALoader, true, 4, 2>(A, Wt, bias, C, M, Nn, K, s, gate);
+        return gemm_launch_wm<ALoader, false, 4, 2>(A, Wt, bias, C, M, Nn, K, s, gate);
     }
     // enough tiles for several blocks per CU: ONE LDS buffer (32 KB, two barriers per K-tile) at 4 blocks per CU -- the
     // co-resident blocks overlap each other's DMA and MFMA phases better than a block's own double buffer does
     // (P2 map: 535 -> 663 TFLOP/s, mask-head convs: 399 -> 593); few tiles: the double-buffered block hides more itself
     if (g_conv_wm == 1 || (g_conv_wm == 0 && blocks128 > 512)) {
-        if (relu) return gemm_launch_wm<ALoader, true, 2, 1>(A, Wt, bias, C, M, Nn, K, s);
-        return gemm_launch_wm<ALoader, false, 2, 1>(A, Wt, bias, C, M, Nn, K, s);
+        if (relu) return gemm_launch_wm<ALoader, true, 2, 1>(A, Wt, bias, C, M, Nn, K, s, gate);
+        return gemm_launch_wm<ALoader, false, 2, 1>(A, Wt, bias, C, M, Nn, K, s, gate);
     }
     if (g_conv_wm == 3 || (g_conv_wm == 0 && blocks128 <= 256)) {      // at most one block per CU: 4-buffer DMA ring
-        if (relu) return gemm_launch_wm<ALoader, true, 2, 4>(A, Wt, bias, C, M, Nn, K, s);
-        return gemm_launch_wm<ALoader, false, 2, 4>(A, Wt, bias, C, M, Nn, K, s);
+        if (relu) return gemm_launch_wm<ALoader, true, 2, 4>(A, Wt, bias, C, M, Nn, K, s, gate);
+        return gemm_launch_wm<ALoader, false, 2, 4>(A, Wt, bias, C, M, Nn, K, s, gate);
     }
-    if (relu) return gemm_launch_wm<ALoader, true, 2, 2>(A, Wt, bias, C, M, Nn, K, s);
-    return gemm_launch_wm<ALoader, false, 2, 2>(A, Wt, bias, C, M, Nn, K, s);
+    if (relu) return gemm_launch_wm<ALoader, true, 2, 2>(A, Wt, bias, C, M, Nn, K, s, gate);
+    return gemm_launch_wm<ALoader, false, 2, 2>(A, Wt, bias, C, M, Nn, K, s, gate);
 }
 
 // x (N,H,W,Cin) bf16 channels-last; w (Cout,3,3,Cin) bf16; bias (Cout) f32 or NULL; y (N,H,W,Cout) bf16.
@@ -333,5 +345,17 @@ extern "C" int conv3x3_nhwc_bf16(const void* x, const void* w, const float* bias
     int64_t M = (int64_t)N * H * W;
     ConvA A{(const bf16*)x, M, ConvGeom{N, H, W, Cin}, Cin / BK};
     return gemm_launch(A, (const bf16*)w, bias, (bf16*)y, M, Cout, 9 * Cin, relu, (hipStream_t)stream);
+}
+
+// The same convolution with its output zeroed wherever gate (N,H,W,Cout) bf16 is not positive: used for data gradients,
+// gate = the ReLU output that was this convolution's input in the forward pass, so the result is already the gradient
+// at the ReLU's INPUT (torch: threshold_backward, one more pass over the map).
+extern "C" int conv3x3_nhwc_bf16_gated(const void* x, const void* w, const float* bias, const void* gate, void* y, int N, int H,
+                                       int W, int Cin, int Cout, void* stream) {
+    if (!x || !w || !y || !gate || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SWIN_ERR_BAD_ARG;
+    if (Cin % BK != 0 || Cout % 4 != 0) return SWIN_ERR_UNSUPPORTED;
+    int64_t M = (int64_t)N * H * W;
+    ConvA A{(const bf16*)x, M, ConvGeom{N, H, W, Cin}, Cin / BK};
+    return gemm_launch(A, (const bf16*)w, bias, (bf16*)y, M, Cout, 9 * Cin, 0, (hipStream_t)stream, (const bf16*)gate);
 }
 

@@ -378,3 +378,134 @@ extern "C" int fpn_upsample_add_bwd(const void* dfine, void* dcoarse, int N, int
     if (dtype == SWIN_F32) return upsample_launch<float>((void*)dfine, dcoarse, N, C, Hf, Wf, Hc, Wc, channels_last, true, (hipStream_t)stream);
     return SWIN_ERR_UNSUPPORTED;
 }
+
+// ------------------------------------------------------------------------------------
+// Weights of the data-gradient convolution for a batch of 3x3 conv weights, one launch: dst[ci][2-ky][2-kx][co] =
+// src[co][ky][kx][ci] (bf16; src = the resident (Cout,3,3,Cin) layout).  The data gradient of y = conv(x, w) is
+// conv(dy, rot180(w) with in/out swapped) (the same implicit-GEMM kernel); with torch this re-layout cost a flip and a
+// permuted copy per layer and step.  One 32x32 (co, ci) tile per block through LDS: both sides move whole 64-byte rows.
+// ------------------------------------------------------------------------------------
+#define DGL_MAX 16
+struct DgradLayoutTable {
+    const bf16* src[DGL_MAX];
+    bf16* dst[DGL_MAX];
+    int co[DGL_MAX], ci[DGL_MAX], tile0[DGL_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void conv_dgrad_layout_kernel(DgradLayoutTable t) {
+    __shared__ bf16 tile[32][34];
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.tile0[k + 1]) ++k;
+    const int co = t.co[k], ci = t.ci[k];
+    const int tci = (ci + 31) / 32, tco = (co + 31) / 32;
+    int id = blockIdx.x - t.tile0[k];
+    const int tap = id / (tci * tco); id -= tap * (tci * tco);
+    const int co0 = (id / tci) * 32, ci0 = (id % tci) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bf16* src = t.src[k];
+    bf16* dst = t.dst[k];
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int o = co0 + r, i = ci0 + tx;
+        if (o < co && i < ci) tile[r][tx] = src[((size_t)o * 9 + tap) * ci + i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int i = ci0 + r, o = co0 + tx;
+        if (o < co && i < ci) dst[((size_t)i * 9 + (8 - tap)) * co + o] = tile[tx][r];
+    }
+}
+
+// srcs / dsts: HOST arrays of n device pointers; couts / cins: HOST arrays of n ints.
+extern "C" int conv_dgrad_layout_multi(const void* const* srcs, void* const* dsts, const int* couts, const int* cins, int n,
+                                       void* stream) {
+    if (n == 0) return SWIN_OK;
+    if (!srcs || !dsts || !couts || !cins || n < 0) return SWIN_ERR_BAD_ARG;
+    for (int base = 0; base < n; base += DGL_MAX) {
+        DgradLayoutTable t;
+        t.n = n - base < DGL_MAX ? n - base : DGL_MAX;
+        int tiles = 0;
+        for (int k = 0; k < t.n; ++k) {
+            if (!srcs[base + k] || !dsts[base + k] || couts[base + k] <= 0 || cins[base + k] <= 0) return SWIN_ERR_BAD_ARG;
+            t.src[k] = (const bf16*)srcs[base + k]; t.dst[k] = (bf16*)dsts[base + k];
+            t.co[k] = couts[base + k]; t.ci[k] = cins[base + k];
+            t.tile0[k] = tiles;
+            tiles += 9 * ((t.co[k] + 31) / 32) * ((t.ci[k] + 31) / 32);
+        }
+        t.tile0[t.n] = tiles;
+        conv_dgrad_layout_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(t);
+        int st = swin_launch_status();
+        if (st != SWIN_OK) return st;
+    }
+    return SWIN_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Data gradient of a narrow head behind a ReLU: dx[t][c] = gate[t][c] > 0 ? sum_k dy[t][k] w[k][c] : 0 with K <= 64
+// (the RPN's fused cls | reg 1x1 heads, rpn_head.py:41-47: K = 5A padded to 16, C = 256; gate = the ReLU output of
+// rpn_conv).  As a GEMM this is 16 deep -- a bandwidth problem, not a matrix-core one: the weights sit in LDS as fp32, a
+// thread owns one 16-byte piece of four consecutive tokens, and the ReLU backward of the layer below (torch:
+// threshold_backward, another pass over the (T, C) map) is the store predicate.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void narrow_dgrad_gated_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ w,
+                                                                 const bf16* __restrict__ gate, bf16* __restrict__ dx, int64_t T,
+                                                                 int K, int C) {
+    extern __shared__ float wl[];                 // [K][C]
+    for (int i = threadIdx.x; i < K * C; i += 256) wl[i] = (float)w[i];
+    __syncthreads();
+    const int cpt = C / 8;
+    const int64_t groups = (T + 3) / 4, total = groups * cpt;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t t0 = (idx / cpt) * 4;
+        const int c0 = (int)(idx % cpt) * 8;
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            bf16x8 d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t t = t0 + q < T ? t0 + q : T - 1;
+                d[q] = *(const bf16x8*)(dy + t * K + k0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 w0 = *(const float4*)(wl + (k0 + j) * C + c0), w1 = *(const float4*)(wl + (k0 + j) * C + c0 + 4);
+                const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float dv = (float)d[q][j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[q][e] = fmaf(dv, wr[e], acc[q][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (t0 + q >= T) break;
+            const bf16x8 g = *(const bf16x8*)(gate + (t0 + q) * C + c0);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (float)g[e] > 0.f ? (bf16)acc[q][e] : (bf16)0.f;
+            *(bf16x8*)(dx + (t0 + q) * C + c0) = o;
+        }
+    }
+}
+
+// dy (T,K) bf16, w (K,C) bf16, gate (T,C) bf16 -> dx (T,C) bf16.  K % 8 == 0, K <= 64, C % 8 == 0, K*C*4 <= 64 KB.
+extern "C" int narrow_dgrad_gated_bf16(const void* dy, const void* w, const void* gate, void* dx, int64_t T, int K, int C,
+                                       void* stream) {
+    if (T == 0) return SWIN_OK;
+    if (!dy || !w || !gate || !dx || T < 0 || K <= 0 || C <= 0) return SWIN_ERR_BAD_ARG;
+    if (K % 8 != 0 || K > 64 || C % 8 != 0 || (size_t)K * C * sizeof(float) > 65536) return SWIN_ERR_UNSUPPORTED;
+    const int64_t total = ((T + 3) / 4) * (C / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    narrow_dgrad_gated_kernel<<<(unsigned)blocks, 256, (size_t)K * C * sizeof(float), (hipStream_t)stream>>>(
+        (const bf16*)dy, (const bf16*)w, (const bf16*)gate, (bf16*)dx, T, K, C);
+    return swin_launch_status();
+}

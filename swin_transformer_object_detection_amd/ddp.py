@@ -80,8 +80,9 @@ class BucketedGradReducer:
         n = sum(p.numel() for p in plist)
         flat = torch.zeros(n, device=plist[0].device, dtype=torch.float32)
         views, off = [], 0
+        from .mixed import dense_view
         for p in plist:
-            views.append(flat[off:off + p.numel()].view_as(p))
+            views.append(dense_view(flat, off, p))          # the parameter's shape AND memory layout (contiguous / channels-last)
             off += p.numel()
         leaves = [self.leaf_of(p) for p in plist]
         b = dict(flat=flat, params=list(plist), leaves=leaves, views=views, pending=len(plist), handle=None,
@@ -216,7 +217,9 @@ class BucketedGradReducer:
         """Initial parameter sync (DDP does the same at construction)."""
         if self.world > 1:
             for p in self.params:
-                dist.broadcast(p.data, src, group=self.group)
+                d = p.data
+                # a channels-last resident conv weight: broadcast its memory as the contiguous (Cout,3,3,Cin) tensor it is
+                dist.broadcast(d if d.is_contiguous() else d.permute(0, 2, 3, 1), src, group=self.group)
 
 
 def reduce_log_vars(log_vars, group=None):

@@ -250,12 +250,17 @@ def assign_and_sample(bboxes, gt_bboxes, a_cfg, s_cfg, means, stds, gt_labels=No
     return boxes, deltas, labels, gt_inds, is_pos, ok, idx, ok.to(torch.uint8) + 2 * is_pos.to(torch.uint8)
 
 
+def _scaled(x, w):
+    """x * loss_weight without the two launches (forward and backward) of a multiplication by one"""
+    return x if w == 1.0 else x * w
+
+
 def _cast(t, dtype):
     """compute-dtype view of a tensor; parameters resolve to their bf16 shadow (mixed.py)"""
     return mixed.weight(t, dtype)
 
 
-def _conv(x, conv, dtype, padding=0, relu=False):
+def _conv(x, conv, dtype, padding=0, relu=False, x_is_relu=False):
     """conv on a channels-last activation.  1x1 convs are GEMMs over the token-major view (no conv
     library involved); 3x3 convs go to the conv library with PACKED channels-last operands (a strided
     view silently selects MIOpen's naive reference kernels)."""
@@ -264,8 +269,8 @@ def _conv(x, conv, dtype, padding=0, relu=False):
         tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
         y = ops.linear(tok, conv.weight, conv.bias, dtype)           # weight/bias gradients on the split-T kernel
         y = y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
-    elif dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and padding == 1 and C % 64 == 0:
-        return ops.conv3x3(x, conv.weight, conv.bias, relu)  # HIP implicit-GEMM kernel (ReLU fused)
+    elif dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and padding == 1 and C % 64 == 0 and conv.out_channels % 64 == 0:
+        return ops.conv3x3(x, conv.weight, conv.bias, relu, x_is_relu=x_is_relu)  # HIP implicit-GEMM kernel (ReLU fused)
     else:
         x = x.contiguous(memory_format=torch.channels_last)
         w = _cast(conv.weight, dtype).contiguous(memory_format=torch.channels_last)
@@ -393,10 +398,11 @@ class _RpnHeads(torch.autograd.Function):
     masters) only so that autograd routes gradients to them."""
 
     @staticmethod
-    def forward(ctx, tok, w_cat, b_cat, head, wc_leaf, wr_leaf, bc_leaf, br_leaf):
+    def forward(ctx, tok, w_cat, b_cat, head, wc_leaf, wr_leaf, bc_leaf, br_leaf, relu_input=False):
         from .ops.functional import gemm_bf16
         ctx.save_for_backward(tok, w_cat)
         ctx.head = head
+        ctx.relu_input = bool(relu_input)      # tok is a ReLU output (rpn_conv + ReLU, rpn_head.py:44): see backward
         ctx.dts = (wc_leaf.dtype, wr_leaf.dtype, bc_leaf.dtype, br_leaf.dtype)
         ctx.counted = any(ctx.needs_input_grad)
         if ctx.counted:
@@ -411,15 +417,24 @@ class _RpnHeads(torch.autograd.Function):
         head = ctx.head
         A = head.num_anchors
         dy = dy.contiguous()
-        dx = gemm_bf16(dy, w_cat, None, b_is_kn=True) if ctx.needs_input_grad[0] else None
-        key = head.rpn_cls.weight
         N1, C = w_cat.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if (ctx.relu_input and tok.is_contiguous() and N1 % 8 == 0 and N1 <= 64 and C % 8 == 0 and N1 * C * 4 <= 65536):
+                # a 16-deep "GEMM" is a bandwidth problem: one pass that also applies rpn_conv's ReLU backward (the 3x3 conv's
+                # backward finds the gradient marked as gated and skips its threshold_backward launch)
+                dx = torch.empty_like(tok)
+                call("narrow_dgrad_gated_bf16", _p(dy), _p(w_cat), _p(tok), _p(dx), dy.shape[0], N1, C, _s())
+                mixed.gated_mark(dx, tok)
+            else:
+                dx = gemm_bf16(dy, w_cat, None, b_is_kn=True)
+        key = head.rpn_cls.weight
         dwb = mixed.step_buffer(key, 'rpn_dw', (N1, C), tok.device)
         dbb = mixed.step_buffer(key, 'rpn_db', (N1,), tok.device)
         ensure_scratch(tok.device)
         call("wgrad_linear_bf16", _p(dy), _p(tok.contiguous()), _p(dwb), _p(dbb), dy.shape[0], N1, C, _s())
         if mixed.use_end(key) > 0:
-            return dx, None, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None
         # last level: hand the accumulated gradients to the four parameters
         mixed.step_buffer_done(key, 'rpn_dw'); mixed.step_buffer_done(key, 'rpn_db')
         parts = ((head.rpn_cls.weight, dwb[:A].view(A, C, 1, 1)), (head.rpn_reg.weight, dwb[A:5 * A].view(4 * A, C, 1, 1)),
@@ -433,7 +448,7 @@ class _RpnHeads(torch.autograd.Function):
                 outs.append(None)
             else:
                 outs.append(g.to(dt_).clone())
-        return (dx, None, None, None) + tuple(outs)
+        return (dx, None, None, None) + tuple(outs) + (None,)
 
 
 @HEADS.register_module()
@@ -496,8 +511,9 @@ class RPNHead(nn.Module):
                 N, C, H, W = x.shape
                 tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
                 if fused:
-                    y = _RpnHeads.apply(tok, w, b, self, _cast(self.rpn_cls.weight, dt), _cast(self.rpn_reg.weight, dt),
-                                        self.rpn_cls.bias, self.rpn_reg.bias).view(N, H, W, -1)
+                    # the four leaves only route gradients (no cast: a parameter without a shadow is passed as it is)
+                    y = _RpnHeads.apply(tok, w, b, self, mixed.leaf(self.rpn_cls.weight), mixed.leaf(self.rpn_reg.weight),
+                                        self.rpn_cls.bias, self.rpn_reg.bias, True).view(N, H, W, -1)
                 else:
                     y = ops.linear(tok, w, b, dt).view(N, H, W, -1)
                 cls.append(y[..., :A].permute(0, 3, 1, 2))
@@ -549,13 +565,22 @@ class RPNHead(nn.Module):
             for i in range(B):
                 h, w = img_shapes[i][:2]
                 inside[i] = ((anchors[:, 0] >= -ab) & (anchors[:, 1] >= -ab) & (anchors[:, 2] < w + ab) & (anchors[:, 3] < h + ab))
-        samples = [assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg, self.means, self.stds, valid=inside[i]) for i in range(B)]
         beta = self.loss_bbox_beta
         if cls.is_cuda:
-            # both losses, over all images, in one forward and one backward launch (csrc/det_losses.hip)
-            lc, lb = ops.rpn_loss(cls, reg, torch.stack([s_[6] for s_ in samples]), torch.stack([s_[7] for s_ in samples]),
-                                  torch.stack([s_[1] for s_ in samples]), beta)
-            return dict(loss_rpn_cls=lc * self.loss_cls_weight, loss_rpn_bbox=lb * self.loss_bbox_weight)
+            # assign -> sample -> encode per image, each kernel writing its row of the batch-level tensors; then both losses, over
+            # all images, in one forward and one backward launch (csrc/det_losses.hip)
+            num = s_cfg['num']
+            inds = torch.empty(B, num, dtype=torch.long, device=cls.device)
+            flags = torch.empty(B, num, dtype=torch.uint8, device=cls.device)
+            tgts = torch.empty(B, num, 4, dtype=torch.float32, device=cls.device)
+            for i in range(B):
+                assigned, _, _ = ops.max_iou_assign(anchors, gt_bboxes[i], a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'], a_cfg['min_pos_iou'],
+                                                    a_cfg.get('match_low_quality', True), None, 0, inside[i])
+                ops.random_sample_raw(assigned, num, s_cfg['pos_fraction'], out=(inds[i], flags[i]))
+                ops.bbox_targets(anchors, inds[i], flags[i], assigned, gt_bboxes[i], self.means, self.stds, out_deltas=tgts[i])
+            lc, lb = ops.rpn_loss(cls, reg, inds, flags, tgts, beta)
+            return dict(loss_rpn_cls=_scaled(lc, self.loss_cls_weight), loss_rpn_bbox=_scaled(lb, self.loss_bbox_weight))
+        samples = [assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg, self.means, self.stds, valid=inside[i]) for i in range(B)]
         loss_cls = loss_bbox = total = 0.
         for i in range(B):
             _, tgt, _, _, is_pos, valid, idx, _ = samples[i]
@@ -795,22 +820,24 @@ class ConvFCBBoxHead(nn.Module):
         reg = F.linear(x, _cast(self.fc_reg.weight, dt), _cast(self.fc_reg.bias, dt))
         return cls, reg
 
-    def loss(self, cls_score, bbox_pred, labels, bbox_targets, pos_mask, valid=None, rois=None):
+    def loss(self, cls_score, bbox_pred, labels, bbox_targets, pos_mask, valid=None, rois=None, flags=None):
         """bbox_head.py:188-238: CE over the sampled RoIs (avg_factor = their count); on the positives -- divided by the
         number of samples -- L1 / SmoothL1 between the labelled (or class-agnostic) deltas and the encoded targets, or
         (reg_decoded_bbox) GIoU between the boxes decoded against ``rois`` (n,4) and the gt boxes in ``bbox_targets``.
-        ``valid`` masks the unused slots of a fixed-size sample."""
+        ``valid`` masks the unused slots of a fixed-size sample; ``flags`` (n,) uint8 = valid + 2 * (pos_mask & valid) when the
+        caller already has it."""
         n = cls_score.size(0)
         if valid is None:
             valid = torch.ones(n, dtype=torch.bool, device=cls_score.device)
         if self.reg_decoded_bbox and rois is None:
             raise ValueError("reg_decoded_bbox=True: loss() needs the sampled rois")
         if cls_score.is_cuda and n > 0:
-            flags = valid.to(torch.uint8) + 2 * (pos_mask & valid).to(torch.uint8)
+            if flags is None:                       # (the packed training path hands over the sampler's own flag bytes)
+                flags = valid.to(torch.uint8) + 2 * (pos_mask & valid).to(torch.uint8)
             giou = (rois[:, -4:], self.means, self.stds, self.giou_eps) if self.reg_decoded_bbox else None
             lc, acc, lb = ops.bbox_loss(cls_score, bbox_pred, labels, bbox_targets, flags, self.num_classes,
                                         self.reg_class_agnostic, self.reg_beta, giou)
-            return dict(loss_cls=lc * self.loss_cls_weight, acc=acc, loss_bbox=lb * self.loss_bbox_weight)
+            return dict(loss_cls=_scaled(lc, self.loss_cls_weight), acc=acc, loss_bbox=_scaled(lb, self.loss_bbox_weight))
         cls_score, bbox_pred = cls_score.float(), bbox_pred.float()
         nv = valid.sum().clamp(min=1).float()
         ce = F.cross_entropy(cls_score, labels, reduction='none')
@@ -909,8 +936,8 @@ class FCNMaskHead(nn.Module):
     def forward(self, x):
         dt = self.compute_dtype
         x = _cast(x, dt).contiguous(memory_format=torch.channels_last)
-        for c in self.convs:
-            x = _conv(x, c.conv, dt, padding=1, relu=True)
+        for i, c in enumerate(self.convs):
+            x = _conv(x, c.conv, dt, padding=1, relu=True, x_is_relu=i > 0)
         x = self._deconv2x2_relu(x, dt)
         return _conv(x, self.conv_logits, dt)
 
@@ -939,15 +966,15 @@ class FCNMaskHead(nn.Module):
         directly.  forward(x)[n, c, 2y+ky, 2x+kx] == forward_rows(x)[((n*H + y)*W + x)*4 + ky*2 + kx, c]."""
         dt = self.compute_dtype
         x = _cast(x, dt).contiguous(memory_format=torch.channels_last)
-        for c in self.convs:
-            x = _conv(x, c.conv, dt, padding=1, relu=True)
+        for i, c in enumerate(self.convs):             # conv -> ReLU chain: from the second on, the input is a ReLU output
+            x = _conv(x, c.conv, dt, padding=1, relu=True, x_is_relu=i > 0)
         Co = self.upsample.out_channels
         rows = self._deconv_rows(x, dt).view(-1, Co)                                   # (P*H*W*4, Co)
         return ops.linear(rows, self.conv_logits.weight, self.conv_logits.bias, dt)    # (P*H*W*4, num_classes)
 
     def loss_rows(self, rows, mask_targets, labels, valid):
         """loss() on forward_rows() output (GPU)."""
-        return dict(loss_mask=ops.mask_loss(rows, mask_targets, labels, valid, deconv_order=True) * self.loss_mask_weight)
+        return dict(loss_mask=_scaled(ops.mask_loss(rows, mask_targets, labels, valid, deconv_order=True), self.loss_mask_weight))
 
     def loss(self, mask_pred, mask_targets, labels, valid=None):
         """mask_cross_entropy (cross_entropy_loss.py): mean BCE over (positives x 28 x 28) of the class channel."""
@@ -956,7 +983,7 @@ class FCNMaskHead(nn.Module):
             return dict(loss_mask=mask_pred.sum() * 0)
         if mask_pred.is_cuda:
             v = valid if valid is not None else torch.ones(n, dtype=torch.bool, device=mask_pred.device)
-            return dict(loss_mask=ops.mask_loss(mask_pred, mask_targets, labels, v) * self.loss_mask_weight)
+            return dict(loss_mask=_scaled(ops.mask_loss(mask_pred, mask_targets, labels, v), self.loss_mask_weight))
         pred = mask_pred.float()[torch.arange(n, device=mask_pred.device), labels]
         per_roi = F.binary_cross_entropy_with_logits(pred, mask_targets, reduction='none').mean(dim=(1, 2))
         if valid is None:
@@ -1122,7 +1149,7 @@ def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cf
         lead = g if add_gt else 0
         assigned, _, lab = ops.max_iou_assign(props, gt_bboxes[i], a['pos_iou_thr'], a['neg_iou_thr'], a['min_pos_iou'],
                                               a.get('match_low_quality', True), gt_labels[i], lead, pvalid)
-        inds, flags = ops.random_sample_raw(assigned, num, s['pos_fraction'])
+        inds, flags = ops.random_sample_raw(assigned, num, s['pos_fraction'], out=(buf.inds[i], buf.flags[i]))
         mh, mw = (gt_masks[i].shape[1:] if with_mask else (0, 0))
         ops.roi_targets_pack(buf, i, props, inds, flags, assigned, gt_bboxes[i], bbox_head.means, bbox_head.stds, lab, nc, lead,
                              bbox_head.reg_decoded_bbox, off if stacked else 0, (mh, mw))
@@ -1137,7 +1164,7 @@ def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cf
     else:
         bbox_feats = bbox_roi_extractor(feats, rois, valid=valid)
     cls_score, bbox_pred = bbox_head(bbox_feats)
-    losses.update(bbox_head.loss(cls_score, bbox_pred, labels, buf.targets, buf.pos, valid, rois=rois))
+    losses.update(bbox_head.loss(cls_score, bbox_pred, labels, buf.targets, buf.pos, valid, rois=rois, flags=buf.flags.view(-1)))
     rv = rois.view(nimg, num, 5)
     state = dict(rois=[rv[i, :, 1:] for i in range(nimg)], labels=labels, cls_score=cls_score, bbox_pred=bbox_pred,
                  valid=list(valid.view(nimg, num).unbind(0)), pos_is_gt=list(buf.is_gt.view(nimg, num).unbind(0)))
@@ -1417,4 +1444,7 @@ def build_detector(cfg, train_cfg=None, test_cfg=None, compute_dtype=torch.float
         cfg['train_cfg'] = train_cfg
     if test_cfg is not None:
         cfg['test_cfg'] = test_cfg
-    return build_from_cfg(cfg, DETECTORS, dict(compute_dtype=compute_dtype))
+    model = build_from_cfg(cfg, DETECTORS, dict(compute_dtype=compute_dtype))
+    if compute_dtype == torch.bfloat16:
+        mixed.khwc_resident_(model)          # 3x3 conv weights live in the HIP conv kernels' (Cout,ky,kx,Cin) memory layout
+    return model

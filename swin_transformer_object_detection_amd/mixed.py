@@ -169,10 +169,28 @@ def flush_pending():
         _PENDING.pop(k)()
 
 
+# ---- data gradients that already carry the ReLU backward of the layer below ------------------------------------------------
+_GATED = {}           # data_ptr of a live data-gradient tensor -> (the tensor (kept alive: its address stays unique), gate data_ptr)
+
+
+def gated_mark(dx, gate):
+    """``dx`` was produced already zeroed where ``gate`` (the ReLU output that fed the producing layer) is not positive."""
+    _GATED[dx.data_ptr()] = (dx, gate.data_ptr(), gate.numel())
+
+
+def gated_take(dy, y):
+    """True when ``dy`` is exactly such a tensor for ReLU output ``y`` (the caller may then skip threshold_backward).  A
+    gradient that autograd summed from several consumers is a new tensor and is not found: the caller masks it as usual
+    (masking is idempotent, so the already-masked contribution stays correct)."""
+    ent = _GATED.pop(dy.data_ptr(), None)
+    return ent is not None and ent[1] == y.data_ptr() and ent[2] == y.numel() and ent[0].numel() == dy.numel()
+
+
 def reset_step():
     _USES.clear()
     _PENDING.clear()
     _STEPLIVE.clear()
+    _GATED.clear()
     if _STEPBUF:                                  # one launch for all of them instead of one memset per layer
         bufs = [b for b in _STEPBUF.values() if b.is_cuda]
         if bufs:
@@ -190,6 +208,11 @@ def weight(p, dtype):
     return p.to(dtype)
 
 
+def leaf(p):
+    """The autograd leaf that stands for master parameter ``p``: its compute-dtype shadow when it has one, else ``p``."""
+    return _SHADOW.get(id(p), p)
+
+
 def shadow_of(p):
     """The bf16 copy an optimizer should refresh together with ``p`` (leaf shadow or constant), or None."""
     s = _SHADOW.get(id(p))
@@ -199,6 +222,7 @@ def shadow_of(p):
 def shadows_refreshed():
     """Called by an optimizer that has rewritten the shadows itself: drops the per-step derived tensors."""
     _DERIVED.clear()
+    refresh_aux()
 
 
 def const(p, dtype):
@@ -223,6 +247,72 @@ def refresh_all():
         else:
             sp.refresh()
     _DERIVED.clear()
+    refresh_aux()
+
+
+def is_khwc(p):
+    """True for a 4-D tensor whose memory is (N, H, W, C)-contiguous ("channels last"), the layout the 3x3 conv kernels
+    read weights in, and that is not also plainly contiguous."""
+    return p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
+
+
+def dense_view(flat, off, p):
+    """A view of flat[off : off + p.numel()] with p's shape AND p's memory layout (contiguous or channels-last), so that
+    parameter, gradient bucket, optimizer state and bf16 shadow correspond element by element in memory."""
+    seg = flat[off:off + p.numel()]
+    if p.is_contiguous():
+        return seg.view_as(p)
+    if is_khwc(p):
+        n, c, h, w = p.shape
+        return seg.view(n, h, w, c).permute(0, 3, 1, 2)
+    raise ValueError(f"parameter of shape {tuple(p.shape)} with strides {p.stride()} is neither contiguous nor channels-last")
+
+
+@torch.no_grad()
+def khwc_resident_(module):
+    """Keep the weights of the 3x3 convolutions that run on csrc/conv_gemm.hip RESIDENT in the kernels' (Cout, ky, kx, Cin)
+    memory layout: the parameter keeps its (Cout, Cin, 3, 3) shape (state_dict, checkpoints and the reference's init code see
+    no difference) with channels-last strides.  Shadow, gradient bucket and optimizer state follow the parameter's layout
+    (dense_view), so the forward needs no re-layout copy and the weight-gradient kernel accumulates straight into the
+    all-reduce bucket.  Call before ShadowParams / the reducer / the optimizer are built."""
+    import torch.nn as nn
+    n = 0
+    for m in module.modules():
+        if (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1
+                and m.in_channels % 64 == 0 and m.out_channels % 64 == 0 and m.weight.is_contiguous()):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+            n += 1
+    return n
+
+
+# ---- second compute-dtype layouts of shadowed weights, rebuilt for all of them by ONE launch after an optimizer step -----------
+_AUX = {}             # (id(master), tag) -> (shadow, buffer)
+
+
+def conv_dgrad_weight(master, shadow):
+    """The (Cin, 3, 3, Cout) weight of the data-gradient convolution -- rot180, in/out swapped -- of a khwc-resident 3x3 conv
+    weight with a bf16 shadow: a persistent buffer that refresh_aux() rewrites for every registered weight in one launch."""
+    k = (id(master), 'dgrad')
+    v = _DERIVED.get(k)
+    if v is not None:
+        return v
+    ent = _AUX.get(k)
+    if ent is None or ent[0] is not shadow:
+        co, ci = shadow.shape[0], shadow.shape[1]
+        _AUX[k] = (shadow, torch.empty(ci, 3, 3, co, device=shadow.device, dtype=shadow.dtype))
+    refresh_aux()
+    return _DERIVED[k]
+
+
+def refresh_aux():
+    """Rebuild every registered auxiliary layout from the current shadows (one multi-tensor launch) and publish them."""
+    if not _AUX:
+        return
+    from .ops.functional import conv_dgrad_layout_multi
+    items = list(_AUX.items())
+    conv_dgrad_layout_multi([e[0] for _, e in items], [e[1] for _, e in items])
+    for k, e in items:
+        _DERIVED[k] = e[1]
 
 
 class ShadowParams:
@@ -253,13 +343,13 @@ class ShadowParams:
         self.shadows, self.consts = [], []
         off = 0
         for p in self.masters:
-            v = self.flat[off:off + p.numel()].view_as(p)
+            v = dense_view(self.flat, off, p)
             v.requires_grad_(True)
             self.shadows.append(v)
             _SHADOW[id(p)] = v
             off += pad(p.numel())
         for p in self.const_masters:
-            v = self.flat[off:off + p.numel()].view_as(p)
+            v = dense_view(self.flat, off, p)
             self.consts.append(v)
             _CONST[id(p)] = v
             off += pad(p.numel())
@@ -273,6 +363,7 @@ class ShadowParams:
         if self.masters:
             torch._foreach_copy_(self.shadows + self.consts, self.masters + self.const_masters)
         _DERIVED.clear()
+        refresh_aux()
 
     def leaf_of(self, p):
         return _SHADOW.get(id(p), p)
@@ -282,4 +373,6 @@ class ShadowParams:
             _SHADOW.pop(id(p), None)
         for p in self.const_masters:
             _CONST.pop(id(p), None)
+        for p in self.masters:
+            _AUX.pop((id(p), 'dgrad'), None)
         _DERIVED.clear()

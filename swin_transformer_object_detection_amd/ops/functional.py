@@ -402,6 +402,23 @@ def _im2col3x3(x_cl):
     return cols.reshape(N * H * W, 9 * C)
 
 
+def conv_dgrad_layout_multi(srcs, dsts):
+    """dsts[i] (Cin,3,3,Cout) <- data-gradient layout of srcs[i], a (Cout,Cin,3,3) bf16 tensor in channels-last memory
+    (= (Cout,3,3,Cin) contiguous); every tensor of the list in one launch."""
+    n = len(srcs)
+    if n == 0:
+        return
+    for s_, d_ in zip(srcs, dsts):
+        if not (s_.is_cuda and s_.dtype == torch.bfloat16 and s_.dim() == 4 and s_.permute(0, 2, 3, 1).is_contiguous()
+                and d_.is_contiguous() and d_.dtype == torch.bfloat16 and d_.numel() == s_.numel()):
+            raise SwinHipError("conv_dgrad_layout_multi: (Cout,Cin,3,3) bf16 sources in channels-last memory, contiguous bf16 outputs")
+    sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    dp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
+    co = (ctypes.c_int * n)(*[t.shape[0] for t in srcs])
+    ci = (ctypes.c_int * n)(*[t.shape[1] for t in srcs])
+    call("conv_dgrad_layout_multi", sp, dp, co, ci, n, _s())
+
+
 class _Conv3x3(torch.autograd.Function):
     """Inputs: x, weight (compute-dtype leaf: the bf16 shadow or a cast of the master), bias (fp32 master), relu,
     weight_master.  The re-laid-out weights are cached per step (mixed.derived); with a reducer active the weight
@@ -409,13 +426,17 @@ class _Conv3x3(torch.autograd.Function):
     accumulator and folded into the parameter's all-reduce bucket after the last use's backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, weight_master):
+    def forward(ctx, x, weight, bias, relu, weight_master, x_is_relu=False):
         from .. import mixed
+        ctx.x_is_relu = bool(x_is_relu)
         if x.dtype != torch.bfloat16 or not x.is_cuda:
             raise SwinHipError("conv3x3: bf16 GPU activations only (fp32 parity runs use the library conv)")
         x = x.contiguous(memory_format=torch.channels_last)
-        w = mixed.derived(weight_master, 'khwc',
-                          lambda: weight.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())   # (Cout,3,3,Cin)
+        if weight.dtype == torch.bfloat16 and mixed.is_khwc(weight):
+            w = weight.detach().permute(0, 2, 3, 1)          # resident in the kernel's layout (mixed.khwc_resident_): a view
+        else:
+            w = mixed.derived(weight_master, 'khwc',
+                              lambda: weight.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())   # (Cout,3,3,Cin)
         b = None if bias is None else _f32(bias.detach().float()).contiguous()
         y = _conv3x3_raw(x, w, b, relu)
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -433,16 +454,26 @@ class _Conv3x3(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         w_master, b_master = ctx.masters
         dy = dy.contiguous(memory_format=torch.channels_last)
-        if ctx.relu:
+        if ctx.relu and not mixed.gated_take(dy, y):       # the producer of dy may have applied this ReLU's backward already
             dy = torch.ops.aten.threshold_backward(dy, y, 0)
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # dx = conv(dy, rot180(w) with in/out swapped): (Cin, 3, 3, Cout)
-            wt = mixed.derived(w_master, 'dgrad',
-                               lambda: weight.detach().to(torch.bfloat16).flip(2, 3).permute(1, 2, 3, 0).contiguous())
-            dx = _conv3x3_raw(dy, wt, None, False)
+            sh = mixed.shadow_of(w_master)
+            if sh is not None and sh.data_ptr() == weight.data_ptr() and sh.dtype == torch.bfloat16 and mixed.is_khwc(sh):
+                wt = mixed.conv_dgrad_weight(w_master, sh)          # persistent, rebuilt for all convs by one launch per step
+            else:
+                wt = mixed.derived(w_master, 'dgrad',
+                                   lambda: weight.detach().to(torch.bfloat16).flip(2, 3).permute(1, 2, 3, 0).contiguous())
+            if ctx.x_is_relu:
+                # x is the ReLU output of the layer below: its ReLU backward rides in this kernel's epilogue
+                dx = torch.empty((N, Cin, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+                call("conv3x3_nhwc_bf16_gated", _p(dy), _p(wt), None, _p(x), _p(dx), N, H, W, Cout, Cin, _s())
+                mixed.gated_mark(dx, x)
+            else:
+                dx = _conv3x3_raw(dy, wt, None, False)
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
@@ -450,7 +481,10 @@ class _Conv3x3(torch.autograd.Function):
             bs = mixed.grad_sink(b_master) if (need_b and ctx.counted) else None
             if ws is not None and tuple(ws[0].shape) != (Cout, Cin, 3, 3):
                 ws = None
-            if ws is not None:
+            direct = ws is not None and mixed.is_khwc(ws[0])      # the bucket view itself has the kernel's layout: no fold
+            if direct:
+                dwf = ws[0].permute(0, 2, 3, 1)
+            elif ws is not None:
                 dwf = mixed.step_buffer(w_master, 'dw_khwc', (Cout, 3, 3, Cin), x.device)
             else:
                 dwf = torch.zeros(Cout, 3, 3, Cin, device=x.device, dtype=torch.float32)
@@ -464,11 +498,12 @@ class _Conv3x3(torch.autograd.Function):
                 side_ok = bs is not None or not need_b        # a bias gradient returned through autograd is read on the main stream
                 with (mixed.on_side(x.device, dy, x) if side_ok else contextlib.nullcontext()):
                     call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), _p(dbf), N, H, W, Cin, Cout, _s())
-                    if last:
+                    if last and not direct:
                         ws[0].add_(dwf.permute(0, 3, 1, 2))
 
-                def notify(ws=ws, bs=bs, w_master=w_master):
-                    mixed.step_buffer_done(w_master, 'dw_khwc')
+                def notify(ws=ws, bs=bs, w_master=w_master, direct=direct):
+                    if not direct:
+                        mixed.step_buffer_done(w_master, 'dw_khwc')
                     mixed.set_pending(w_master, None)
                     ws[1]()
                     if bs is not None:
@@ -476,9 +511,10 @@ class _Conv3x3(torch.autograd.Function):
                 if last:
                     notify()
                 else:
-                    def finalize(ws=ws, dwf=dwf, dev=x.device, notify=notify):     # a use whose backward never came
-                        with mixed.on_side(dev):
-                            ws[0].add_(dwf.permute(0, 3, 1, 2))
+                    def finalize(ws=ws, dwf=dwf, dev=x.device, notify=notify, direct=direct):     # a use whose backward never came
+                        if not direct:
+                            with mixed.on_side(dev):
+                                ws[0].add_(dwf.permute(0, 3, 1, 2))
                         notify()
                     mixed.set_pending(w_master, finalize)
             else:
@@ -489,15 +525,17 @@ class _Conv3x3(torch.autograd.Function):
                 db = dbf
         elif ctx.counted:
             mixed.use_end(w_master)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def conv3x3(x, weight, bias=None, relu=False, dtype=torch.bfloat16):
+def conv3x3(x, weight, bias=None, relu=False, dtype=torch.bfloat16, x_is_relu=False):
     """3x3, padding 1, stride 1 conv of a logically-NCHW bf16 tensor (channels-last memory).  ``weight`` / ``bias``
     are the fp32 master parameters (the compute-dtype weight is resolved through mixed.weight; gradients may be
-    accumulated straight into the reducer's buckets)."""
+    accumulated straight into the reducer's buckets).  ``x_is_relu``: the caller guarantees that ``x`` is the output of a
+    ReLU (x == 0 wherever the ReLU was inactive); the data gradient is then produced already multiplied by [x > 0], i.e.
+    as the gradient at that ReLU's input, and a conv3x3(relu=True) below recognises it and skips its own masking pass."""
     from .. import mixed
-    return _Conv3x3.apply(x, mixed.weight(weight, dtype), bias, relu, weight)
+    return _Conv3x3.apply(x, mixed.weight(weight, dtype), bias, relu, weight, x_is_relu)
 
 
 # --------------------------------------------------------------------------------------

@@ -68,18 +68,24 @@ def _f4(v):
     return (ctypes.c_float * 4)(*[float(x) for x in v])
 
 
-def random_sample_raw(assigned_gt_inds, num, pos_fraction, seed=None):
+def random_sample_raw(assigned_gt_inds, num, pos_fraction, seed=None, out=None):
     """random_sample returning the kernel's (inds, flags) pair (bit 0 used, bit 1 positive) for bbox_targets."""
     a = assigned_gt_inds.long().contiguous()
-    inds = torch.empty(num, dtype=torch.long, device=a.device)
-    flags = torch.empty(num, dtype=torch.uint8, device=a.device)
+    if out is not None:                       # rows of batch-level tensors provided by the caller
+        inds, flags = out
+        if not (inds.is_contiguous() and flags.is_contiguous() and inds.numel() == num and flags.numel() == num
+                and inds.dtype == torch.long and flags.dtype == torch.uint8):
+            raise SwinHipError("random_sample_raw: out = (int64 (num,), uint8 (num,)) contiguous tensors")
+    else:
+        inds = torch.empty(num, dtype=torch.long, device=a.device)
+        flags = torch.empty(num, dtype=torch.uint8, device=a.device)
     ws = torch.empty(_lib.lib().det_random_sample_workspace_bytes(), dtype=torch.uint8, device=a.device)
     call("det_random_sample", _p(a) if a.numel() else None, a.numel(), int(num), int(num * pos_fraction),
          _next_seed() if seed is None else int(seed), _p(inds), _p(flags), _p(ws), _s())
     return inds, flags
 
 
-def bbox_targets(bboxes, inds, flags, assigned_gt_inds, gt_bboxes, means, stds, assigned_labels=None, bg_label=0):
+def bbox_targets(bboxes, inds, flags, assigned_gt_inds, gt_bboxes, means, stds, assigned_labels=None, bg_label=0, out_deltas=None):
     """Targets of a fixed-size sample in one launch: the gathers of anchor_head.py:221-247 / bbox_head.py:140-186 and
     DeltaXYWHBBoxCoder.encode (delta_xywh_bbox_coder.py:82-130).
 
@@ -88,7 +94,9 @@ def bbox_targets(bboxes, inds, flags, assigned_gt_inds, gt_bboxes, means, stds, 
     k = inds.numel()
     dev = bboxes.device
     boxes = torch.empty(k, 4, dtype=torch.float32, device=dev)
-    deltas = torch.empty(k, 4, dtype=torch.float32, device=dev)
+    deltas = torch.empty(k, 4, dtype=torch.float32, device=dev) if out_deltas is None else out_deltas
+    if not (deltas.is_contiguous() and deltas.dtype == torch.float32 and deltas.numel() == 4 * k):
+        raise SwinHipError("bbox_targets: out_deltas must be a contiguous float32 (k,4) tensor")
     gt_inds = torch.empty(k, dtype=torch.long, device=dev)
     labels = torch.empty(k, dtype=torch.long, device=dev) if assigned_labels is not None else None
     g = gt_bboxes.size(0)
@@ -112,6 +120,8 @@ class RoiStageBuffers:
         self.pos = e(nimg * num, dt=torch.bool)
         self.valid = e(nimg * num, dt=torch.bool)
         self.is_gt = e(nimg * num, dt=torch.bool)
+        self.inds = e(nimg, num, dt=torch.long)       # the sampler's own outputs (det_random_sample), one row per image:
+        self.flags = e(nimg, num, dt=torch.uint8)     # bit 0 used, bit 1 positive -- the form the loss kernels read
         self.feat_rois = e(nimg * km, 5)          # bbox2roi of the mask slots (RoI extractor input)
         self.mask_rois = e(nimg * km, 5)          # [gt mask index (+ offset), clipped box] (crop_and_resize input)
         self.mlabels = e(nimg * km, dt=torch.long)

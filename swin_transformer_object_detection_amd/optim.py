@@ -47,17 +47,22 @@ class FusedAdamW:
             for p in g['params']:
                 if not p.requires_grad or p.grad is None:
                     continue
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.dtype == torch.float32
-                        and p.grad.is_contiguous()):
-                    raise SwinHipError("FusedAdamW: contiguous fp32 GPU parameters and gradients only")
+                # the kernel pairs parameter, gradient, moments and shadow by memory offset: all five must be dense with ONE
+                # layout (contiguous, or channels-last for the resident 3x3 conv weights -- mixed.khwc_resident_)
+                dense = p.is_contiguous() or mixed.is_khwc(p)
+                if not (p.is_cuda and p.dtype == torch.float32 and dense and p.grad.dtype == torch.float32
+                        and p.grad.stride() == p.stride()):
+                    raise SwinHipError("FusedAdamW: dense fp32 GPU parameters with gradients of the same memory layout only")
                 dev = p.device
                 st = self.state.setdefault(p, {})
                 if 'exp_avg' not in st:
-                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if st['exp_avg'].stride() != p.stride() or st['exp_avg_sq'].stride() != p.stride():
+                    raise SwinHipError("FusedAdamW: optimizer state laid out differently from its parameter")
                 sh = mixed.shadow_of(p)
-                if sh is not None and not (sh.dtype == torch.bfloat16 and sh.is_contiguous() and sh.numel() == p.numel()):
-                    raise SwinHipError("FusedAdamW: shadows must be contiguous bf16 copies")
+                if sh is not None and not (sh.dtype == torch.bfloat16 and sh.stride() == p.stride() and sh.numel() == p.numel()):
+                    raise SwinHipError("FusedAdamW: shadows must be bf16 copies with the parameter's memory layout")
                 n = p.numel()
                 si = len(segs)
                 segs.append(struct.pack("<QQQQQqii", p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
@@ -134,7 +139,7 @@ class FusedAdamW:
                 st = self.state.setdefault(p, {})
                 for name in ('exp_avg', 'exp_avg_sq'):
                     if name not in st:
-                        st[name] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                        st[name] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st[name].copy_(st_src[name])
                 steps.add(int(float(st_src['step'])))
         if len(steps) > 1:

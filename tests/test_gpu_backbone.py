@@ -411,6 +411,70 @@ def test_simple_test_matches_oracle_callers():
 
 
 @pytest.mark.gpu
+def test_resident_conv_weights_optimizer_and_dgrad_layout():
+    """khwc-resident 3x3 conv weights (mixed.khwc_resident_): (a) conv_dgrad_layout_multi == flip + permute of the reference
+    layout for several tensors in one launch; (b) FusedAdamW steps them exactly like torch.optim.AdamW steps a plain
+    contiguous copy, with the bf16 shadow and the dgrad layout following; (c) conv3x3 forward / backward with a reducer
+    (weight gradient accumulated straight into the channels-last bucket view, no fold) == F.conv2d autograd."""
+    import torch.nn as nn
+    from swin_transformer_object_detection_amd import ddp, mixed, ops, optim
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    torch.manual_seed(0)
+    convs = nn.ModuleList([nn.Conv2d(64, 128, 3, padding=1), nn.Conv2d(128, 64, 3, padding=1), nn.Conv2d(64, 64, 1)]).cuda()
+    assert mixed.khwc_resident_(convs) == 2
+    ref = [p.detach().clone().contiguous().requires_grad_(True) for p in convs.parameters()]
+    sh = mixed.ShadowParams(convs, torch.bfloat16)
+    red = ddp.BucketedGradReducer(convs.parameters(), leaf_of=sh.leaf_of)
+    try:
+        # (a)
+        srcs = [mixed.shadow_of(convs[0].weight), mixed.shadow_of(convs[1].weight)]
+        dsts = [torch.empty(s_.shape[1], 3, 3, s_.shape[0], device="cuda", dtype=torch.bfloat16) for s_ in srcs]
+        Fn.conv_dgrad_layout_multi(srcs, dsts)
+        for s_, d_ in zip(srcs, dsts):
+            assert torch.equal(d_, s_.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous())
+        # (c) one training-like step through the HIP conv with the reducer's sinks
+        x = torch.randn(2, 64, 20, 24, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        red.zero_grad()
+        y = ops.conv3x3(x, convs[0].weight, convs[0].bias, relu=False)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        red.finish()
+        wr = mixed.shadow_of(convs[0].weight).detach().float().contiguous().requires_grad_(True)
+        xr = x.detach().float().requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr, wr, convs[0].bias.detach(), padding=1)
+        yr.backward(gy.float())
+        tol = lambda r: 0.02 * float(r.abs().max()) + 1e-5                     # noqa: E731  (bf16 operands, fp32 accumulation)
+        assert float((y.float() - yr).abs().max()) <= tol(yr)
+        assert float((x.grad.float() - xr.grad).abs().max()) <= tol(xr.grad)
+        g = convs[0].weight.grad
+        assert g.stride() == convs[0].weight.stride()
+        assert float((g - wr.grad).abs().max()) <= tol(wr.grad)
+        assert float((convs[0].bias.grad - gy.float().sum((0, 2, 3))).abs().max()) <= tol(gy.float().sum((0, 2, 3)))
+        # (b)
+        params = list(convs.parameters())
+        mine = optim.FusedAdamW([dict(params=params, weight_decay=0.05)], lr=1e-2, betas=(0.9, 0.999))
+        theirs = torch.optim.AdamW([dict(params=ref, weight_decay=0.05)], lr=1e-2, betas=(0.9, 0.999))
+        for step in range(3):
+            red.zero_grad()
+            for p, r in zip(params, ref):
+                gq = torch.randn(p.shape, device="cuda") * (0.1 + step)
+                p.grad.copy_(gq); r.grad = gq.clone()
+            mine.step(); theirs.step()
+            for p, r in zip(params, ref):
+                torch.testing.assert_close(p.detach().contiguous(), r.detach(), rtol=2e-5, atol=2e-6)
+                s_ = mixed.shadow_of(p)
+                if s_ is not None:
+                    assert s_.stride() == p.stride() and torch.equal(s_.detach(), p.detach().to(torch.bfloat16))
+            wt = mixed.conv_dgrad_weight(convs[0].weight, mixed.shadow_of(convs[0].weight))
+            assert torch.equal(wt, mixed.shadow_of(convs[0].weight).detach().flip(2, 3).permute(1, 2, 3, 0).contiguous())
+        st = mine.state[params[0]]
+        assert st['exp_avg'].stride() == params[0].stride()
+    finally:
+        red.release()
+        sh.release()
+
+
+@pytest.mark.gpu
 def test_fused_adamw_matches_torch_adamw():
     """optim.FusedAdamW (one HIP launch, bf16 shadows written in the same pass) == torch.optim.AdamW over several
     steps, two parameter groups (weight decay 0.05 / 0, as configs/swin/*_coco.py:64-67 build them)."""

@@ -280,6 +280,65 @@ def test_roi_stage_packed_equals_per_op_stage(pkg):
         np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
 
 
+def test_relu_backward_rides_in_the_producing_kernel(pkg):
+    """conv -> ReLU -> conv chains (fcn_mask_head.py:73-104) and rpn_conv -> ReLU -> 1x1 heads (rpn_head.py:41-47): the data
+    gradient kernels write the gradient already multiplied by [relu output > 0] (conv3x3_nhwc_bf16_gated /
+    narrow_dgrad_gated_bf16) and the conv below skips threshold_backward.  Checked against fp32 autograd of
+    F.conv2d / F.relu on the same bf16-rounded operands, and against the un-fused path of this package bit for bit."""
+    import torch.nn as nn
+    from swin_transformer_object_detection_amd import mixed, ops
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    torch.manual_seed(0)
+    c1, c2 = nn.Conv2d(64, 128, 3, padding=1).cuda(), nn.Conv2d(128, 64, 3, padding=1).cuda()
+    x0 = torch.randn(3, 64, 14, 14, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(3, 64, 14, 14, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        for q in (c1, c2):
+            q.weight.grad = q.bias.grad = None
+        h = ops.conv3x3(x, c1.weight, c1.bias, relu=True)
+        y = ops.conv3x3(h, c2.weight, c2.bias, relu=True, x_is_relu=fused)
+        y.backward(gy)
+        return y.detach(), x.grad.clone(), c1.weight.grad.clone(), c1.bias.grad.clone(), c2.weight.grad.clone()
+    calls = []
+    orig = torch.ops.aten.threshold_backward
+
+    class _Count:                                   # count the masking passes each variant launches
+        def __call__(self, *a):
+            calls.append(1)
+            return orig(*a)
+    try:
+        torch.ops.aten.threshold_backward = _Count()
+        plain = run(False); n_plain = len(calls); calls.clear()
+        fused = run(True); n_fused = len(calls)
+    finally:
+        torch.ops.aten.threshold_backward = orig
+    assert (n_plain, n_fused) == (2, 1)
+    for a, b in zip(plain, fused):
+        assert torch.equal(a, b)
+    # against fp32 autograd
+    xr = x0.float().requires_grad_(True)
+    w1, w2 = c1.weight.detach().bfloat16().float().requires_grad_(True), c2.weight.detach().bfloat16().float().requires_grad_(True)
+    hr = F.relu(F.conv2d(xr, w1, c1.bias.detach(), padding=1)).bfloat16().float()
+    hr.retain_grad() if hr.requires_grad else None
+    yr = F.relu(F.conv2d(hr, w2, c2.bias.detach(), padding=1))
+    yr.backward(gy.float())
+    _close(fused[1], xr.grad, _bf16_tol(xr.grad, 6), "dx through both gated ReLUs")
+    _close(fused[2], w1.grad, 0.02 * float(w1.grad.abs().max()), "dW of the lower conv")
+
+    # the narrow head: dx = [gate > 0] * dy w
+    T, K, C = 5003, 16, 256
+    dy = torch.randn(T, K, device="cuda").bfloat16()
+    w = (torch.randn(K, C, device="cuda") * 0.1).bfloat16()
+    gate = torch.relu(torch.randn(T, C, device="cuda")).bfloat16()
+    dx = torch.full((T, C), 7.0, device="cuda", dtype=torch.bfloat16)
+    Fn.call("narrow_dgrad_gated_bf16", Fn._p(dy), Fn._p(w), Fn._p(gate), Fn._p(dx), T, K, C, Fn._s())
+    ref = (dy.float() @ w.float()) * (gate > 0)
+    _close(dx, ref, _bf16_tol(ref, 1.01), "narrow gated dgrad")
+    assert bool(((dx == 0) | (gate > 0)).all())
+
+
 # ------------------------------------------------------------------------------------- kernels at the bench's own sizes
 def oracle_attention_natural(qkv, qkv_bias, table, B, H, W, nH, shift):
     """Reference semantics on the natural grid: pad (padded tokens are 0 before the qkv Linear, so their q|k|v equal

@@ -186,6 +186,46 @@ def test_shadow_params_and_gradient_gather():
         sh.release()
 
 
+def test_khwc_resident_conv_weights_layout_follows_through():
+    """mixed.khwc_resident_: eligible 3x3 conv weights keep their (Cout,Cin,3,3) shape with channels-last strides; the bf16
+    shadow, the reducer's bucket view and (by stride equality) the optimizer state share that memory layout, values
+    unchanged; other parameters stay contiguous; gradients through plain autograd land in the bucket correctly."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from swin_transformer_object_detection_amd import ddp, mixed
+    torch.manual_seed(0)
+    c3, c1, odd = nn.Conv2d(64, 64, 3, padding=1), nn.Conv2d(64, 16, 1), nn.Conv2d(24, 8, 3, padding=1)     # odd: Cin % 64 != 0
+    model = nn.ModuleList([c3, c1, odd])
+    w0 = c3.weight.detach().clone()
+    assert mixed.khwc_resident_(model) == 1
+    assert tuple(c3.weight.shape) == (64, 64, 3, 3) and mixed.is_khwc(c3.weight) and torch.equal(c3.weight.detach(), w0)
+    assert c1.weight.is_contiguous() and odd.weight.is_contiguous()
+    assert c3.weight.permute(0, 2, 3, 1).is_contiguous()
+    sh = mixed.ShadowParams(model, torch.bfloat16)
+    try:
+        s3 = mixed.shadow_of(c3.weight)
+        assert s3.stride() == c3.weight.stride() and torch.equal(s3.detach(), w0.bfloat16())
+        red = ddp.BucketedGradReducer(model.parameters(), bucket_bytes=1 << 20, leaf_of=sh.leaf_of)
+        assert c3.weight.grad.stride() == c3.weight.stride() and c1.weight.grad.is_contiguous()
+        x = torch.randn(2, 64, 5, 6)
+        red.zero_grad()
+        y = F.conv2d(x.bfloat16(), mixed.weight(c3.weight, torch.bfloat16), None, padding=1)
+        y.float().square().mean().backward()
+        red.finish()
+        wr = w0.bfloat16().float().requires_grad_(True)
+        F.conv2d(x.bfloat16().float(), wr, None, padding=1).square().mean().backward()
+        np.testing.assert_allclose(c3.weight.grad.numpy(), wr.grad.numpy(), atol=0.05 * float(wr.grad.abs().max()) + 1e-4)
+        # the memory of the bucket view is (Cout,3,3,Cin): what the weight-gradient kernel writes
+        b0 = red.buckets[0]
+        i3 = [i for i, q in enumerate(b0['params']) if q is c3.weight][0]
+        off = sum(q.numel() for q in b0['params'][:i3])
+        np.testing.assert_array_equal(b0['flat'][off:off + c3.weight.numel()].numpy(),
+                                      c3.weight.grad.permute(0, 2, 3, 1).contiguous().view(-1).numpy())
+        red.release()
+    finally:
+        sh.release()
+
+
 def test_sample_static_counts_and_order():
     """Fixed-size sampler: same counts as RandomSampler (random_sampler.py:31-78); positives first, then negatives,
     then invalid padding; never picks ignored (-1) entries."""
