@@ -455,8 +455,7 @@ def test_resident_conv_weights_optimizer_and_dgrad_layout():
         mine = optim.FusedAdamW([dict(params=params, weight_decay=0.05)], lr=1e-2, betas=(0.9, 0.999))
         theirs = torch.optim.AdamW([dict(params=ref, weight_decay=0.05)], lr=1e-2, betas=(0.9, 0.999))
         for step in range(3):
-            red.zero_grad()
-            for p, r in zip(params, ref):
+            for p, r in zip(params, ref):               # p.grad is the bucket view since finish()
                 gq = torch.randn(p.shape, device="cuda") * (0.1 + step)
                 p.grad.copy_(gq); r.grad = gq.clone()
             mine.step(); theirs.step()

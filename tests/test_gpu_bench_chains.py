@@ -315,13 +315,13 @@ def test_relu_backward_rides_in_the_producing_kernel(pkg):
     finally:
         torch.ops.aten.threshold_backward = orig
     assert (n_plain, n_fused) == (2, 1)
-    for a, b in zip(plain, fused):
-        assert torch.equal(a, b)
+    assert torch.equal(plain[0], fused[0]) and torch.equal(plain[1], fused[1])          # y and dx: deterministic kernels
+    for a, b in zip(plain[2:], fused[2:]):                                              # weight gradients: fp32 atomics
+        _close(a, b, 1e-3 * float(a.abs().max()), "weight gradient, fused vs plain")
     # against fp32 autograd
     xr = x0.float().requires_grad_(True)
     w1, w2 = c1.weight.detach().bfloat16().float().requires_grad_(True), c2.weight.detach().bfloat16().float().requires_grad_(True)
     hr = F.relu(F.conv2d(xr, w1, c1.bias.detach(), padding=1)).bfloat16().float()
-    hr.retain_grad() if hr.requires_grad else None
     yr = F.relu(F.conv2d(hr, w2, c2.bias.detach(), padding=1))
     yr.backward(gy.float())
     _close(fused[1], xr.grad, _bf16_tol(xr.grad, 6), "dx through both gated ReLUs")
