@@ -324,6 +324,13 @@ int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, int decon
                       const int64_t* labels, const uint8_t* valid, const float* out2, const float* grad_out, void* dpred,
                       int dtype, void* stream);
 
+/* swin_set_aux_stream: per device, a second hipStream_t (NULL = none) for the small reductions at the end of
+ *   swin_layernorm_bwd (parameter gradients), swin_window_attn_bwd (bias-gradient slabs) and swin_rel_bias_reduce: while it
+ *   is set they are enqueued there behind an event recorded on the call's own stream, so they leave the data-gradient chain.
+ *   The caller joins the two streams before reading those results and keeps the calls' workspaces untouched until then.
+ *   swin_block_bwd sets it to its table entry 55 for the duration of the call. */
+int swin_set_aux_stream(void* side);
+
 /* conv3x3_nhwc_bf16_gated: conv3x3_nhwc_bf16 whose output is zeroed where gate (N,H,W,Cout) bf16 is not positive -- a data
  *   gradient that already includes the ReLU backward (torch.ops.aten.threshold_backward) of the layer below, whose output
  *   `gate` is (the conv -> ReLU -> conv chains of fcn_mask_head.py:73-104).

@@ -1,2 +1,39 @@
 #include "common.h"
 extern "C" int swin_hip_abi_version(void) { return 1; }
+
+// ---- second stream for work that nothing on the main stream waits for ------------------------------------------------------
+// Per device: while an auxiliary stream is set, the entry points that end in a small REDUCTION nobody on the main stream
+// consumes -- swin_layernorm_bwd's parameter-gradient reduce, swin_window_attn_bwd's bias-gradient slab reduce,
+// swin_rel_bias_reduce -- enqueue that launch on the auxiliary stream, behind an event recorded on the main stream after the
+// producing kernel.  The caller joins the streams before the results are read, and must not hand the workspaces of those
+// calls to later main-stream work before the join (the reductions still read them).
+static void* g_aux_stream[16] = {};
+
+extern "C" int swin_set_aux_stream(void* side) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    g_aux_stream[dev] = side;
+    return SWIN_OK;
+}
+
+void* swin_aux_stream(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    return g_aux_stream[dev];
+}
+
+// `side` waits for everything enqueued on `main` so far (no host synchronisation).  A ring of events per device:
+// hipStreamWaitEvent captures the event's latest record at the time of the call, so an event may be re-recorded as soon as
+// the wait has been enqueued; the ring only keeps that property from mattering.
+int swin_fork_stream(void* main, void* side) {
+    if (!side || side == main) return SWIN_OK;
+    static hipEvent_t ring[16][64];
+    static unsigned next_ev[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    hipEvent_t& ev = ring[dev][next_ev[dev]++ & 63];
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return SWIN_ERR_LAUNCH;
+    if (hipEventRecord(ev, (hipStream_t)main) != hipSuccess) return SWIN_ERR_LAUNCH;
+    if (hipStreamWaitEvent((hipStream_t)side, ev, 0) != hipSuccess) return SWIN_ERR_LAUNCH;
+    return SWIN_OK;
+}

@@ -5,6 +5,7 @@
 // the training step had become bound by exactly that.  All buffers are provided by the caller (pointer tables below);
 // nothing is allocated, nothing synchronises.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/swin_hip.h"
 #include "common.h"
@@ -68,25 +69,16 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
 // ints: B, H, W, C, nH, shift, fused_mlp;  floats: scale
 // fused_mlp != 0: 9 (hpre) and 10 (h) were not saved; swin_mlp_bwd_bf16 recomputes them from n2 (8), writes dn2 (32) and, as
 // temporaries for the two weight-gradient GEMMs, h into 30 and dhpre into 31; db1 (43) then comes from the dW1 launch.
-// `side` waits for everything enqueued on `main` so far (no host synchronisation).  A small ring of events per device:
-// hipStreamWaitEvent captures the event's latest record at the time of the call, so an event may be re-recorded as
-// soon as the wait has been enqueued; the ring only keeps that property from mattering.
-static int fork_stream(void* main, void* side) {
-    if (!side || side == main) return SWIN_OK;
-    static hipEvent_t ring[16][32];
-    static unsigned next_ev[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
-    hipEvent_t& ev = ring[dev][next_ev[dev]++ & 31];
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return SWIN_ERR_LAUNCH;
-    if (hipEventRecord(ev, (hipStream_t)main) != hipSuccess) return SWIN_ERR_LAUNCH;
-    if (hipStreamWaitEvent((hipStream_t)side, ev, 0) != hipSuccess) return SWIN_ERR_LAUNCH;
-    return SWIN_OK;
-}
+struct AuxScope {                 // the auxiliary stream is set for the duration of one block backward
+    explicit AuxScope(void* side) { swin_set_aux_stream(side); }
+    ~AuxScope() { swin_set_aux_stream(nullptr); }
+};
 
 extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const float* fv, void* stream) {
     if (!p || !iv || !fv) return SWIN_ERR_BAD_ARG;
     void* const wst = p[55] ? const_cast<void*>(p[55]) : stream;      // where the weight-gradient GEMMs go
+    static const bool aux_on = !(getenv("SWIN_AUX_REDUCE") && atoi(getenv("SWIN_AUX_REDUCE")) == 0);      // development A/B
+    AuxScope aux(p[55] && aux_on ? wst : nullptr);                              // ... and the parameter-gradient reductions of LN / attention
     const int B = (int)iv[0], H = (int)iv[1], W = (int)iv[2], C = (int)iv[3], nH = (int)iv[4], shift = (int)iv[5];
     const float scale = fv[0];
     const int64_t L = (int64_t)H * W, T = (int64_t)B * L;
@@ -108,12 +100,12 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
         CHK(swin_mlp_bwd_bf16(p[8], dy2, p[18], (const float*)p[22], p[19], M(32), M(30), M(31), T, C, stream));
         if (p[44] || p[45]) {
             if (!p[44]) return SWIN_ERR_UNSUPPORTED;
-            CHK(fork_stream(stream, wst));
+            CHK(swin_fork_stream(stream, wst));
             CHK(wgrad_linear_bf16(dy2, p[30], (float*)p[44], (float*)p[45], T, C, 4 * C, wst));
         }
         if (p[42] || p[43]) {
             if (!p[42]) return SWIN_ERR_UNSUPPORTED;
-            CHK(fork_stream(stream, wst));
+            CHK(swin_fork_stream(stream, wst));
             CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], (float*)p[43], T, 4 * C, C, wst));
         }
     } else {
@@ -121,7 +113,7 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     CHK(swin_gemm_bf16(dy2, p[19], nullptr, M(30), T, 4 * C, C, 1, gws, stream));
     if (p[44] || p[45]) {
         if (!p[44]) return SWIN_ERR_UNSUPPORTED;
-        CHK(fork_stream(stream, wst));
+        CHK(swin_fork_stream(stream, wst));
         CHK(wgrad_linear_bf16(dy2, p[10], (float*)p[44], (float*)p[45], T, C, 4 * C, wst));
     }
     // GELU
@@ -129,7 +121,7 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     // fc1
     CHK(swin_gemm_bf16(p[31], p[18], nullptr, M(32), T, C, 4 * C, 1, gws, stream));
     if (p[42]) {
-        CHK(fork_stream(stream, wst));
+        CHK(swin_fork_stream(stream, wst));
         CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], nullptr, T, 4 * C, C, wst));
     }
     }
@@ -142,7 +134,7 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     CHK(swin_gemm_bf16(dy, p[17], nullptr, M(34), T, C, C, 1, gws, stream));
     if (p[40] || p[41]) {
         if (!p[40]) return SWIN_ERR_UNSUPPORTED;
-        CHK(fork_stream(stream, wst));
+        CHK(swin_fork_stream(stream, wst));
         CHK(wgrad_linear_bf16(dy, p[4], (float*)p[40], (float*)p[41], T, C, C, wst));
     }
     // window attention
@@ -154,7 +146,7 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     CHK(swin_gemm_bf16(p[35], p[16], nullptr, M(27), T, C, 3 * C, 1, gws, stream));
     if (p[37] || p[38]) {
         if (!p[37]) return SWIN_ERR_UNSUPPORTED;
-        CHK(fork_stream(stream, wst));
+        CHK(swin_fork_stream(stream, wst));
         CHK(wgrad_linear_bf16(p[35], p[0], (float*)p[37], (float*)p[38], T, 3 * C, C, wst));
     }
     return SWIN_OK;

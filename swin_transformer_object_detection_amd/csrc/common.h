@@ -19,6 +19,10 @@ static inline int swin_launch_status() {
     return hipGetLastError() == hipSuccess ? SWIN_OK : SWIN_ERR_LAUNCH;
 }
 
+// csrc/abi.hip: the per-device auxiliary stream (null = none) and the event fork used to order work on it
+void* swin_aux_stream(void);
+int swin_fork_stream(void* main, void* side);
+
 template <typename T> struct Elt;
 template <> struct Elt<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }

@@ -337,8 +337,16 @@ static int ln_bwd_launch(Src src, const T* dy, const float* gamma, const float* 
     LN_DISPATCH((ln_bwd_kernel<T, G, NV, Src, MERGE><<<blocks, 256, shm, s>>>(src, dy, gamma, mean, rstd, dres, dx, dy2,
                                                                               scale, rps, dgamma, dbeta, rows, C, use_slab,
                                                                               partials)))
-    if (partials)
-        ln_param_reduce_kernel<<<(2 * C + 63) / 64, 1024, 0, s>>>(partials, blocks, C, dgamma, dbeta);
+    if (partials) {
+        // nobody on this stream consumes the parameter gradients: with an auxiliary stream set, reduce them there
+        void* aux = swin_aux_stream();
+        hipStream_t rs = s;
+        if (aux && aux != (void*)s) {
+            if (swin_fork_stream((void*)s, aux) != SWIN_OK) return SWIN_ERR_LAUNCH;
+            rs = (hipStream_t)aux;
+        }
+        ln_param_reduce_kernel<<<(2 * C + 63) / 64, 1024, 0, rs>>>(partials, blocks, C, dgamma, dbeta);
+    }
     return swin_launch_status();
 }
 

@@ -84,6 +84,9 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
     // Every output tile of one split reads the SAME token range, so a split's tiles belong on ONE XCD: there its dY / X rows
     // are fetched into that L2 once and hit by the other tiles.  The plain (x, y, z) order put the tiles of a split on all
     // eight XCDs: each L2 fetched nearly every operand byte (PMC, round 2: 43 % L2 hit rate, 3-6x the unique bytes fetched).
+    // (The opposite affinity -- all splits of a TILE on one XCD, so that the fp32 atomics onto its 64 KB stay in one L2 -- was
+    // measured too, round 2: no gain on any shape, 38 -> 57 us at 768x192 and 262 -> 292 us on the P2 conv where it unbalances
+    // the XCDs.  The atomics are not limited by lines migrating between L2s.)
     int bx, by, bz;
     if (g2 > 0) {
         const int L = blockIdx.x, xcd = L & 7, q = L >> 3, tiles = g1 * g2;
@@ -336,7 +339,7 @@ static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, i
     // the XCD-aware map below keeps a split's tiles on one XCD: it needs the splits to spread evenly over the 8 XCDs
     // measured (profiles/r02_wgrad_modes.txt): +7 % on the P2 conv weight gradient (36 tiles x 16 splits), neutral to negative on the
     // Linear shapes (few tiles or short t ranges: there balance over the CUs matters more than L2 reuse) -> conv, long t only
-    bool use_xcd = xcd_map && XLoader::kBlocksManyTiles == 512 && T >= 24000 && g1 * g2 > 1 && splits >= 8;
+    bool use_xcd = xcd_map == 1 && XLoader::kBlocksManyTiles == 512 && T >= 24000 && g1 * g2 > 1 && splits >= 8;
     if (use_xcd) {
         int s8 = (splits + 4) / 8 * 8;
         if (s8 < 8) s8 = 8;

@@ -1011,6 +1011,11 @@ extern "C" int swin_rel_bias_expand(const float* table, float* bias_exp, int nH,
 
 extern "C" int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int nH, void* stream) {
     if (!dbias_exp || !dtable || nH <= 0) return SWIN_ERR_BAD_ARG;
+    void* aux = swin_aux_stream();                 // follows the slab reduce onto the auxiliary stream when one is set
+    if (aux && aux != stream) {
+        if (swin_fork_stream(stream, aux) != SWIN_OK) return SWIN_ERR_LAUNCH;
+        stream = aux;
+    }
     rel_bias_reduce_kernel<<<nH, 256, 0, (hipStream_t)stream>>>(dbias_exp, dtable, nH);
     return swin_launch_status();
 }
@@ -1055,7 +1060,13 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
                                                           (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks);
         int n = nH * (TILE * TILE + 3 * HD);
         dim3 rgrid((n + 255) / 256, 16);
-        dbias_slab_reduce_kernel<<<rgrid, 256, 0, s>>>((const float*)workspace, dbias_exp, dqkv_bias_pad, blocks * 4, nH, C);
+        hipStream_t rs = s;                       // bias-gradient reduce: off the data-gradient chain (see csrc/abi.hip)
+        void* aux = swin_aux_stream();
+        if (aux && aux != (void*)s) {
+            if (swin_fork_stream((void*)s, aux) != SWIN_OK) return SWIN_ERR_LAUNCH;
+            rs = (hipStream_t)aux;
+        }
+        dbias_slab_reduce_kernel<<<rgrid, 256, 0, rs>>>((const float*)workspace, dbias_exp, dqkv_bias_pad, blocks * 4, nH, C);
     } else {
         win_attn_bwd_f32_kernel<<<n_tasks, 64, 0, s>>>((const float*)qkv, qkv_bias, bias_exp, lse, (const float*)dout,
                                                        (float*)dqkv, dbias_exp, dqkv_bias_pad, g, scale);

@@ -369,12 +369,17 @@ class _SwinBlockFn(torch.autograd.Function):
         # buffer returned through autograd would be read on the main stream)
         side = mixed.side_stream(dev)
         if side is not None:
-            for q_ in (m_wqkv, m_wproj, m_w1, m_w2, bqkv, bproj, b1, b2):
+            for q_ in (m_wqkv, m_wproj, m_w1, m_w2, bqkv, bproj, b1, b2, n2w, n2b, table) + ((nnw, nnb) if has_next else ()):
                 if q_ is not None and q_.requires_grad and mixed.grad_sink(q_) is None:
                     side = None
                     break
         if side is not None:
-            mixed.side_protect(dev, flat, qkv, n1, dx2, dnn if has_next else None)
+            # the reductions behind attention / LayerNorm backward run on the side stream too (csrc/abi.hip): their workspaces
+            # must not be the shared scratch (the next block's kernels would overwrite it under them)
+            ws_attn = torch.empty(max(lib.swin_window_attn_bwd_workspace_bytes(B, H, W, nH, SWIN_BF16), 16), device=dev, dtype=torch.uint8)
+            ws_ln2 = torch.empty(max(ln_bytes, 16), device=dev, dtype=torch.uint8)
+            ws_ln3 = torch.empty(max(ln_bytes, 16), device=dev, dtype=torch.uint8) if has_next else ws_ln2
+            mixed.side_protect(dev, flat, qkv, n1, dx2, dnn if has_next else None, ws_attn, ws_ln2, ws_ln3, dbexp, mean2, lse)
             mixed.side_mark(dev)
         ptrs = (ctypes.c_void_p * 56)(
             _ptr(n1), _ptr(qkv), _ptr(bias_exp), _ptr(lse), _ptr(o), _ptr(x1), _ptr(mean2), _ptr(rstd2), _ptr(n2), _ptr(hpre),

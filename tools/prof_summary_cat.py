@@ -1,0 +1,23 @@
+"""Kernel name -> category (shared by prof_summary.py and step_trace.py)."""
+
+
+def cat(n):
+    if 'win_attn' in n or 'dbias_slab' in n or 'rel_bias' in n: return 'attention'
+    if 'wgrad' in n: return 'wgrad'
+    if 'gemm_bf16' in n: return 'conv/gemm (mine)'
+    if 'Cijk' in n: return 'hipBLASLt'
+    if 'ln_' in n or 'layernorm' in n or 'patch_merge' in n: return 'layernorm'
+    if 'gelu' in n: return 'bias_gelu'
+    if 'roi_align' in n: return 'roi_align'
+    if 'nms' in n: return 'nms'
+    if 'rpn_topk' in n: return 'rpn select (mine)'
+    if 'ts_mlp' in n: return 'fused mlp (mine)'
+    if 'assign_' in n or 'sample_' in n: return 'targets'
+    if 'upsample' in n or 'im2row' in n: return 'fpn/embed (mine)'
+    if 'bn_' in n: return 'batchnorm'
+    if 'loss' in n or 'regress' in n or 'bbox_targets' in n or 'delta2bbox' in n or 'rpn_flatten' in n: return 'losses/targets (mine)'
+    if 'adamw_kernel' in n: return 'optimizer (mine)'
+    if 'multi_tensor' in n: return 'optimizer (torch)'
+    if 'rocprim' in n or 'sort' in n.lower() or 'topk' in n.lower(): return 'sort/topk (torch)'
+    if 'rocclr' in n: return 'memcpy/fill (runtime)'
+    return 'elementwise (torch)'
