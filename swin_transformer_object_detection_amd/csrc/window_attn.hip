@@ -845,6 +845,304 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
     for (int i = lane; i < 3 * HD + 32; i += WAVE) slab[TILE * TILE + i] = i < 3 * HD ? Lm->padacc[i] : 0.f;
 }
 
+// ------------------------------------------------------------------------------------
+// bf16 backward, TWO waves per (window, head) task (round 2).  The one-wave kernel above holds 476 VGPRs and 38.5 KB of LDS
+// per wave: one wave per SIMD, so nothing hides a task's MFMA -> VALU -> LDS dependency chain.  Here a task belongs to a
+// PAIR of waves sharing one BwdLds2:
+//   staging : each wave loads half of the task's q|k|v|dO rows (8 tokens per round over the pair, 7 rounds)
+//   phase A : wave w owns query tile w (32 queries x 64 keys): S^T, dP^T, P, delta, dS, dQ -- independent per query tile, so
+//             the bias / dbias register tiles halve (32 + 32 instead of 64 + 64)
+//   phase B : wave w owns key tile w: dV^T = dO^T P and dK^T = Q^T dS over ALL 64 queries, reading the P / dS rows both
+//             waves wrote
+//   output  : wave w writes dq | dk | dv of tokens 32 w + lane
+// with block-level barriers between the phases (every wave runs the same number of iterations; a pair without a task only
+// meets the barriers).  <= 256 VGPRs per wave and the same 39 KB per task: 8 waves per CU instead of 4.
+// ------------------------------------------------------------------------------------
+struct BwdLds2 {
+    bf16 t[4][TILE][LROW];     // Q, K, V, dO head slices
+    bf16 p[TILE][PROW];        // P        [query][key]
+    bf16 ds[TILE][PROW];       // scale*dS [query][key]
+    float padacc[2][3 * HD + 32];   // per wave: gradient reaching qkv.bias through padded tokens (q|k|v x 32)
+};
+
+struct Bwd2Lane {
+    int lane, c, h, w, tokr, which, part;
+    unsigned ld_off[7];        // interior path: element offset of staged piece i (qkv stride 3C or dout stride C)
+    unsigned st_off;           // interior path: element offset (x 3C) of this lane's token
+};
+
+template <bool INTERIOR>
+__device__ __forceinline__ void bwd2_issue_loads(bf16x8 (&stg)[7], const Bwd2Lane& L, const WinGeom& g, const bf16* __restrict__ qkv,
+                                                 const bf16* __restrict__ dout, const float* __restrict__ qkv_bias, int head,
+                                                 int b, int wr, int wc) {
+    const int C3 = 3 * g.C;
+    const bool is_do = L.which == 3;
+    const int ch = is_do ? head * HD + L.part * 8 : L.which * g.C + head * HD + L.part * 8;
+    if (INTERIOR) {
+        const size_t wbase = (size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift;
+        const bf16* pb = is_do ? dout + wbase * g.C + ch : qkv + wbase * C3 + ch;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) stg[i] = *(const bf16x8*)(pb + L.ld_off[i]);    // unpredicated: see fwd_issue_loads
+    } else {
+        bf16x8 padv;
+        if (is_do) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) padv[e] = (bf16)0.f;
+        } else padv = bias_to_bf16x8(qkv_bias + ch);
+        const bf16* pb = is_do ? dout + ch : qkv + ch;
+        const int stride = is_do ? g.C : C3;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            int t = 8 * i + L.tokr; if (t >= NTOK) t = NTOK - 1;
+            const int src = token_src(g, b, wr, wc, t);
+            const bf16x8 v = *(const bf16x8*)(pb + (size_t)(src >= 0 ? src : 0) * stride);
+            stg[i] = src >= 0 ? v : padv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void win_attn_bwd2_bf16_kernel(
+    const bf16* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
+    const float* __restrict__ lse, const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
+    float* __restrict__ dbias_ws, float* __restrict__ dbias_pad, WinGeom g, float scale, int n_tasks, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave >> 1, w = wave & 1;
+    BwdLds2* Lm = reinterpret_cast<BwdLds2*>(smem_raw) + pair;
+    Bwd2Lane L;
+    L.lane = threadIdx.x & 63; L.c = L.lane & 31; L.h = L.lane >> 5; L.w = w;
+    const int lane = L.lane, c = L.c, h = L.h;
+    bf16(*Qs)[LROW] = Lm->t[0];
+    bf16(*Ks)[LROW] = Lm->t[1];
+    bf16(*Vs)[LROW] = Lm->t[2];
+    bf16(*Ds)[LROW] = Lm->t[3];
+    {
+        uint4 z = {0, 0, 0, 0};
+        uint4* p = (uint4*)Lm;
+        for (int i = lane + WAVE * w; i < (int)(sizeof(BwdLds2) / 16); i += 2 * WAVE) p[i] = z;
+    }
+    const int n_pairs = gridDim.x * 4;
+    int task = blockIdx.x * 4 + pair;
+    float* const slab = dbias_ws + (size_t)task * SLAB;
+    const int head = task % g.nH;                      // n_pairs % nH == 0: constant over the pair's tasks
+    const int C3 = 3 * g.C;
+
+    // this wave's query tile (w): bias and the running bias gradient, [key tile][reg]
+    float biasr[2][16], dbacc[2][16];
+    {
+        const float* bp = bias_exp + (size_t)head * TILE * TILE;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                biasr[kt][reg] = bp[key * TILE + 32 * w + c] * LOG2E;
+                dbacc[kt][reg] = 0.f;
+            }
+    }
+    uint64_t mrow = 0, mcol = 0;
+    if (g.shift > 0) lane_mask_bits(lane, mrow, mcol);
+    const float sl2 = scale * LOG2E;
+
+    // staging: 8 tokens per round over the pair (wave w: tokens 8 i + 4 w + lane/16), 16 pieces per token
+    L.tokr = (lane >> 4) + 4 * w;
+    L.which = (lane & 15) >> 2; L.part = lane & 3;
+    {
+        const int stride = L.which == 3 ? g.C : C3;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            int t = 8 * i + L.tokr; if (t >= NTOK) t = NTOK - 1;
+            L.ld_off[i] = (unsigned)(((t / 7) * g.W + (t % 7)) * stride);
+        }
+        int q = 32 * w + c; if (q >= NTOK) q = NTOK - 1;
+        L.st_off = (unsigned)(((q / 7) * g.W + (q % 7)) * C3);
+    }
+    const int which = L.which, part = L.part, tokr = L.tokr;
+
+    WinPos cur = win_decode(g, task / g.nH);
+    WinStride stride;
+    {
+        const WinPos d = win_decode(g, n_pairs / g.nH);
+        stride.db = d.b; stride.dwr = d.wr; stride.dwc = d.wc;
+    }
+    WinPos nxt = cur;
+    win_advance(nxt, stride, g);
+
+    bf16x8 stg[7];
+    float lse_n = 0.f;
+    const int qtok = 32 * w + c;                      // this lane's query (phase A) and token (output)
+    if (task < n_tasks) {
+        lse_n = lse[(size_t)task * TILE + (qtok < NTOK ? qtok : 0)];
+        if (win_interior(g, cur)) bwd2_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, cur.b, cur.wr, cur.wc);
+        else bwd2_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, cur.b, cur.wr, cur.wc);
+    }
+    __syncthreads();                                  // LDS zeroed by both waves of every pair
+
+    for (int it = 0; it < iters; ++it, task += n_pairs, cur = nxt, win_advance(nxt, stride, g)) {
+        const bool act = task < n_tasks;              // wave-uniform (pair-uniform)
+        const int b = cur.b, wr = cur.wr, wc = cur.wc;
+        const bool interior = win_interior(g, cur);
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                int t = 8 * i + tokr;
+                if (t < NTOK) *(bf16x8*)&Lm->t[which][t][part * 8] = stg[i];
+            }
+        }
+        __syncthreads();                              // (1) the task's tiles are staged
+        const float lse_q = lse_n;
+        if (task + n_pairs < n_tasks) {               // prefetch the next task (its lse row with it: see the one-wave kernel)
+            lse_n = lse[(size_t)(task + n_pairs) * TILE + (qtok < NTOK ? qtok : 0)];
+            if (win_interior(g, nxt)) bwd2_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
+            else bwd2_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
+        }
+        f32x16 dq = {0};
+        if (act) {
+            // ---------------- phase A: query tile w ------------------------------------------------
+            const bool edge = g.shift > 0 && (wr == g.nWh - 1 || wc == g.nWw - 1);
+            uint64_t mbits = 0;
+            if (edge) {
+                if (wr == g.nWh - 1) mbits |= mrow;
+                if (wc == g.nWw - 1) mbits |= mcol;
+            }
+            bf16x8 qf[2], df[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                qf[s] = *(const bf16x8*)&Qs[32 * w + c][16 * s + 8 * h];
+                df[s] = *(const bf16x8*)&Ds[32 * w + c][16 * s + 8 * h];
+            }
+            f32x16 pacc[2], dpacc[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 a = {0}, d = {0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 kf = *(const bf16x8*)&Ks[32 * kt + c][16 * s + 8 * h];
+                    const bf16x8 vf = *(const bf16x8*)&Vs[32 * kt + c][16 * s + 8 * h];
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], a, 0, 0, 0);   // S^T
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[s], d, 0, 0, 0);   // dP^T
+                }
+                pacc[kt] = a;
+                dpacc[kt] = d;
+            }
+            const bool qv = qtok < NTOK;
+            const float l2 = lse_q * LOG2E;
+            float d4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    if (kt == 1 && reg >= 9) { pacc[kt][reg] = 0.f; continue; }   // keys 49..63 (padding): P = 0
+                    float v = fmaf(pacc[kt][reg], sl2, biasr[kt][reg]);
+                    if (edge && ((mbits >> ((kt * 2 + w) * 16 + reg)) & 1)) v += -100.0f * LOG2E;
+                    float p = qv ? __builtin_amdgcn_exp2f(v - l2) : 0.f;
+                    pacc[kt][reg] = p;
+                    d4[reg & 3] = fmaf(p, dpacc[kt][reg], d4[reg & 3]);
+                }
+            const float delta = half_swap_sum((d4[0] + d4[1]) + (d4[2] + d4[3]));
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    bf16x4 p4, s4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = 4 * gq + e;
+                        if (kt == 1 && reg >= 9) { dpacc[kt][reg] = 0.f; p4[e] = (bf16)0.f; s4[e] = (bf16)0.f; continue; }
+                        float ds = pacc[kt][reg] * (dpacc[kt][reg] - delta);
+                        dbacc[kt][reg] += ds;
+                        ds *= scale;
+                        dpacc[kt][reg] = ds;
+                        p4[e] = (bf16)pacc[kt][reg];
+                        s4[e] = (bf16)ds;
+                    }
+                    *(bf16x4*)&Lm->p[qtok][32 * kt + 8 * gq + 4 * h] = p4;
+                    *(bf16x4*)&Lm->ds[qtok][32 * kt + 8 * gq + 4 * h] = s4;
+                }
+            // dQ^T = K^T (scale dS^T)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 kc = lds_tr_frag_perm(Ks, 32 * kt + 16 * s, lane);
+                    bf16x8 sf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sf[j] = (bf16)dpacc[kt][8 * s + j];
+                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, sf, dq, 0, 0, 0);
+                }
+        }
+        __syncthreads();                              // (2) P / dS rows of both query tiles are in LDS
+
+        if (act) {
+            // ---------------- phase B: key tile w: dV^T = dO^T P ,  dK^T = Q^T (scale dS) ----------
+            f32x16 dv = {0}, dk = {0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 doc = lds_tr_frag_lin<LROW>(&Ds[0][0], 16 * ks, 0, lane);
+                bf16x8 qc = lds_tr_frag_lin<LROW>(&Qs[0][0], 16 * ks, 0, lane);
+                bf16x8 pb = lds_tr_frag_lin<PROW>(&Lm->p[0][0], 16 * ks, 32 * w, lane);
+                bf16x8 sb = lds_tr_frag_lin<PROW>(&Lm->ds[0][0], 16 * ks, 32 * w, lane);
+                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doc, pb, dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qc, sb, dk, 0, 0, 0);
+            }
+            // ---------------- dq | dk | dv of token 32 w + c ----------------------------------------
+            bool pad = false;
+            if (qtok < NTOK) {
+                bf16* op = nullptr;
+                if (interior) {
+                    op = dqkv + ((size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift) * C3 + L.st_off + head * HD + 4 * h;
+                } else {
+                    int src = token_src(g, b, wr, wc, qtok);
+                    if (src >= 0) op = dqkv + (size_t)src * C3 + head * HD + 4 * h;
+                    else pad = true;
+                }
+                if (op) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        bf16x4 a, bb, cc;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[e] = (bf16)dq[4 * gq + e];
+                            bb[e] = (bf16)dk[4 * gq + e];
+                            cc[e] = (bf16)dv[4 * gq + e];
+                        }
+                        *(bf16x4*)(op + 8 * gq) = a;
+                        *(bf16x4*)(op + g.C + 8 * gq) = bb;
+                        *(bf16x4*)(op + 2 * g.C + 8 * gq) = cc;
+                    }
+                }
+            }
+            if (__ballot(pad)) {                       // wave-uniform; see the one-wave kernel for the history of this form
+                float* bp = Lm->padacc[w] + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float a = pad ? dq[r] : 0.f, bq = pad ? dk[r] : 0.f, cv = pad ? dv[r] : 0.f;
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) {
+                        a += __shfl_xor(a, o); bq += __shfl_xor(bq, o); cv += __shfl_xor(cv, o);
+                    }
+                    if (c == 0) {
+                        const int d = (r & 3) + 8 * (r >> 2);
+                        bp[d] += a; bp[HD + d] += bq; bp[2 * HD + d] += cv;
+                    }
+                }
+            }
+        }
+        __syncthreads();                              // (3) all reads of this task's tiles are done
+    }
+    // this pair's partial relative-position-bias gradient -> its slab (wave w: query columns 32 w ..)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            slab[key * TILE + 32 * w + c] = dbacc[kt][reg];
+        }
+    if (w == 0)
+        for (int i = lane; i < 3 * HD + 32; i += WAVE)
+            slab[TILE * TILE + i] = i < 3 * HD ? Lm->padacc[0][i] + Lm->padacc[1][i] : 0.f;
+}
+
 // dbias_exp[head][key][query] += sum over the slabs of that head (slab s belongs to head s % nH);
 // dbias_pad[which*C + head*32 + d] += the slabs' pad-token part.  grid.y splits the slab range.
 __global__ __launch_bounds__(256) void dbias_slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dbias_exp,
@@ -1024,7 +1322,12 @@ static int attn_bwd_blocks(int n_tasks, int nH) {
     static const int forced = getenv("SWIN_ATTN_BWD_BLOCKS") ? atoi(getenv("SWIN_ATTN_BWD_BLOCKS")) : 0;   // development sweep
     if (forced > 0) return round_blocks(forced, n_tasks, nH);
     const bool many_rounds = n_tasks >= 6 * 960;                 // >= 6 rounds at 240 blocks
-    return round_blocks(many_rounds ? 240 : 384, n_tasks, nH);
+    // two-waves-per-task kernel, swept over 192..512 blocks (round 2): stage 1 (8004 tasks) 72.9 us at 240 (256: 73.2, 320+: 84-88);
+    // stage 2 (4140) 56.5 at 256 (240: 58.4, 384: 57.9); stages 3 / 4 (2304 / 1152 tasks: whole rounds at 768 pairs) 42.0 / 39.5 at
+    // 192 (256: 49.1 / 40.3, 384: 45.2 / 40.9).  One block per CU (158 KB of LDS): more blocks than CUs only add a second wave of blocks.
+    static const int one_wave = getenv("SWIN_ATTN_BWD_WAVES") ? atoi(getenv("SWIN_ATTN_BWD_WAVES")) == 1 : 0;
+    if (one_wave) return round_blocks(many_rounds ? 240 : 384, n_tasks, nH);
+    return round_blocks(many_rounds ? 240 : (n_tasks <= 2400 ? 192 : 256), n_tasks, nH);
 }
 
 extern "C" int64_t swin_window_attn_bwd_workspace_bytes(int B, int H, int W, int nH, int dtype) {
@@ -1048,16 +1351,25 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
         if (!workspace) return SWIN_ERR_BAD_ARG;
         int blocks = attn_bwd_blocks(n_tasks, nH);
         static bool attr_set[16] = {};                       // per device: the attribute belongs to the device's code object
-        size_t shm = 4 * sizeof(BwdLds);
+        static const int two_waves = getenv("SWIN_ATTN_BWD_WAVES") ? atoi(getenv("SWIN_ATTN_BWD_WAVES")) != 1 : 1;   // 1: the one-wave-per-task kernel (A/B)
+        size_t shm = two_waves ? 4 * sizeof(BwdLds2) : 4 * sizeof(BwdLds);
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
         if (!attr_set[dev]) {
             if (hipFuncSetAttribute((const void*)win_attn_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shm) != hipSuccess) return SWIN_ERR_LAUNCH;
+                                    (int)(4 * sizeof(BwdLds))) != hipSuccess) return SWIN_ERR_LAUNCH;
+            if (hipFuncSetAttribute((const void*)win_attn_bwd2_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(4 * sizeof(BwdLds2))) != hipSuccess) return SWIN_ERR_LAUNCH;
             attr_set[dev] = true;
         }
-        win_attn_bwd_bf16_kernel<<<blocks, 256, shm, s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
-                                                          (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks);
+        if (two_waves) {
+            const int iters = (n_tasks + blocks * 4 - 1) / (blocks * 4);
+            win_attn_bwd2_bf16_kernel<<<blocks, 512, shm, s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
+                                                               (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks, iters);
+        } else {
+            win_attn_bwd_bf16_kernel<<<blocks, 256, shm, s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
+                                                              (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks);
+        }
         int n = nH * (TILE * TILE + 3 * HD);
         dim3 rgrid((n + 255) / 256, 16);
         hipStream_t rs = s;                       // bias-gradient reduce: off the data-gradient chain (see csrc/abi.hip)

@@ -317,7 +317,7 @@ def test_relu_backward_rides_in_the_producing_kernel(pkg):
     assert (n_plain, n_fused) == (2, 1)
     assert torch.equal(plain[0], fused[0]) and torch.equal(plain[1], fused[1])          # y and dx: deterministic kernels
     for a, b in zip(plain[2:], fused[2:]):                                              # weight gradients: fp32 atomics
-        _close(a, b, 1e-3 * float(a.abs().max()), "weight gradient, fused vs plain")
+        _close(a, b, _bf16_tol(a, 2), "weight gradient, fused vs plain")                    # returned rounded to bf16: an ulp may flip
     # against fp32 autograd
     xr = x0.float().requires_grad_(True)
     w1, w2 = c1.weight.detach().bfloat16().float().requires_grad_(True), c2.weight.detach().bfloat16().float().requires_grad_(True)
