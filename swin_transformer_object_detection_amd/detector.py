@@ -19,6 +19,7 @@ get their own kernels); the hot-path ops (``ops.batched_nms``, ``ops.RoIAlign``)
 Everything between the kernels runs on the device: the reference's numpy round trips in
 ``mask_target`` are gone.
 """
+import contextlib
 import math
 
 import numpy as np
@@ -432,17 +433,27 @@ class _RpnHeads(torch.autograd.Function):
         dwb = mixed.step_buffer(key, 'rpn_dw', (N1, C), tok.device)
         dbb = mixed.step_buffer(key, 'rpn_db', (N1,), tok.device)
         ensure_scratch(tok.device)
-        call("wgrad_linear_bf16", _p(dy), _p(tok.contiguous()), _p(dwb), _p(dbb), dy.shape[0], N1, C, _s())
-        if mixed.use_end(key) > 0:
-            return dx, None, None, None, None, None, None, None, None
-        # last level: hand the accumulated gradients to the four parameters
-        mixed.step_buffer_done(key, 'rpn_dw'); mixed.step_buffer_done(key, 'rpn_db')
         parts = ((head.rpn_cls.weight, dwb[:A].view(A, C, 1, 1)), (head.rpn_reg.weight, dwb[A:5 * A].view(4 * A, C, 1, 1)),
                  (head.rpn_cls.bias, dbb[:A]), (head.rpn_reg.bias, dbb[A:5 * A]))
+        sinks = [mixed.grad_sink(p) for p, _ in parts]
+        all_sinks = all(sk is not None and sk[0].shape == g.shape for sk, (_, g) in zip(sinks, parts))
+        tokc = tok.contiguous()
+        last = mixed.use_end(key) == 0
+        # with every parameter delivered through a reducer sink nothing on this stream reads the result: second stream
+        with (mixed.on_side(tok.device, dy, tokc) if all_sinks else contextlib.nullcontext()):
+            call("wgrad_linear_bf16", _p(dy), _p(tokc), _p(dwb), _p(dbb), dy.shape[0], N1, C, _s())
+            if last and all_sinks:                      # last level: hand the accumulated gradients to the four parameters
+                for sk, (_, g) in zip(sinks, parts):
+                    sk[0].add_(g)
+        if not last:
+            return dx, None, None, None, None, None, None, None, None
+        mixed.step_buffer_done(key, 'rpn_dw'); mixed.step_buffer_done(key, 'rpn_db')
         outs = []
-        for (p, g), dt_ in zip(parts, ctx.dts):
-            sk = mixed.grad_sink(p)
-            if sk is not None and sk[0].shape == g.shape:
+        for sk, (p, g), dt_ in zip(sinks, parts, ctx.dts):
+            if all_sinks:
+                sk[1]()
+                outs.append(None)
+            elif sk is not None and sk[0].shape == g.shape:
                 sk[0].add_(g)
                 sk[1]()
                 outs.append(None)
@@ -1408,13 +1419,22 @@ class MaskRCNN(nn.Module):
         losses = {}
         img_shapes = [m['img_shape'] for m in img_metas]
         cls_scores, bbox_preds = self.rpn_head(x)
-        losses.update(self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_shapes))
+        # The RPN's training branch (anchor assignment, sampling, loss: ~30 small latency-bound launches) does not feed the RoI
+        # stage: it runs on the second stream next to proposal selection / NMS and the RoI heads; the main stream joins before the
+        # losses are summed (parse_losses) -- autograd runs the branch's backward on that stream too.
+        with mixed.on_side(cls_scores[0].device, *cls_scores, *bbox_preds) as side:
+            rpn_losses = self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_shapes)
+        if side is not None:
+            for v in rpn_losses.values():
+                v.record_stream(torch.cuda.current_stream(v.device))
+        losses.update(rpn_losses)
         proposal_cfg = _cfg_get(self.train_cfg, 'rpn_proposal', _cfg_get(self.test_cfg, 'rpn'))
         proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_shapes, proposal_cfg, static=True)
         if isinstance(self.roi_head, CascadeRoIHead):
             losses.update(self.roi_head.forward_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, img_shapes))
         else:
             losses.update(self.roi_head.forward_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks))
+        mixed.side_join()
         return losses
 
     @torch.no_grad()
