@@ -26,9 +26,9 @@ Design for MI355X / xGMI (one process per GPU, backend "nccl" == RCCL):
     shows by itself how much of the exchange overlapped backward.
 Works unchanged on CPU with the gloo backend (tests/test_ddp_gloo.py, world_size 2).
 """
-import time
-
+import contextlib
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -49,6 +49,7 @@ class BucketedGradReducer:
         self._l2b = {}
         self._next = 0                      # index of the next bucket whose collective may be issued
         self._t0 = None
+        self._home = None                   # the stream the step is issued on (set by zero_grad)
         self.timeline = []                  # per step: [(bucket, launch_s, done_s | None, bytes)] relative to mark_backward_start
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
@@ -123,14 +124,19 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         from . import mixed
-        mixed.side_join()           # weight-gradient kernels on the second stream may still be writing this bucket's views
-        self._gather(b)
-        b['launched'] = True
-        if self.world > 1:
-            if self.average:
-                b['flat'].div_(self.world)
-            b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.timeline.append([b['no'], self._now(), None, b['flat'].numel() * 4])
+        # A bucket may complete inside a backward node that autograd runs on an auxiliary stream (mixed.small_branch): gather and
+        # collective are always issued on the reducer's home stream, after it has waited for the auxiliary streams (weight-gradient
+        # kernels may still be writing this bucket's views there).
+        home = self._home if (self._home is not None and b['flat'].is_cuda) else None
+        with (torch.cuda.stream(home) if home is not None else contextlib.nullcontext()):
+            mixed.side_join()
+            self._gather(b)
+            b['launched'] = True
+            if self.world > 1:
+                if self.average:
+                    b['flat'].div_(self.world)
+                b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.timeline.append([b['no'], self._now(), None, b['flat'].numel() * 4])
 
     def _issue_ready(self, force=False):
         """issue the collectives of buckets _next, _next+1, ... while they are complete (all, when force)"""
@@ -201,6 +207,8 @@ class BucketedGradReducer:
         """Before forward: ONE memset per bucket (kernels accumulate into the views) and drop the leaves' grads."""
         from . import mixed
         mixed.reset_step()
+        if self.buckets and self.buckets[0]['flat'].is_cuda:
+            self._home = torch.cuda.current_stream(self.buckets[0]['flat'].device)      # the stream the step is issued on
         self.timeline = []
         for b in self.buckets:
             b['flat'].zero_()

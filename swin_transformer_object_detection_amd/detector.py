@@ -517,22 +517,27 @@ class RPNHead(nn.Module):
                 b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias, torch.zeros(pad, device=w.device)], 0).to(dt)
         ys = []
         for x in feats:
-            x = _conv(x, self.rpn_conv, dt, padding=1, relu=True)
-            if dt == torch.bfloat16:
-                N, C, H, W = x.shape
-                tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
-                if fused:
-                    # the four leaves only route gradients (no cast: a parameter without a shadow is passed as it is)
-                    y = _RpnHeads.apply(tok, w, b, self, mixed.leaf(self.rpn_cls.weight), mixed.leaf(self.rpn_reg.weight),
-                                        self.rpn_cls.bias, self.rpn_reg.bias, True).view(N, H, W, -1)
+            # a small level's conv + heads (P4-P6: 10-126 tiles, 40 us each) run on the second stream next to the big levels
+            with (mixed.small_branch(x) if (fused and dt == torch.bfloat16) else contextlib.nullcontext()) as sd:
+                x = _conv(x, self.rpn_conv, dt, padding=1, relu=True)
+                if dt == torch.bfloat16:
+                    N, C, H, W = x.shape
+                    tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
+                    if fused:
+                        # the four leaves only route gradients (no cast: a parameter without a shadow is passed as it is)
+                        y = _RpnHeads.apply(tok, w, b, self, mixed.leaf(self.rpn_cls.weight), mixed.leaf(self.rpn_reg.weight),
+                                            self.rpn_cls.bias, self.rpn_reg.bias, True).view(N, H, W, -1)
+                    else:
+                        y = ops.linear(tok, w, b, dt).view(N, H, W, -1)
+                    cls.append(y[..., :A].permute(0, 3, 1, 2))
+                    reg.append(y[..., A:5 * A].permute(0, 3, 1, 2))
+                    ys.append(y.view(N, H * W, -1))
                 else:
-                    y = ops.linear(tok, w, b, dt).view(N, H, W, -1)
-                cls.append(y[..., :A].permute(0, 3, 1, 2))
-                reg.append(y[..., A:5 * A].permute(0, 3, 1, 2))
-                ys.append(y.view(N, H * W, -1))
-            else:
-                cls.append(_conv(x, self.rpn_cls, dt))
-                reg.append(_conv(x, self.rpn_reg, dt))
+                    cls.append(_conv(x, self.rpn_cls, dt))
+                    reg.append(_conv(x, self.rpn_reg, dt))
+            if sd is not None:
+                mixed.side_outputs(x, y)
+        mixed.side_join()            # the levels computed on the second stream (here and in the FPN) are read below / by the RoI heads
         self._flat = None
         if ys:
             # the anchor-major flattening that loss() and get_bboxes() need (anchor_head.py:474-486, rpn_head.py:119-125):
@@ -1415,7 +1420,16 @@ class MaskRCNN(nn.Module):
         return self.neck(x) if self.neck is not None else x
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_masks=None, proposals=None):
-        x = self.extract_feat(img)
+        if self.neck is not None and hasattr(self.neck, 'defer_join'):
+            # the small pyramid levels' convs run on the second stream (mixed.small_branch); here the RPN head, which continues
+            # on that stream, joins -- a stand-alone extract_feat() joins at the end of the neck
+            self.neck.defer_join = True
+            try:
+                x = self.extract_feat(img)
+            finally:
+                self.neck.defer_join = False
+        else:
+            x = self.extract_feat(img)
         losses = {}
         img_shapes = [m['img_shape'] for m in img_metas]
         cls_scores, bbox_preds = self.rpn_head(x)

@@ -8,6 +8,8 @@ Execution plan: feature maps stay channels-last (the backbone's token-major buff
 kernel (``ops.upsample_add``); the 3x3 output convs go to the library conv (MIOpen) in
 channels-last; the extra pyramid level ``max_pool2d(k=1, s=2)`` is a strided view.
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -69,6 +71,7 @@ class FPN(nn.Module):
         assert num_outs >= self.num_ins
         self.fp16_enabled = False
         self.compute_dtype = compute_dtype
+        self.defer_join = False          # True (set by the detector around its training forward): the caller joins the second stream
         self.upsample_cfg = upsample_cfg.copy()
         self.lateral_convs = nn.ModuleList()
         self.fpn_convs = nn.ModuleList()
@@ -99,13 +102,28 @@ class FPN(nn.Module):
             laterals.append(y.view(N, H, W, self.out_channels).permute(0, 3, 1, 2))
         for i in range(len(laterals) - 1, 0, -1):               # fpn.py:182-191
             laterals[i - 1] = ops.upsample_add(laterals[i - 1], laterals[i])
+        branched = False
         if dt == torch.bfloat16 and self.out_channels % 64 == 0:
-            outs = [ops.conv3x3(laterals[i], fc.conv.weight, fc.conv.bias) for i, fc in enumerate(self.fpn_convs)]
+            outs = []
+            for i, fc in enumerate(self.fpn_convs):
+                # the small levels' convs (P4, P5: one block per CU on half the chip) go to the second stream
+                with mixed.small_branch(laterals[i]) as sd:
+                    o = ops.conv3x3(laterals[i], fc.conv.weight, fc.conv.bias)
+                if sd is not None:
+                    mixed.side_outputs(o)
+                    branched = True
+                outs.append(o)
         else:                                                   # fp32 parity path: library conv
             outs = [F.conv2d(laterals[i].contiguous(memory_format=torch.channels_last),
                              self._w(fc.conv.weight).contiguous(memory_format=torch.channels_last),
                              self._w(fc.conv.bias), padding=1)
                     for i, fc in enumerate(self.fpn_convs)]     # fpn.py:195-197
         for _ in range(self.num_outs - len(outs)):              # fpn.py:202-204: max_pool2d(k=1, s=2)
-            outs.append(outs[-1][:, :, ::2, ::2].contiguous(memory_format=torch.channels_last))
+            with (mixed.small_branch(outs[-1]) if branched else contextlib.nullcontext()) as sd:
+                o = outs[-1][:, :, ::2, ::2].contiguous(memory_format=torch.channels_last)
+            if sd is not None:
+                mixed.side_outputs(o)
+            outs.append(o)
+        if branched and not self.defer_join:
+            mixed.side_join()                                    # a caller that does not join itself (the detector's RPN head does)
         return tuple(outs)

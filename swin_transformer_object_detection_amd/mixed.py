@@ -43,8 +43,9 @@ def clear_sinks(ids=None):
 # the producing kernel (fork); the main stream waits for the side stream before a bucket is reduced and at
 # reducer.finish() (join).  Tensors the side stream reads are protected from reuse with Tensor.record_stream.
 _SIDE_ON = os.environ.get("SWIN_WGRAD_STREAM", "1") != "0"      # 0: everything on one stream (A/B)
-_SIDE = {}            # device index -> torch.cuda.Stream
-_SIDE_DIRTY = set()   # device indices with side-stream work since the last join
+_SIDE = {}            # (device index, kind) -> torch.cuda.Stream; kind 'side': weight gradients and reductions (work nothing waits
+                      # for), 'branch': data-dependent work of an independent sub-graph (it must not queue behind the former)
+_SIDE_DIRTY = set()   # (device index, kind) with work since the last join
 
 
 def side_enabled():
@@ -57,21 +58,26 @@ def set_side_enabled(on):
     _SIDE_ON = bool(on)
 
 
-def side_stream(device):
-    """The weight-gradient stream of ``device`` (created on first use), or None when the feature is off."""
+def _dev_index(device):
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def side_stream(device, kind='side'):
+    """The weight-gradient stream (or, kind='branch', the sub-graph stream) of ``device``, created on first use; None when the
+    feature is off."""
     if not _SIDE_ON or device.type != 'cuda':
         return None
-    i = device.index if device.index is not None else torch.cuda.current_device()
-    s = _SIDE.get(i)
+    k = (_dev_index(device), kind)
+    s = _SIDE.get(k)
     if s is None:
-        s = _SIDE[i] = torch.cuda.Stream(device=i)
+        s = _SIDE[k] = torch.cuda.Stream(device=k[0])
     return s
 
 
-def side_protect(device, *tensors):
+def side_protect(device, *tensors, kind='side'):
     """Tell the caching allocator that the side stream reads these tensors (their memory is not handed out again until
     the side stream has passed the point of their release)."""
-    s = side_stream(device)
+    s = side_stream(device, kind)
     if s is None:
         return
     for t in tensors:
@@ -79,31 +85,61 @@ def side_protect(device, *tensors):
             t.record_stream(s)
 
 
-def side_mark(device):
-    i = device.index if device.index is not None else torch.cuda.current_device()
-    _SIDE_DIRTY.add(i)
+def side_mark(device, kind='side'):
+    _SIDE_DIRTY.add((_dev_index(device), kind))
 
 
 @contextlib.contextmanager
-def on_side(device, *tensors):
-    """Run the enclosed launches on the weight-gradient stream, after everything enqueued so far on the current
-    stream; ``tensors`` = what they read.  No-op (current stream) when the feature is off.  Reducer callbacks must be
-    made OUTSIDE this context (they may enqueue collectives relative to the current stream)."""
-    s = side_stream(device)
+def on_side(device, *tensors, kind='side'):
+    """Run the enclosed launches on the weight-gradient stream (kind='branch': the sub-graph stream), after everything
+    enqueued so far on the current stream; ``tensors`` = what they read.  No-op (current stream) when the feature is off.
+    Reducer callbacks must be made OUTSIDE this context (they may enqueue collectives relative to the current stream)."""
+    s = side_stream(device, kind)
     if s is None:
         yield None
         return
-    s.wait_stream(torch.cuda.current_stream(device))
-    side_protect(device, *tensors)
-    side_mark(device)
+    cur = torch.cuda.current_stream(device)
+    if cur != s:
+        s.wait_stream(cur)
+    side_protect(device, *tensors, kind=kind)
+    side_mark(device, kind)
     with torch.cuda.stream(s):
         yield s
 
 
+# Off by default: measured round 2 (bench.py, same box) 12.53 ms per step without, 12.93 ms with the small levels on their own
+# stream (and 13.6 ms when they shared the weight-gradient stream, queueing behind its backlog in backward) -- the engine's
+# cross-stream events and the extra record_stream / wait_stream host work cost more than the idle CUs were worth.
+_SMALL_ON = os.environ.get("SWIN_SMALL_LEVELS_SIDE", "0") == "1"
+
+
+def small_branch(x, limit=16384):
+    """Context for the work of ONE small pyramid level (N*H*W <= limit pixels: P4-P6 at 800x1280) in training: its 3x3 convs
+    and head GEMMs occupy 10-126 of the 256 CUs for 40 us each, so they run on the second stream next to the big levels'
+    kernels on the main one -- a stream of its own: in backward these are data gradients the FPN waits for, which must not
+    queue behind the weight-gradient stream's backlog (measured: sharing that stream cost 1.2 ms per step).  Autograd runs
+    their backward on the same stream.  Yields the stream, or None when the level stays on the main stream.  The caller hands results that the main stream will read to ``side_outputs`` and joins
+    (``side_join``) before reading them."""
+    if (_SMALL_ON and _SIDE_ON and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4
+            and x.shape[0] * x.shape[2] * x.shape[3] <= limit):
+        return on_side(x.device, x, kind='branch')
+    return contextlib.nullcontext()
+
+
+def side_outputs(*tensors):
+    """Tensors produced on the second stream that the current (main) stream will read: their memory must not return to the
+    second stream's pool while main-stream work still uses it."""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(torch.cuda.current_stream(t.device))
+
+
 def side_join():
     """The current stream of every device with outstanding side-stream work waits for it."""
-    for i in list(_SIDE_DIRTY):
-        torch.cuda.current_stream(i).wait_stream(_SIDE[i])
+    for k in list(_SIDE_DIRTY):
+        cur = torch.cuda.current_stream(k[0])
+        if cur != _SIDE[k]:
+            cur.wait_stream(_SIDE[k])
     _SIDE_DIRTY.clear()
 
 

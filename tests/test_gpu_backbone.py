@@ -307,12 +307,17 @@ def test_weight_gradient_stream_gives_the_same_gradients(pkg):
         again = run(False)              # the run-to-run noise of the float atomics (RoIAlign backward feeds bf16 chains)
         got = run(True)
         assert mixed.side_stream(torch.device("cuda", 0)) is not None
+        small_was, mixed._SMALL_ON = mixed._SMALL_ON, True      # + the small pyramid levels on the sub-graph stream (off by default)
+        try:
+            got_small = run(True)
+        finally:
+            mixed._SMALL_ON = small_was
         for it in range(3):
-            for fr, fa, fg in zip(ref[it], again[it], got[it]):
+            for fr, fa, fg, fs in zip(ref[it], again[it], got[it], got_small[it]):
                 scale = float(fr.abs().max())
                 noise = float((fr - fa).abs().max())
-                err = float((fr - fg).abs().max())
-                assert err <= 4 * noise + 2e-3 * scale + 1e-7, (it, err, noise, scale)
+                for err in (float((fr - fg).abs().max()), float((fr - fs).abs().max())):
+                    assert err <= 4 * noise + 2e-3 * scale + 1e-7, (it, err, noise, scale)
     finally:
         mixed.set_side_enabled(was)
         red.release()
