@@ -163,7 +163,8 @@ class BucketedGradReducer:
             b['pending'] -= 1
             if b['pending'] == 0:
                 b['ready'] = True
-                self._issue_ready()
+                if self.world > 1:          # one process: nothing to overlap -- everything is gathered at finish(), after ONE join
+                    self._issue_ready()
 
     def _pre(self, b, i, g):
         b['real'][i] = g is not None

@@ -20,6 +20,7 @@ Everything between the kernels runs on the device: the reference's numpy round t
 ``mask_target`` are gone.
 """
 import contextlib
+import ctypes
 import math
 
 import numpy as np
@@ -440,9 +441,11 @@ class _RpnHeads(torch.autograd.Function):
         tokc = tok.contiguous()
         last = mixed.use_end(key) == 0
         # with every parameter delivered through a reducer sink nothing on this stream reads the result: second stream
-        with (mixed.on_side(tok.device, dy, tokc) if all_sinks else contextlib.nullcontext()):
-            call("wgrad_linear_bf16", _p(dy), _p(tokc), _p(dwb), _p(dbb), dy.shape[0], N1, C, _s())
-            if last and all_sinks:                      # last level: hand the accumulated gradients to the four parameters
+        sst = mixed.fork_to_side(tok.device, dy, tokc) if all_sinks else None
+        call("wgrad_linear_bf16", _p(dy), _p(tokc), _p(dwb), _p(dbb), dy.shape[0], N1, C,
+             ctypes.c_void_p(sst) if sst is not None else _s())
+        if last and all_sinks:                          # last level: hand the accumulated gradients to the four parameters
+            with mixed.on_side(tok.device):
                 for sk, (_, g) in zip(sinks, parts):
                     sk[0].add_(g)
         if not last:

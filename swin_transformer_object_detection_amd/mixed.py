@@ -41,7 +41,7 @@ def clear_sinks(ids=None):
 # weight-gradient launches go to a second stream where they fill the idle issue slots of the data-gradient chain
 # (DESIGN section 5 "two streams").  Ordering: the side stream waits for an event recorded on the main stream after
 # the producing kernel (fork); the main stream waits for the side stream before a bucket is reduced and at
-# reducer.finish() (join).  Tensors the side stream reads are protected from reuse with Tensor.record_stream.
+# reducer.finish() (join).  Tensors the side stream reads are kept alive until the join (side_keep).
 _SIDE_ON = os.environ.get("SWIN_WGRAD_STREAM", "1") != "0"      # 0: everything on one stream (A/B)
 _SIDE = {}            # (device index, kind) -> torch.cuda.Stream; kind 'side': weight gradients and reductions (work nothing waits
                       # for), 'branch': data-dependent work of an independent sub-graph (it must not queue behind the former)
@@ -89,6 +89,47 @@ def side_mark(device, kind='side'):
     _SIDE_DIRTY.add((_dev_index(device), kind))
 
 
+# Tensors an auxiliary stream reads are kept alive HERE until the next join instead of being handed to the allocator with
+# Tensor.record_stream: that costs an event per freed block plus polling -- with ~10 tensors per Swin block it made the step
+# host-bound (tools/host_time.py: 13.8 ms of host work per step against 11.7 ms on one stream).  After the join the main
+# stream has waited for the auxiliary ones, so dropping the references (the memory returns to the main stream's pool) is safe.
+_SIDE_KEEP = []
+
+
+def side_keep(*tensors):
+    _SIDE_KEEP.extend(t for t in tensors if t is not None)
+
+
+_FORK_EVENTS = {}     # (device index, slot) -> torch.cuda.Event, reused round-robin (creating one per fork costs ~10 us of host time)
+_FORK_NEXT = [0]
+
+
+def _fork(cur, s, i):
+    """``s`` waits for everything enqueued on ``cur`` so far."""
+    k = (i, _FORK_NEXT[0] & 63)
+    _FORK_NEXT[0] += 1
+    ev = _FORK_EVENTS.get(k)
+    if ev is None:
+        ev = _FORK_EVENTS[k] = torch.cuda.Event()
+    ev.record(cur)
+    s.wait_event(ev)
+
+
+def fork_to_side(device, *tensors):
+    """For a launch through the C ABI that nothing on the current stream waits for (a weight gradient): make the side stream
+    wait for the current one, keep ``tensors`` (what the launch reads) alive until the next join, and return the side stream's
+    handle to pass as the call's stream argument -- or None when the feature is off (use the current stream)."""
+    s = side_stream(device)
+    if s is None:
+        return None
+    cur = torch.cuda.current_stream(device)
+    if cur != s:
+        _fork(cur, s, _dev_index(device))
+    side_keep(*tensors)
+    side_mark(device)
+    return s.cuda_stream
+
+
 @contextlib.contextmanager
 def on_side(device, *tensors, kind='side'):
     """Run the enclosed launches on the weight-gradient stream (kind='branch': the sub-graph stream), after everything
@@ -100,8 +141,8 @@ def on_side(device, *tensors, kind='side'):
         return
     cur = torch.cuda.current_stream(device)
     if cur != s:
-        s.wait_stream(cur)
-    side_protect(device, *tensors, kind=kind)
+        _fork(cur, s, _dev_index(device))
+    side_keep(*tensors)
     side_mark(device, kind)
     with torch.cuda.stream(s):
         yield s
@@ -139,8 +180,9 @@ def side_join():
     for k in list(_SIDE_DIRTY):
         cur = torch.cuda.current_stream(k[0])
         if cur != _SIDE[k]:
-            cur.wait_stream(_SIDE[k])
+            _fork(_SIDE[k], cur, k[0])
     _SIDE_DIRTY.clear()
+    _SIDE_KEEP.clear()
 
 
 # ---- per-step caches and use counts ------------------------------------------------------------------------------

@@ -496,10 +496,17 @@ class _Conv3x3(torch.autograd.Function):
                 # sink mode: nothing on the main stream reads the result before the reducer -> weight-gradient stream
                 last = mixed.use_end(w_master) == 0
                 side_ok = bs is not None or not need_b        # a bias gradient returned through autograd is read on the main stream
-                with (mixed.on_side(x.device, dy, x) if side_ok else contextlib.nullcontext()):
-                    call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), _p(dbf), N, H, W, Cin, Cout, _s())
-                    if last and not direct:
-                        ws[0].add_(dwf.permute(0, 3, 1, 2))
+                if direct:
+                    # one C call: fork the side stream behind the producer of dy and launch there (no stream context, no events
+                    # made per call: the step had become host-bound on exactly that bookkeeping)
+                    sst = mixed.fork_to_side(x.device, dy, x) if side_ok else None
+                    call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), _p(dbf), N, H, W, Cin, Cout,
+                         ctypes.c_void_p(sst) if sst is not None else _s())
+                else:
+                    with (mixed.on_side(x.device, dy, x) if side_ok else contextlib.nullcontext()):
+                        call("wgrad_conv3x3_nhwc_bf16", _p(dy), _p(x), _p(dwf), _p(dbf), N, H, W, Cin, Cout, _s())
+                        if last:
+                            ws[0].add_(dwf.permute(0, 3, 1, 2))
 
                 def notify(ws=ws, bs=bs, w_master=w_master, direct=direct):
                     if not direct:
@@ -608,9 +615,9 @@ class _LinearBf16(torch.autograd.Function):
             if need_b:
                 dbf = bs[0] if bs is not None else torch.zeros(N1, device=x.device, dtype=torch.float32)
             ensure_scratch(x2.device)
-            with (mixed.on_side(x2.device, dy2, x2) if ws is not None and (bs is not None or not need_b)
-                  else contextlib.nullcontext()):
-                call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2, _s())
+            sst = mixed.fork_to_side(x2.device, dy2, x2) if ws is not None and (bs is not None or not need_b) else None
+            call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2,
+                 ctypes.c_void_p(sst) if sst is not None else _s())
             if ws is not None:
                 def finalize(ws=ws, bs=bs, w_master=w_master):
                     mixed.set_pending(w_master, None)

@@ -379,7 +379,7 @@ class _SwinBlockFn(torch.autograd.Function):
             ws_attn = torch.empty(max(lib.swin_window_attn_bwd_workspace_bytes(B, H, W, nH, SWIN_BF16), 16), device=dev, dtype=torch.uint8)
             ws_ln2 = torch.empty(max(ln_bytes, 16), device=dev, dtype=torch.uint8)
             ws_ln3 = torch.empty(max(ln_bytes, 16), device=dev, dtype=torch.uint8) if has_next else ws_ln2
-            mixed.side_protect(dev, flat, qkv, n1, dx2, dnn if has_next else None, ws_attn, ws_ln2, ws_ln3, dbexp, mean2, lse)
+            mixed.side_keep(flat, qkv, n1, dx2, dnn if has_next else None, ws_attn, ws_ln2, ws_ln3, dbexp, mean2, lse)
             mixed.side_mark(dev)
         ptrs = (ctypes.c_void_p * 56)(
             _ptr(n1), _ptr(qkv), _ptr(bias_exp), _ptr(lse), _ptr(o), _ptr(x1), _ptr(mean2), _ptr(rstd2), _ptr(n2), _ptr(hpre),

@@ -1,5 +1,6 @@
-"""cProfile of the host side of the training step (development aid): where the ~12 ms of Python / dispatch time per step go."""
-import cProfile, io, os, pstats, sys
+"""Is the training step host-bound?  Host time to ENQUEUE n steps (no synchronisation) against the time until the GPU has
+finished them (development aid).  host ~ total: the GPU waits for the host."""
+import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swin_transformer_object_detection_amd import data, ddp, detector, mixed, presets
@@ -20,16 +21,15 @@ def step():
 
 for _ in range(8): step()
 torch.cuda.synchronize()
-n = 20
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(n): step()
-pr.disable()
+n = 30
+t0 = time.perf_counter()
+marks = []
+for _ in range(n):
+    step(); marks.append(time.perf_counter())
+t1 = time.perf_counter()
 torch.cuda.synchronize()
-for key in ("cumulative", "tottime"):
-    s = io.StringIO()
-    st = pstats.Stats(pr, stream=s).sort_stats(key)
-    st.print_stats(45)
-    txt = s.getvalue()
-    print(f"==== sorted by {key} (totals over {n} steps; divide by {n})")
-    print("\n".join(l[:200] for l in txt.splitlines()[4:]))
+t2 = time.perf_counter()
+print(f"host enqueue {(t1 - t0) / n * 1e3:.2f} ms/step, until GPU done {(t2 - t0) / n * 1e3:.2f} ms/step, "
+      f"GPU still busy for {(t2 - t1) * 1e3:.2f} ms after the last enqueue")
+d = [(marks[i] - marks[i - 1]) * 1e3 for i in range(1, n)]
+print("per-step host intervals (ms): first 5", [f"{x:.2f}" for x in d[:5]], " last 5", [f"{x:.2f}" for x in d[-5:]])
