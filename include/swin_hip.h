@@ -330,6 +330,9 @@ int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, int decon
  *   The caller joins the two streams before reading those results and keeps the calls' workspaces untouched until then.
  *   swin_block_bwd sets it to its table entry 55 for the duration of the call. */
 int swin_set_aux_stream(void* side);
+/* swin_fork_stream: `side` waits for everything enqueued on `main` so far (an event from a per-device ring is recorded on
+ *   `main` and waited for on `side`; no host synchronisation).  The join is the same call with the arguments swapped. */
+int swin_fork_stream(void* main, void* side);
 
 /* conv3x3_nhwc_bf16_gated: conv3x3_nhwc_bf16 whose output is zeroed where gate (N,H,W,Cout) bf16 is not positive -- a data
  *   gradient that already includes the ReLU backward (torch.ops.aten.threshold_backward) of the layer below, whose output

@@ -25,13 +25,16 @@ void* swin_aux_stream(void) {
 // `side` waits for everything enqueued on `main` so far (no host synchronisation).  A ring of events per device:
 // hipStreamWaitEvent captures the event's latest record at the time of the call, so an event may be re-recorded as soon as
 // the wait has been enqueued; the ring only keeps that property from mattering.
-int swin_fork_stream(void* main, void* side) {
+extern "C" int swin_fork_stream(void* main, void* side) {
     if (!side || side == main) return SWIN_OK;
-    static hipEvent_t ring[16][64];
+    // 2048 events per device: several steps of forks.  Re-recording an event whose previous record the GPU has not passed yet
+    // makes the host wait for it on this runtime -- with a ring of 64 the host could never run more than half a step ahead.
+    constexpr unsigned RING = 2048;
+    static hipEvent_t ring[16][RING];
     static unsigned next_ev[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
-    hipEvent_t& ev = ring[dev][next_ev[dev]++ & 63];
+    hipEvent_t& ev = ring[dev][next_ev[dev]++ & (RING - 1)];
     if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return SWIN_ERR_LAUNCH;
     if (hipEventRecord(ev, (hipStream_t)main) != hipSuccess) return SWIN_ERR_LAUNCH;
     if (hipStreamWaitEvent((hipStream_t)side, ev, 0) != hipSuccess) return SWIN_ERR_LAUNCH;

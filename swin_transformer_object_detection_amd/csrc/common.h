@@ -21,7 +21,6 @@ static inline int swin_launch_status() {
 
 // csrc/abi.hip: the per-device auxiliary stream (null = none) and the event fork used to order work on it
 void* swin_aux_stream(void);
-int swin_fork_stream(void* main, void* side);
 
 template <typename T> struct Elt;
 template <> struct Elt<float> {

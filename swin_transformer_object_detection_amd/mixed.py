@@ -7,6 +7,7 @@ refreshed from the masters with a single multi-tensor copy after the optimizer s
 the autograd leaves (their bf16 gradients are gathered into the flat fp32 gradient buckets by ``ddp.py``).
 """
 import contextlib
+import ctypes
 import os
 
 import torch
@@ -106,13 +107,23 @@ _FORK_NEXT = [0]
 
 def _fork(cur, s, i):
     """``s`` waits for everything enqueued on ``cur`` so far."""
-    k = (i, _FORK_NEXT[0] & 63)
+    k = (i, _FORK_NEXT[0] & 1023)
     _FORK_NEXT[0] += 1
     ev = _FORK_EVENTS.get(k)
     if ev is None:
         ev = _FORK_EVENTS[k] = torch.cuda.Event()
     ev.record(cur)
     s.wait_event(ev)
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _raw_current(i):
+    """handle (int) of device i's current stream"""
+    if _raw_stream is not None:
+        return _raw_stream(i)
+    return torch.cuda.current_stream(i).cuda_stream
 
 
 def fork_to_side(device, *tensors):
@@ -122,12 +133,14 @@ def fork_to_side(device, *tensors):
     s = side_stream(device)
     if s is None:
         return None
-    cur = torch.cuda.current_stream(device)
-    if cur != s:
-        _fork(cur, s, _dev_index(device))
+    i = _dev_index(device)
+    cur, sp = _raw_current(i), s.cuda_stream
+    if cur != sp:
+        from ._lib import call
+        call("swin_fork_stream", ctypes.c_void_p(cur), ctypes.c_void_p(sp))      # event ring in the library: no torch objects
     side_keep(*tensors)
-    side_mark(device)
-    return s.cuda_stream
+    _SIDE_DIRTY.add((i, 'side'))
+    return sp
 
 
 @contextlib.contextmanager
@@ -177,11 +190,13 @@ def side_outputs(*tensors):
 
 def side_join():
     """The current stream of every device with outstanding side-stream work waits for it."""
-    for k in list(_SIDE_DIRTY):
-        cur = torch.cuda.current_stream(k[0])
-        if cur != _SIDE[k]:
-            _fork(_SIDE[k], cur, k[0])
-    _SIDE_DIRTY.clear()
+    if _SIDE_DIRTY:
+        from ._lib import call
+        for k in _SIDE_DIRTY:
+            cur, sp = _raw_current(k[0]), _SIDE[k].cuda_stream
+            if cur != sp:
+                call("swin_fork_stream", ctypes.c_void_p(sp), ctypes.c_void_p(cur))
+        _SIDE_DIRTY.clear()
     _SIDE_KEEP.clear()
 
 

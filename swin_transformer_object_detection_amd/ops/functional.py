@@ -39,7 +39,15 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _s():
+    """the current HIP stream's handle.  torch.cuda.current_stream() builds a Stream object through three Python layers (~9 us;
+    ~190 calls per step were 1.5 ms of a host-bound step); the raw query is one C call."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
