@@ -50,6 +50,7 @@ class BucketedGradReducer:
         self._next = 0                      # index of the next bucket whose collective may be issued
         self._t0 = None
         self._home = None                   # the stream the step is issued on (set by zero_grad)
+        self.force_overlap = os.environ.get("SWIN_DDP_OVERLAP") == "1"    # world size 1: still gather mid-backward on the launch stream (tests)
         self.timeline = []                  # per step: [(bucket, launch_s, done_s | None, bytes)] relative to mark_backward_start
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
@@ -95,8 +96,9 @@ class BucketedGradReducer:
             p.grad = v
         self.buckets.append(b)
 
-    def _gather(self, b):
-        """fresh leaf gradients -> flat fp32 bucket (one multi-tensor copy; converts bf16 -> fp32)."""
+    def _gather(self, b, keep=False):
+        """fresh leaf gradients -> flat fp32 bucket (one multi-tensor copy; converts bf16 -> fp32).  keep: the copies run on
+        another stream than the one the gradients' memory belongs to -- hold the gradients until the next join."""
         src, dst, asrc, adst = [], [], [], []
         for i, (leaf, p, v) in enumerate(zip(b['leaves'], b['params'], b['views'])):
             g = leaf.grad
@@ -110,6 +112,9 @@ class BucketedGradReducer:
             torch._foreach_copy_(dst, src)
         for d_, s_ in zip(adst, asrc):
             d_.add_(s_)
+        if keep and (src or asrc):
+            from . import mixed
+            mixed.side_keep(*src, *asrc)
         for leaf, p, v in zip(b['leaves'], b['params'], b['views']):
             if leaf is not p:
                 leaf.grad = None
@@ -122,12 +127,32 @@ class BucketedGradReducer:
     def _now(self):
         return time.perf_counter() - (self._t0 if self._t0 is not None else time.perf_counter())
 
-    def _launch(self, b):
+    def _launch(self, b, final=False):
         from . import mixed
-        # A bucket may complete inside a backward node that autograd runs on an auxiliary stream (mixed.small_branch): gather and
-        # collective are always issued on the reducer's home stream, after it has waited for the auxiliary streams (weight-gradient
-        # kernels may still be writing this bucket's views there).
-        home = self._home if (self._home is not None and b['flat'].is_cuda) else None
+        cuda = b['flat'].is_cuda
+        home = self._home if (self._home is not None and cuda) else None
+        overlap = cuda and not final and (self.world > 1 or self.force_overlap)
+        if overlap:
+            # Mid-backward: the bucket is gathered and reduced on a LAUNCH stream that waits for what has been enqueued so far on
+            # the step's stream (autograd-delivered gradients) and on the auxiliary streams (weight-gradient kernels writing this
+            # bucket's views) -- the step's stream itself does not wait for anything and goes on with backward.  finish() joins.
+            dev = b['flat'].device
+            L = mixed.side_stream(dev, kind='launch')
+            if L is None:
+                overlap = False
+        if overlap:
+            mixed.fork_into(dev, L, home)
+            with torch.cuda.stream(L):
+                self._gather(b, keep=True)
+                b['launched'] = True
+                if self.average and self.world > 1:
+                    b['flat'].div_(self.world)
+                if self.world > 1:
+                    b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.timeline.append([b['no'], self._now(), None, b['flat'].numel() * 4])
+            return
+        # finish() (or CPU): on the step's own stream, after it has waited for the auxiliary streams.  (A bucket may complete
+        # inside a backward node that autograd runs on another stream: never rely on the current one.)
         with (torch.cuda.stream(home) if home is not None else contextlib.nullcontext()):
             mixed.side_join()
             self._gather(b)
@@ -144,7 +169,7 @@ class BucketedGradReducer:
             b = self.buckets[self._next]
             if not (b['ready'] or force):
                 break
-            self._launch(b)
+            self._launch(b, final=force)
             self._next += 1
 
     def _arrive(self, b, i):
@@ -163,7 +188,7 @@ class BucketedGradReducer:
             b['pending'] -= 1
             if b['pending'] == 0:
                 b['ready'] = True
-                if self.world > 1:          # one process: nothing to overlap -- everything is gathered at finish(), after ONE join
+                if self.world > 1 or self.force_overlap:    # one process: nothing to overlap -- all gathered at finish(), after ONE join
                     self._issue_ready()
 
     def _pre(self, b, i, g):

@@ -188,6 +188,24 @@ def side_outputs(*tensors):
             t.record_stream(torch.cuda.current_stream(t.device))
 
 
+def fork_into(device, target, home=None):
+    """``target`` (a torch stream) waits for everything enqueued so far on ``home`` (default: the current stream) and on every
+    auxiliary stream with outstanding work; none of them waits for anything.  Marks ``target`` as having work to join."""
+    from ._lib import call
+    i = _dev_index(device)
+    tp = target.cuda_stream
+    hp = home.cuda_stream if home is not None else _raw_current(i)
+    if hp != tp:
+        call("swin_fork_stream", ctypes.c_void_p(hp), ctypes.c_void_p(tp))
+    for k in _SIDE_DIRTY:
+        sp = _SIDE[k].cuda_stream
+        if k[0] == i and sp != tp and sp != hp:
+            call("swin_fork_stream", ctypes.c_void_p(sp), ctypes.c_void_p(tp))
+    for k, st in _SIDE.items():
+        if st is target:
+            _SIDE_DIRTY.add(k)
+
+
 def side_join():
     """The current stream of every device with outstanding side-stream work waits for it."""
     if _SIDE_DIRTY:

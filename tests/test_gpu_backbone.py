@@ -312,11 +312,18 @@ def test_weight_gradient_stream_gives_the_same_gradients(pkg):
             got_small = run(True)
         finally:
             mixed._SMALL_ON = small_was
+        # + buckets gathered mid-backward on the launch stream, as with world size > 1 (the collective itself needs peers)
+        red.force_overlap = True
+        try:
+            got_overlap = run(True)
+            assert mixed.side_stream(torch.device("cuda", 0), kind='launch') is not None
+        finally:
+            red.force_overlap = False
         for it in range(3):
-            for fr, fa, fg, fs in zip(ref[it], again[it], got[it], got_small[it]):
+            for fr, fa, fg, fs, fo in zip(ref[it], again[it], got[it], got_small[it], got_overlap[it]):
                 scale = float(fr.abs().max())
                 noise = float((fr - fa).abs().max())
-                for err in (float((fr - fg).abs().max()), float((fr - fs).abs().max())):
+                for err in (float((fr - fg).abs().max()), float((fr - fs).abs().max()), float((fr - fo).abs().max())):
                     assert err <= 4 * noise + 2e-3 * scale + 1e-7, (it, err, noise, scale)
     finally:
         mixed.set_side_enabled(was)
