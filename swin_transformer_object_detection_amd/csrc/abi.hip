@@ -1,3 +1,6 @@
+#include <functional>
+#include <vector>
+
 #include "common.h"
 extern "C" int swin_hip_abi_version(void) { return 1; }
 
@@ -20,6 +23,51 @@ void* swin_aux_stream(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     return g_aux_stream[dev];
+}
+
+// Deferred form (used by swin_block_bwd): instead of one fork per reduction -- two runtime calls each, eight per Swin block --
+// the reductions are collected while the block's data-gradient chain is enqueued and flushed behind ONE fork at its end.
+static bool g_aux_defer[16] = {};
+static std::vector<std::function<int(void*)>> g_aux_deferred[16];
+
+static int cur_dev() {
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? dev : -1;
+}
+
+void swin_aux_defer(bool on) {
+    const int dev = cur_dev();
+    if (dev < 0) return;
+    g_aux_defer[dev] = on;
+    if (!on) g_aux_deferred[dev].clear();
+}
+
+// true: `launch` was queued for swin_aux_flush; false: the caller launches it itself (forking if an auxiliary stream is set)
+bool swin_aux_push(std::function<int(void*)> launch) {
+    const int dev = cur_dev();
+    if (dev < 0 || !g_aux_defer[dev] || !g_aux_stream[dev]) return false;
+    g_aux_deferred[dev].push_back(std::move(launch));
+    return true;
+}
+
+int swin_fork_stream(void* main, void* side);
+
+// the queued launches, on `side` behind one fork from `main` (on `main` itself when side is null)
+int swin_aux_flush(void* main, void* side) {
+    const int dev = cur_dev();
+    if (dev < 0) return SWIN_ERR_UNSUPPORTED;
+    void* st = side ? side : main;
+    if (side && side != main) {
+        int f = swin_fork_stream(main, side);
+        if (f != SWIN_OK) return f;
+    }
+    int rc = SWIN_OK;
+    for (auto& fn : g_aux_deferred[dev]) {
+        int r = fn(st);
+        if (r != SWIN_OK && rc == SWIN_OK) rc = r;
+    }
+    g_aux_deferred[dev].clear();
+    return rc;
 }
 
 // `side` waits for everything enqueued on `main` so far (no host synchronisation).  A ring of events per device:

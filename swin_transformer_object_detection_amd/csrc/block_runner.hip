@@ -69,16 +69,22 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
 // ints: B, H, W, C, nH, shift, fused_mlp;  floats: scale
 // fused_mlp != 0: 9 (hpre) and 10 (h) were not saved; swin_mlp_bwd_bf16 recomputes them from n2 (8), writes dn2 (32) and, as
 // temporaries for the two weight-gradient GEMMs, h into 30 and dhpre into 31; db1 (43) then comes from the dW1 launch.
-struct AuxScope {                 // the auxiliary stream is set for the duration of one block backward
-    explicit AuxScope(void* side) { swin_set_aux_stream(side); }
-    ~AuxScope() { swin_set_aux_stream(nullptr); }
+struct AuxScope {                 // the auxiliary stream is set (and its launches collected) for the duration of one block backward
+    explicit AuxScope(void* side) : on(side != nullptr) { swin_set_aux_stream(side); if (on) swin_aux_defer(true); }
+    ~AuxScope() { if (on) swin_aux_defer(false); swin_set_aux_stream(nullptr); }
+    bool on;
 };
 
 extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const float* fv, void* stream) {
     if (!p || !iv || !fv) return SWIN_ERR_BAD_ARG;
-    void* const wst = p[55] ? const_cast<void*>(p[55]) : stream;      // where the weight-gradient GEMMs go
+    // Everything nothing on `stream` waits for -- the four weight-gradient GEMMs and the parameter-gradient reductions behind
+    // LayerNorm / attention backward -- is enqueued on the second stream (entry 55) AFTER the block's data-gradient chain, behind
+    // ONE event: a fork per launch was two runtime calls each, 16 of a block's 47, with the step host-bound.  On the GPU that
+    // work then overlaps the NEXT block's data-gradient chain instead of this one's.
+    void* const side = const_cast<void*>(p[55]);
+    void* const wst = side ? side : stream;
     static const bool aux_on = !(getenv("SWIN_AUX_REDUCE") && atoi(getenv("SWIN_AUX_REDUCE")) == 0);      // development A/B
-    AuxScope aux(p[55] && aux_on ? wst : nullptr);                              // ... and the parameter-gradient reductions of LN / attention
+    AuxScope aux(side && aux_on ? side : nullptr);
     const int B = (int)iv[0], H = (int)iv[1], W = (int)iv[2], C = (int)iv[3], nH = (int)iv[4], shift = (int)iv[5];
     const float scale = fv[0];
     const int64_t L = (int64_t)H * W, T = (int64_t)B * L;
@@ -86,6 +92,7 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     auto M = [&](int i) { return const_cast<void*>(p[i]); };
     const void* dx1 = p[28];
     const void* dy2 = p[29];
+    if ((p[45] && !p[44]) || (p[43] && iv[6] && !p[42]) || (p[41] && !p[40]) || (p[38] && !p[37])) return SWIN_ERR_UNSUPPORTED;
     if (p[21]) {                              // second residual + next norm
         if (!p[25] || !p[48] || !p[49]) return SWIN_ERR_BAD_ARG;
         CHK(swin_layernorm_bwd(p[25], p[11], (const float*)p[21], (const float*)p[12], (const float*)p[13], p[24], M(28),
@@ -96,47 +103,29 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
         if (!p[24]) return SWIN_ERR_BAD_ARG;
         dx1 = p[24];
     }
+    const void* hbuf;                          // the hidden activation h the fc2 weight gradient contracts with
     if (iv[6]) {
         CHK(swin_mlp_bwd_bf16(p[8], dy2, p[18], (const float*)p[22], p[19], M(32), M(30), M(31), T, C, stream));
-        if (p[44] || p[45]) {
-            if (!p[44]) return SWIN_ERR_UNSUPPORTED;
-            CHK(swin_fork_stream(stream, wst));
-            CHK(wgrad_linear_bf16(dy2, p[30], (float*)p[44], (float*)p[45], T, C, 4 * C, wst));
-        }
-        if (p[42] || p[43]) {
-            if (!p[42]) return SWIN_ERR_UNSUPPORTED;
-            CHK(swin_fork_stream(stream, wst));
-            CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], (float*)p[43], T, 4 * C, C, wst));
-        }
+        hbuf = p[30];
     } else {
-    // fc2: dh = dy2 w2 ; dW2 += dy2^T h ; db2 += colsum dy2
-    CHK(swin_gemm_bf16(dy2, p[19], nullptr, M(30), T, 4 * C, C, 1, gws, stream));
-    if (p[44] || p[45]) {
-        if (!p[44]) return SWIN_ERR_UNSUPPORTED;
-        CHK(swin_fork_stream(stream, wst));
-        CHK(wgrad_linear_bf16(dy2, p[10], (float*)p[44], (float*)p[45], T, C, 4 * C, wst));
-    }
-    // GELU
-    CHK(swin_bias_gelu_bwd(p[30], p[9], (const float*)p[22], M(31), (float*)p[43], T, 4 * C, SWIN_BF16, stream));
-    // fc1
-    CHK(swin_gemm_bf16(p[31], p[18], nullptr, M(32), T, C, 4 * C, 1, gws, stream));
-    if (p[42]) {
-        CHK(swin_fork_stream(stream, wst));
-        CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], nullptr, T, 4 * C, C, wst));
-    }
+        // fc2: dh = dy2 w2; GELU; fc1: dn2 = dhpre w1
+        CHK(swin_gemm_bf16(dy2, p[19], nullptr, M(30), T, 4 * C, C, 1, gws, stream));
+        CHK(swin_bias_gelu_bwd(p[30], p[9], (const float*)p[22], M(31), (float*)p[43], T, 4 * C, SWIN_BF16, stream));
+        CHK(swin_gemm_bf16(p[31], p[18], nullptr, M(32), T, C, 4 * C, 1, gws, stream));
+        hbuf = p[10];
     }
     // first residual + norm2
     if (!p[46] || !p[47]) return SWIN_ERR_BAD_ARG;
-    CHK(swin_layernorm_bwd(p[32], p[5], (const float*)p[20], (const float*)p[6], (const float*)p[7], dx1, M(26), p[14] ? M(33) : nullptr,
+    // dy = the gradient entering the attention branch: dx scaled by DropPath, or dx itself.  With a second stream it is ALWAYS the
+    // private copy (33): dx (26) is handed to autograd, which adds a second gradient into it IN PLACE when x has two consumers
+    // (the first block of a stage: x also feeds norm1) -- while the proj weight gradient would still be reading it on the other
+    // stream (found by test_weight_gradient_stream_gives_the_same_gradients: 30 % error on those four proj.weight gradients).
+    const bool own_dy = p[14] || side;
+    CHK(swin_layernorm_bwd(p[32], p[5], (const float*)p[20], (const float*)p[6], (const float*)p[7], dx1, M(26), own_dy ? M(33) : nullptr,
                            (const float*)p[14], L, (float*)p[46], (float*)p[47], T, C, SWIN_BF16, M(52), stream));
-    const void* dy = p[14] ? p[33] : p[26];
+    const void* dy = own_dy ? p[33] : p[26];
     // proj
     CHK(swin_gemm_bf16(dy, p[17], nullptr, M(34), T, C, C, 1, gws, stream));
-    if (p[40] || p[41]) {
-        if (!p[40]) return SWIN_ERR_UNSUPPORTED;
-        CHK(swin_fork_stream(stream, wst));
-        CHK(wgrad_linear_bf16(dy, p[4], (float*)p[40], (float*)p[41], T, C, C, wst));
-    }
     // window attention
     if (hipMemsetAsync(M(36), 0, (size_t)nH * 64 * 64 * sizeof(float), (hipStream_t)stream) != hipSuccess) return SWIN_ERR_LAUNCH;
     CHK(swin_window_attn_bwd(p[1], (const float*)p[23], (const float*)p[2], (const float*)p[3], p[34], M(35), (float*)p[36],
@@ -144,10 +133,13 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     if (p[50]) CHK(swin_rel_bias_reduce((const float*)p[36], (float*)p[50], nH, stream));
     // qkv
     CHK(swin_gemm_bf16(p[35], p[16], nullptr, M(27), T, C, 3 * C, 1, gws, stream));
-    if (p[37] || p[38]) {
-        if (!p[37]) return SWIN_ERR_UNSUPPORTED;
-        CHK(swin_fork_stream(stream, wst));
-        CHK(wgrad_linear_bf16(p[35], p[0], (float*)p[37], (float*)p[38], T, 3 * C, C, wst));
-    }
+
+    // ---- off the chain: one fork, then the collected reductions and the weight gradients (dW += dY^T X, db += colsum dY)
+    if (aux.on) CHK(swin_aux_flush(stream, side));
+    else if (side) CHK(swin_fork_stream(stream, side));
+    if (p[44]) CHK(wgrad_linear_bf16(dy2, hbuf, (float*)p[44], (float*)p[45], T, C, 4 * C, wst));                           // fc2
+    if (p[42]) CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], iv[6] ? (float*)p[43] : nullptr, T, 4 * C, C, wst));       // fc1
+    if (p[40]) CHK(wgrad_linear_bf16(dy, p[4], (float*)p[40], (float*)p[41], T, C, C, wst));                                // proj
+    if (p[37]) CHK(wgrad_linear_bf16(p[35], p[0], (float*)p[37], (float*)p[38], T, 3 * C, C, wst));                         // qkv
     return SWIN_OK;
 }

@@ -21,6 +21,8 @@ static inline int swin_launch_status() {
 
 // csrc/abi.hip: the per-device auxiliary stream (null = none) and the event fork used to order work on it
 void* swin_aux_stream(void);
+void swin_aux_defer(bool on);                                 // block runner: collect the reductions, flush once
+int swin_aux_flush(void* main, void* side);
 
 template <typename T> struct Elt;
 template <> struct Elt<float> {

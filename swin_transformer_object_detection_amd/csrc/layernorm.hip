@@ -11,6 +11,9 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "aux_defer.h"
+
+extern "C" int swin_fork_stream(void* main, void* side);
 
 template <typename T> struct PlainSrc {
     const T* x; int C;
@@ -339,13 +342,19 @@ static int ln_bwd_launch(Src src, const T* dy, const float* gamma, const float* 
                                                                               partials)))
     if (partials) {
         // nobody on this stream consumes the parameter gradients: with an auxiliary stream set, reduce them there
-        void* aux = swin_aux_stream();
-        hipStream_t rs = s;
-        if (aux && aux != (void*)s) {
-            if (swin_fork_stream((void*)s, aux) != SWIN_OK) return SWIN_ERR_LAUNCH;
-            rs = (hipStream_t)aux;
+        auto launch = [=](void* st) {
+            ln_param_reduce_kernel<<<(2 * C + 63) / 64, 1024, 0, (hipStream_t)st>>>(partials, blocks, C, dgamma, dbeta);
+            return swin_launch_status();
+        };
+        if (!swin_aux_push(launch)) {
+            void* aux = swin_aux_stream();
+            void* rs = (void*)s;
+            if (aux && aux != (void*)s) {
+                if (swin_fork_stream((void*)s, aux) != SWIN_OK) return SWIN_ERR_LAUNCH;
+                rs = aux;
+            }
+            return launch(rs);
         }
-        ln_param_reduce_kernel<<<(2 * C + 63) / 64, 1024, 0, rs>>>(partials, blocks, C, dgamma, dbeta);
     }
     return swin_launch_status();
 }

@@ -14,6 +14,9 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "aux_defer.h"
+
+extern "C" int swin_fork_stream(void* main, void* side);
 
 #define NTOK 49
 #define TILE 64
@@ -1309,13 +1312,17 @@ extern "C" int swin_rel_bias_expand(const float* table, float* bias_exp, int nH,
 
 extern "C" int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int nH, void* stream) {
     if (!dbias_exp || !dtable || nH <= 0) return SWIN_ERR_BAD_ARG;
-    void* aux = swin_aux_stream();                 // follows the slab reduce onto the auxiliary stream when one is set
+    auto launch = [=](void* st) {
+        rel_bias_reduce_kernel<<<nH, 256, 0, (hipStream_t)st>>>(dbias_exp, dtable, nH);
+        return swin_launch_status();
+    };
+    if (swin_aux_push(launch)) return SWIN_OK;         // follows the slab reduce onto the auxiliary stream when one is set
+    void* aux = swin_aux_stream();
     if (aux && aux != stream) {
         if (swin_fork_stream(stream, aux) != SWIN_OK) return SWIN_ERR_LAUNCH;
         stream = aux;
     }
-    rel_bias_reduce_kernel<<<nH, 256, 0, (hipStream_t)stream>>>(dbias_exp, dtable, nH);
-    return swin_launch_status();
+    return launch(stream);
 }
 
 static int attn_bwd_blocks(int n_tasks, int nH) {
@@ -1372,13 +1379,20 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
         }
         int n = nH * (TILE * TILE + 3 * HD);
         dim3 rgrid((n + 255) / 256, 16);
-        hipStream_t rs = s;                       // bias-gradient reduce: off the data-gradient chain (see csrc/abi.hip)
-        void* aux = swin_aux_stream();
-        if (aux && aux != (void*)s) {
-            if (swin_fork_stream((void*)s, aux) != SWIN_OK) return SWIN_ERR_LAUNCH;
-            rs = (hipStream_t)aux;
+        // bias-gradient reduce: off the data-gradient chain (see csrc/abi.hip)
+        auto launch = [=](void* st) {
+            dbias_slab_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)st>>>((const float*)workspace, dbias_exp, dqkv_bias_pad, blocks * 4, nH, C);
+            return swin_launch_status();
+        };
+        if (!swin_aux_push(launch)) {
+            void* rs = (void*)s;
+            void* aux = swin_aux_stream();
+            if (aux && aux != (void*)s) {
+                if (swin_fork_stream((void*)s, aux) != SWIN_OK) return SWIN_ERR_LAUNCH;
+                rs = aux;
+            }
+            return launch(rs);
         }
-        dbias_slab_reduce_kernel<<<rgrid, 256, 0, rs>>>((const float*)workspace, dbias_exp, dqkv_bias_pad, blocks * 4, nH, C);
     } else {
         win_attn_bwd_f32_kernel<<<n_tasks, 64, 0, s>>>((const float*)qkv, qkv_bias, bias_exp, lse, (const float*)dout,
                                                        (float*)dqkv, dbias_exp, dqkv_bias_pad, g, scale);
