@@ -276,7 +276,9 @@ class SwinTransformer(nn.Module):
         pe = self.patch_embed
         rows = ops.patch_im2row(x.float().contiguous(), dt)                              # :433-438
         Wh, Ww = (Hi + 3) // 4, (Wi + 3) // 4
-        t = F.linear(rows, mixed.weight(pe.proj.weight, dt).view(self.embed_dim, 48), mixed.weight(pe.proj.bias, dt))
+        # the 4x4 / stride-4 conv as a GEMM over the (c, ky, kx) patch rows; through ops.linear its weight / bias gradients
+        # (a 96 x 48 x 128000 contraction: 213 us on the library's 16x16 tile, + a reduce launch) run on the split-T kernel
+        t = ops.linear(rows, pe.proj.weight, pe.proj.bias, dt)
         if pe.norm is not None:
             t = ops.layer_norm(t, pe.norm.weight, pe.norm.bias)                          # :441-443
         t = t.view(B, Wh * Ww, self.embed_dim)

@@ -655,8 +655,8 @@ def linear(x, weight, bias=None, dtype=None):
     from .. import mixed
     dtype = dtype or x.dtype
     w = mixed.weight(weight, dtype)
-    if w.dim() == 4 and w.shape[2] == 1 and w.shape[3] == 1:        # 1x1 conv weight (Cout,Cin,1,1)
-        w = w.view(w.shape[0], w.shape[1])
+    if w.dim() == 4 and w.is_contiguous():       # a conv weight used as a GEMM over (Cin, ky, kx)-ordered rows: 1x1 convs, patch embedding
+        w = w.view(w.shape[0], -1)
     if (x.dtype == torch.bfloat16 and x.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[0] % 8 == 0
             and w.shape[1] % 8 == 0 and x.numel() // w.shape[1] >= _MIN_T):
         b = mixed.const(bias, dtype)                                # bf16 constant; gradient delivered to the master
