@@ -333,6 +333,9 @@ int swin_set_aux_stream(void* side);
 /* swin_fork_stream: `side` waits for everything enqueued on `main` so far (an event from a per-device ring is recorded on
  *   `main` and waited for on `side`; no host synchronisation).  The join is the same call with the arguments swapped. */
 int swin_fork_stream(void* main, void* side);
+/* swin_stream_create_low_priority: a non-blocking hipStream_t of the device's lowest priority for that off-chain work (so that
+ *   the hardware prefers the main stream's workgroups when both have some); the stream lives as long as the process. */
+int swin_stream_create_low_priority(void** out);
 
 /* conv3x3_nhwc_bf16_gated: conv3x3_nhwc_bf16 whose output is zeroed where gate (N,H,W,Cout) bf16 is not positive -- a data
  *   gradient that already includes the ReLU backward (torch.ops.aten.threshold_backward) of the layer below, whose output

@@ -56,6 +56,7 @@ SIGNATURES = {
     "conv_dgrad_layout_multi": [_p, _p, _p, _p, _i, _p],
     "swin_set_aux_stream": [_p],
     "swin_fork_stream": [_p, _p],
+    "swin_stream_create_low_priority": [_p],
     "conv3x3_nhwc_bf16_gated": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "narrow_dgrad_gated_bf16": [_p, _p, _p, _p, _i64, _i, _i, _p],
     "swin_gemm_workspace_bytes": [],

@@ -88,3 +88,16 @@ extern "C" int swin_fork_stream(void* main, void* side) {
     if (hipStreamWaitEvent((hipStream_t)side, ev, 0) != hipSuccess) return SWIN_ERR_LAUNCH;
     return SWIN_OK;
 }
+
+// A stream of the LOWEST priority the device offers (never destroyed: one or two per process).  The second stream carries work
+// nothing waits for; at equal priority its workgroups take CUs and memory bandwidth from the data-gradient chain on the main
+// stream, which is the step's critical path.
+extern "C" int swin_stream_create_low_priority(void** out) {
+    if (!out) return SWIN_ERR_BAD_ARG;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return SWIN_ERR_LAUNCH;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) return SWIN_ERR_LAUNCH;
+    *out = (void*)s;
+    return SWIN_OK;
+}

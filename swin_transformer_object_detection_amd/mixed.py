@@ -44,6 +44,7 @@ def clear_sinks(ids=None):
 # the producing kernel (fork); the main stream waits for the side stream before a bucket is reduced and at
 # reducer.finish() (join).  Tensors the side stream reads are kept alive until the join (side_keep).
 _SIDE_ON = os.environ.get("SWIN_WGRAD_STREAM", "1") != "0"      # 0: everything on one stream (A/B)
+_LOW_PRIO = os.environ.get("SWIN_SIDE_PRIORITY", "low") == "low"      # "normal": a plain stream (A/B)
 _SIDE = {}            # (device index, kind) -> torch.cuda.Stream; kind 'side': weight gradients and reductions (work nothing waits
                       # for), 'branch': data-dependent work of an independent sub-graph (it must not queue behind the former)
 _SIDE_DIRTY = set()   # (device index, kind) with work since the last join
@@ -71,7 +72,20 @@ def side_stream(device, kind='side'):
     k = (_dev_index(device), kind)
     s = _SIDE.get(k)
     if s is None:
-        s = _SIDE[k] = torch.cuda.Stream(device=k[0])
+        s = None
+        if kind == 'side' and _LOW_PRIO:
+            # work nothing waits for: the lowest stream priority, so that it fills idle CUs instead of competing with the main stream
+            try:
+                from ._lib import call
+                h = ctypes.c_void_p()
+                with torch.cuda.device(k[0]):
+                    call("swin_stream_create_low_priority", ctypes.byref(h))
+                s = torch.cuda.ExternalStream(h.value, device=k[0])
+            except Exception:
+                s = None
+        if s is None:
+            s = torch.cuda.Stream(device=k[0])
+        _SIDE[k] = s
     return s
 
 
