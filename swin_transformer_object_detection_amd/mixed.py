@@ -300,6 +300,8 @@ _GATED = {}           # data_ptr of a live data-gradient tensor -> (the tensor (
 
 def gated_mark(dx, gate):
     """``dx`` was produced already zeroed where ``gate`` (the ReLU output that fed the producing layer) is not positive."""
+    if len(_GATED) > 64:          # marks nobody took (a consumer that is not one of this package's convs): do not pile up tensors
+        _GATED.clear()
     _GATED[dx.data_ptr()] = (dx, gate.data_ptr(), gate.numel())
 
 

@@ -331,6 +331,45 @@ def test_weight_gradient_stream_gives_the_same_gradients(pkg):
         sh.release()
 
 
+def test_training_loop_on_two_streams_tracks_the_one_stream_loop(pkg):
+    """Eight optimizer steps at the bench geometry WITHOUT any host synchronisation inside the loop (the host runs ahead of
+    the GPU across step boundaries, as in bench.py), with the second stream on and off: the losses must stay finite and the
+    two trajectories must agree step by step within training noise.  (A reordering of the RPN branch on the second stream
+    once passed the single-step gradient comparison and still blew up here within two steps.)"""
+    from swin_transformer_object_detection_amd import data, ddp, detector, mixed, presets
+    from swin_transformer_object_detection_amd.optim import FusedAdamW
+    dev = torch.device("cuda")
+    was = mixed.side_enabled()
+
+    def run(on):
+        mixed.set_side_enabled(on)
+        torch.manual_seed(0)
+        model = detector.build_detector(presets.mask_rcnn_swin("tiny"), compute_dtype=torch.bfloat16).to(dev).train()
+        sh = mixed.ShadowParams(model, torch.bfloat16)
+        red = ddp.BucketedGradReducer(model.parameters(), leaf_of=sh.leaf_of)
+        opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
+        batch = data.synthetic_batch(2, 800, 1280, dev, seed=0)
+        out = []
+        try:
+            for it in range(8):
+                red.zero_grad()
+                loss, _ = model.parse_losses(model.forward_train(**batch))
+                loss.backward(); red.finish(); opt.step()
+                out.append(loss.detach())
+            return [float(v) for v in out]
+        finally:
+            red.release(); sh.release()
+    try:
+        one, two = run(False), run(True)
+    finally:
+        mixed.set_side_enabled(was)
+    assert all(np.isfinite(one)) and all(np.isfinite(two)), (one, two)
+    assert abs(one[0] - two[0]) < 1e-2 * abs(one[0])                     # same initial weights, same batch
+    for a, b in zip(one, two):
+        assert abs(a - b) < 0.15 * max(abs(a), abs(b)) + 0.05, (one, two)
+    assert one[-1] < 0.6 * one[0] and two[-1] < 0.6 * two[0], (one, two)  # and both are learning
+
+
 # ------------------------------------------------------------------------------------------
 # test-time path (two_stage.py:187-204): kernels vs the oracle's callers on the model's own head outputs
 # ------------------------------------------------------------------------------------------
