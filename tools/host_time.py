@@ -12,6 +12,7 @@ sh = mixed.ShadowParams(model, torch.bfloat16)
 red = ddp.BucketedGradReducer(model.parameters(), leaf_of=sh.leaf_of)
 opt = FusedAdamW(model.parameters(), lr=1e-4)
 batch = data.synthetic_batch(2, 800, 1280, dev, seed=0)
+_st = torch.cuda.Stream(device=dev); _st.wait_stream(torch.cuda.current_stream(dev)); torch.cuda.set_stream(_st)   # as bench.py: not the default stream
 
 
 def step():
