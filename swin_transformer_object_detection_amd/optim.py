@@ -31,13 +31,18 @@ class FusedAdamW:
         if len({(tuple(g['betas']), g['eps']) for g in self.param_groups}) != 1:
             raise SwinHipError("FusedAdamW: betas / eps must be shared by all groups")
         self.state = {}
+        self._flat_params = [p for g in self.param_groups for p in g['params']]
         self.step_count = 0
         self._tables = None
 
     # -- tables: built on the first step (gradients must exist), rebuilt if any pointer moved --------------------
     def _signature(self):
-        return tuple((p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0, id(mixed.shadow_of(p)))
-                     for g in self.param_groups for p in g['params'])
+        """Everything the device-resident table depends on: each parameter's storage, its gradient's storage and its shadow.
+        Flat list passes instead of a tuple per parameter: this check runs every step."""
+        ps = self._flat_params
+        sh = mixed._SHADOW
+        return ([p.data_ptr() for p in ps], [0 if p.grad is None else p.grad.data_ptr() for p in ps],
+                [id(sh.get(id(p))) if id(p) in sh else id(mixed.shadow_of(p)) for p in ps])
 
     def _build(self):
         chunk = _lib.lib().swin_adamw_chunk_elems()
