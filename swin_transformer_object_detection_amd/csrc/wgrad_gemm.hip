@@ -377,7 +377,8 @@ static int wgrad_launch(const bf16* dy, XLoader X, float* dw, float* dbias, int6
     // few output tiles and a long t axis: the split-T atomics dominate -> two k-groups per block (half the atomic bytes);
     // many tiles: two independent 4-wave blocks per CU overlap each other's barriers better
     const int tiles = ((N1 + WN - 1) / WN) * ((N2 + WN - 1) / WN);
-    if (tiles <= 16) return wgrad_launch_kg<XLoader, 2>(dy, X, dw, dbias, T, N1, N2, s);
+    static const int kg2_tiles = getenv("SWIN_WGRAD_KG2_TILES") ? atoi(getenv("SWIN_WGRAD_KG2_TILES")) : 16;      // development sweep
+    if (tiles <= kg2_tiles) return wgrad_launch_kg<XLoader, 2>(dy, X, dw, dbias, T, N1, N2, s);
     return wgrad_launch_kg<XLoader, 1>(dy, X, dw, dbias, T, N1, N2, s);
 }
 
