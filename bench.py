@@ -285,7 +285,10 @@ def main():
     model.train()
     from swin_transformer_object_detection_amd import mixed
     shadows = mixed.ShadowParams(model, dtype) if dtype != torch.float32 else None
-    reducer = ddp.BucketedGradReducer(model.parameters(), leaf_of=shadows.leaf_of if shadows else None)
+    # buckets in reverse first-use order (= the order gradients arrive): with plain registration order the backbone's output norms
+    # sit in the first backbone bucket and hold it back until the end of backward
+    reducer = ddp.BucketedGradReducer(model.parameters_in_forward_order(), leaf_of=shadows.leaf_of if shadows else None,
+                                      bucket_bytes=32 << 20)
     reducer.broadcast_parameters()
     if shadows:
         shadows.refresh()

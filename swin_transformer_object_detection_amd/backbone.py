@@ -168,6 +168,29 @@ class SwinTransformer(nn.Module):
             self.add_module(f'norm{i}', nn.LayerNorm(self.num_features[i]))
         self._freeze_stages()
 
+    def parameters_in_forward_order(self):
+        """The parameters in the order the forward pass first uses them.  Registration order puts the output norms (norm0..3)
+        after all stages; in backward they arrive between the stages, so a gradient bucket formed by reverse REGISTRATION order
+        holds norm0 next to stage-4 parameters and cannot be reduced until the very end of backward."""
+        out, seen = [], set()
+
+        def add(ps):
+            for p in ps:
+                if id(p) not in seen:
+                    seen.add(id(p)); out.append(p)
+        add(self.patch_embed.parameters())
+        if getattr(self, 'ape', False):
+            add([self.absolute_pos_embed])
+        for i, layer in enumerate(self.layers):
+            for blk in layer.blocks:
+                add(blk.parameters())
+            if i in self.out_indices:
+                add(getattr(self, f'norm{i}').parameters())
+            if getattr(layer, 'downsample', None) is not None:
+                add(layer.downsample.parameters())
+        add(self.parameters())                       # anything not named above, in registration order
+        return out
+
     # ------------------------------------------------------------------ reference plumbing
     def _freeze_stages(self):                                   # swin_transformer.py:557-572
         if self.frozen_stages >= 0:

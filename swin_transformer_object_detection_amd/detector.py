@@ -1425,6 +1425,21 @@ class MaskRCNN(nn.Module):
         self.rpn_head.init_weights()
         self.roi_head.init_weights(pretrained)
 
+    def parameters_in_forward_order(self):
+        """Parameters in first-use order (for gradient buckets: reverse of it ~ the order gradients arrive in backward)."""
+        out, seen = [], set()
+        for m in (self.backbone, self.neck, self.rpn_head, self.roi_head):
+            if m is None:
+                continue
+            ps = m.parameters_in_forward_order() if hasattr(m, 'parameters_in_forward_order') else m.parameters()
+            for p in ps:
+                if id(p) not in seen:
+                    seen.add(id(p)); out.append(p)
+        for p in self.parameters():
+            if id(p) not in seen:
+                seen.add(id(p)); out.append(p)
+        return out
+
     def extract_feat(self, img):                                # two_stage.py:80-85
         x = self.backbone(img)
         return self.neck(x) if self.neck is not None else x
