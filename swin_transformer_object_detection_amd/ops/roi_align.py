@@ -5,6 +5,8 @@ Signature and semantics follow the reference's call sites
 by name with ``getattr``; ``structures.py:353-354`` calls
 ``roi_align(input, rois, output_size, 1.0, 0, 'avg', True)`` positionally).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -147,6 +149,9 @@ class _RoIAlignMultiLevelFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None) + grads
 
 
+_ACC_ON_SIDE = os.environ.get("SWIN_ROI_ACC_SIDE", "1") != "0"      # 0: zero the backward accumulator in backward, on the main stream (A/B)
+
+
 class _RoIAlignMultiLevelGroupFn(torch.autograd.Function):
     """Several RoI sets (e.g. the bbox head's 7x7 and the mask head's 14x14 RoIs of one R-CNN stage) pooled from the SAME
     pyramid: one forward launch per set, and in backward ONE fp32 accumulator for the pyramid shared by all sets -- one
@@ -184,6 +189,17 @@ class _RoIAlignMultiLevelGroupFn(torch.autograd.Function):
         ctx.save_for_backward(*saved)
         ctx.cfg = (n, C, tuple(specs), tuple(strides), int(sampling_ratio), int(bool(aligned)), [tuple(f.shape) for f in feats],
                    f0.dtype)
+        # The backward's fp32 accumulator (174 MB at 2x800x1280) needs 35-85 us of zero fill at the head of the data-gradient chain.
+        # With a second stream it is allocated and zeroed THERE, now, while this stream runs the heads; backward waits for the event.
+        ctx.acc = None
+        if _ACC_ON_SIDE and any(f.requires_grad for f in tensors[:n]):
+            from .. import mixed
+            with mixed.on_side(f0.device) as sd:
+                if sd is not None:
+                    acc = torch.zeros(sum(f.numel() for f in feats), device=f0.device, dtype=torch.float32)
+                    ev = torch.cuda.Event()
+                    ev.record(sd)
+                    ctx.acc = (acc, ev)
         return tuple(outs)
 
     @staticmethod
@@ -193,7 +209,14 @@ class _RoIAlignMultiLevelGroupFn(torch.autograd.Function):
         n, C, specs, strides, sr, aligned, shapes, in_dtype = ctx.cfg
         sizes = [s[0] * s[1] * s[2] * s[3] for s in shapes]
         dev = saved[0].device
-        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        if getattr(ctx, 'acc', None) is not None and ctx.acc[0].numel() == sum(sizes):
+            flat, ev = ctx.acc
+            ctx.acc = None
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ev)                       # zeroed on the second stream during the forward pass
+            flat.record_stream(cur)                  # its memory belongs to that stream's pool; it is used (and freed) here
+        else:
+            flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
         offs = [sum(sizes[:i]) for i in range(n)]
         ptrs = (ctypes.c_void_p * n)(*[flat.data_ptr() + 4 * o for o in offs])
         Hs = (ctypes.c_int * n)(*[s[2] for s in shapes])
