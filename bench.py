@@ -295,6 +295,11 @@ def main():
     opt_cfg = presets.OPTIMIZER
     from swin_transformer_object_detection_amd.optim import FusedAdamW
     optim = FusedAdamW(build_param_groups(model, opt_cfg), lr=opt_cfg["lr"], betas=opt_cfg["betas"])      # one launch, refreshes the bf16 shadows
+    if world == 1 and os.environ.get("SWIN_EARLY_OPT", "0") == "1":
+        # one process: a bucket's gradients are final as soon as its parameters have arrived -- the optimizer can run for it right
+        # then, on the second stream, instead of for everything after the join at the end of backward.  Measured: no gain
+        # (11.64 / 11.69 ms with, 11.67 / 11.67 without, same box): the join then waits for that work instead.  Off by default.
+        reducer.early_step = optim.step_partial
     batch = data.synthetic_batch(PER_GPU_BATCH, img_h, img_w, device, seed=rank)     # per-rank data
     torch.manual_seed(1000 + rank)             # per-rank sampling / DropPath randomness
     # The step runs on a stream of its own, not on the legacy default stream: on this runtime a launch on the default stream that

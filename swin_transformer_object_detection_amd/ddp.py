@@ -50,6 +50,7 @@ class BucketedGradReducer:
         self._next = 0                      # index of the next bucket whose collective may be issued
         self._t0 = None
         self._home = None                   # the stream the step is issued on (set by zero_grad)
+        self.early_step = None              # one process: callable(params, stream) -> bool that applies the optimizer to a finished bucket
         self.force_overlap = os.environ.get("SWIN_DDP_OVERLAP") == "1"    # world size 1: still gather mid-backward on the launch stream (tests)
         self.timeline = []                  # per step: [(bucket, launch_s, done_s | None, bytes)] relative to mark_backward_start
         cur, cur_bytes = [], 0
@@ -135,6 +136,8 @@ class BucketedGradReducer:
 
     def _launch(self, b, final=False):
         from . import mixed
+        if b.get('stepped'):
+            return                                  # gathered and already updated by the optimizer (early_step)
         cuda = b['flat'].is_cuda
         home = self._home if (self._home is not None and cuda) else None
         overlap = cuda and not final and (self.world > 1 or self.force_overlap)
@@ -196,6 +199,8 @@ class BucketedGradReducer:
                 b['ready'] = True
                 if self.world > 1 or self.force_overlap:    # one process: nothing to overlap -- all gathered at finish(), after ONE join
                     self._issue_ready()
+                elif self.early_step is not None:
+                    self._early(b)
 
     def _pre(self, b, i, g):
         b['real'][i] = g is not None
@@ -210,6 +215,25 @@ class BucketedGradReducer:
         if not real and b['arrived'][i]:
             return                                      # autograd visited the leaf with no gradient (a sink kernel delivered it)
         self._arrive(b, i)
+
+    def _early(self, b):
+        """One process: the bucket's gradients are final -- run the optimizer for its parameters NOW, on the second stream, behind
+        a fork (every kernel that still reads these parameters, and every autograd-delivered gradient, is already enqueued on
+        the current stream; the weight-gradient kernels that write the bucket's views are on the second stream itself)."""
+        from . import mixed
+        if not b['flat'].is_cuda:
+            return
+        dev = b['flat'].device
+        side = mixed.side_stream(dev)
+        if side is None:
+            return
+        sp = mixed.fork_to_side(dev)
+        with torch.cuda.stream(side):
+            self._gather(b, keep=True)
+        if self.early_step(b['params'], sp):
+            b['launched'] = b['stepped'] = True
+        # (False: the optimizer has no tables yet -- first step; the gather above is harmless, finish() repeats nothing: 'auto'
+        # gradients were moved into the views and the leaves' .grad cleared)
 
     def _on_direct(self, b, i):
         """A kernel accumulated parameter i's gradient straight into its bucket view (mixed.grad_sink)."""
@@ -235,7 +259,7 @@ class BucketedGradReducer:
             b['direct'] = [False] * len(b['params'])
             b['real'] = [False] * len(b['params'])
             b['auto'] = []
-            b['launched'] = b['ready'] = False
+            b['launched'] = b['ready'] = b['stepped'] = False
         self._next = 0
 
     def zero_grad(self):

@@ -32,6 +32,7 @@ class FusedAdamW:
             raise SwinHipError("FusedAdamW: betas / eps must be shared by all groups")
         self.state = {}
         self._flat_params = [p for g in self.param_groups for p in g['params']]
+        self._partial_done = set()
         self.step_count = 0
         self._tables = None
 
@@ -46,7 +47,7 @@ class FusedAdamW:
 
     def _build(self):
         chunk = _lib.lib().swin_adamw_chunk_elems()
-        segs, chunks = [], []
+        segs, chunks, rows = [], [], {}
         dev = None
         for gi, g in enumerate(self.param_groups):
             for p in g['params']:
@@ -72,7 +73,9 @@ class FusedAdamW:
                 si = len(segs)
                 segs.append(struct.pack("<QQQQQqii", p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(),
                                         st['exp_avg_sq'].data_ptr(), sh.data_ptr() if sh is not None else 0, n, gi, 0))
+                rows[id(p)] = (len(chunks), (n + chunk - 1) // chunk)
                 chunks += [(si, c) for c in range((n + chunk - 1) // chunk)]
+        self._rows, self._chunks_host, self._subsets = rows, chunks, {}
         if not segs:
             self._tables = (None, None, 0)
             self._sig = self._signature()
@@ -82,21 +85,64 @@ class FusedAdamW:
         self._tables = (seg_t, ck_t, len(chunks))
         self._sig = self._signature()
 
-    @torch.no_grad()
-    def step(self):
-        if self._tables is None or self._sig != self._signature():
-            self._build()
-        seg_t, ck_t, n_chunks = self._tables
-        self.step_count += 1
-        if n_chunks == 0:
-            return
+    def _launch(self, ck_t, n_chunks, step_no, stream):
+        seg_t = self._tables[0]
         g0 = self.param_groups[0]
         b1, b2 = g0['betas']
         ng = len(self.param_groups)
         lr = (ctypes.c_float * ng)(*[float(g['lr']) for g in self.param_groups])
         wd = (ctypes.c_float * ng)(*[float(g['weight_decay']) for g in self.param_groups])
         call("swin_adamw_step", seg_t.data_ptr(), ck_t.data_ptr(), n_chunks, lr, wd, ng, float(b1), float(b2), float(g0['eps']),
-             1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count, torch.cuda.current_stream().cuda_stream)
+             1.0 - b1 ** step_no, 1.0 - b2 ** step_no, stream)
+
+    def _subset(self, key, ids):
+        """device chunk table of the parameters ``ids`` (cached: the reducer's buckets are the same every step)"""
+        t = self._subsets.get(key)
+        if t is None:
+            rows = []
+            for i in ids:
+                r = self._rows.get(i)
+                if r is not None:
+                    rows += self._chunks_host[r[0]:r[0] + r[1]]
+            dev = self._tables[0].device
+            t = self._subsets[key] = (torch.tensor(rows, dtype=torch.int32).reshape(-1, 2).to(dev), len(rows))
+        return t
+
+    @torch.no_grad()
+    def step_partial(self, params, stream):
+        """This step's update for ``params`` only, launched on ``stream`` (a raw handle) NOW -- for a reducer that knows these
+        gradients are final while backward is still running (one process: ddp.BucketedGradReducer.early_step).  The caller orders
+        the stream behind everything that still reads the parameters or writes their gradients.  step() then updates the rest.
+        Returns False (nothing done) until the tables exist, i.e. during the first step."""
+        if self._tables is None or self._tables[2] == 0:
+            return False
+        ids = tuple(id(p) for p in params)
+        ck, n = self._subset(ids, ids)
+        if n:
+            self._launch(ck, n, self.step_count + 1, stream)
+        self._partial_done.update(ids)
+        return True
+
+    @torch.no_grad()
+    def step(self):
+        done = self._partial_done
+        if self._tables is None or (not done and self._sig != self._signature()):
+            self._build()                       # (with early partial steps in flight the tables are by construction the current ones)
+        seg_t, ck_t, n_chunks = self._tables
+        self.step_count += 1
+        if n_chunks == 0:
+            return
+        stream = torch.cuda.current_stream().cuda_stream
+        if done:
+            rest = tuple(i for i in self._rows if i not in done)
+            ck, n = self._subset(('rest',) + tuple(sorted(done)), rest)
+            if n:
+                self._launch(ck, n, self.step_count, stream)
+            self._partial_done = set()
+            if self._sig != self._signature():      # something moved since the tables were built: rebuild before the next use
+                self._tables = None
+        else:
+            self._launch(ck_t, n_chunks, self.step_count, stream)
         mixed.shadows_refreshed()
 
     def zero_grad(self, set_to_none=False):

@@ -385,13 +385,15 @@ def test_training_loop_on_two_streams_tracks_the_one_stream_loop(pkg):
     dev = torch.device("cuda")
     was = mixed.side_enabled()
 
-    def run(on):
+    def run(on, early=False):
         mixed.set_side_enabled(on)
         torch.manual_seed(0)
         model = detector.build_detector(presets.mask_rcnn_swin("tiny"), compute_dtype=torch.bfloat16).to(dev).train()
         sh = mixed.ShadowParams(model, torch.bfloat16)
-        red = ddp.BucketedGradReducer(model.parameters(), leaf_of=sh.leaf_of)
+        red = ddp.BucketedGradReducer(model.parameters_in_forward_order(), leaf_of=sh.leaf_of, bucket_bytes=32 << 20)
         opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
+        if early:
+            red.early_step = opt.step_partial        # the optimizer per finished bucket, on the second stream, during backward
         batch = data.synthetic_batch(2, 800, 1280, dev, seed=0)
         out = []
         try:
@@ -404,14 +406,15 @@ def test_training_loop_on_two_streams_tracks_the_one_stream_loop(pkg):
         finally:
             red.release(); sh.release()
     try:
-        one, two = run(False), run(True)
+        one, two, three = run(False), run(True), run(True, early=True)
     finally:
         mixed.set_side_enabled(was)
-    assert all(np.isfinite(one)) and all(np.isfinite(two)), (one, two)
-    assert abs(one[0] - two[0]) < 1e-2 * abs(one[0])                     # same initial weights, same batch
-    for a, b in zip(one, two):
-        assert abs(a - b) < 0.15 * max(abs(a), abs(b)) + 0.05, (one, two)
-    assert one[-1] < 0.6 * one[0] and two[-1] < 0.6 * two[0], (one, two)  # and both are learning
+    for other in (two, three):
+        assert all(np.isfinite(one)) and all(np.isfinite(other)), (one, other)
+        assert abs(one[0] - other[0]) < 1e-2 * abs(one[0])               # same initial weights, same batch
+        for a, b in zip(one, other):
+            assert abs(a - b) < 0.15 * max(abs(a), abs(b)) + 0.05, (one, other)
+        assert one[-1] < 0.6 * one[0] and other[-1] < 0.6 * other[0], (one, other)  # and both are learning
 
 
 # ------------------------------------------------------------------------------------------
