@@ -639,6 +639,31 @@ def test_two_rank_replicas_stay_identical(workload):
 
 
 @pytest.mark.gpu
+def test_reducer_over_rccl_one_rank():
+    """The reducer's N > 1 path over a real RCCL process group (one rank -- all a one-GPU box can hold; the two-rank test
+    above runs over gloo): buckets gathered on the launch stream, pre-divided, all-reduced asynchronously, waited for in
+    finish(), with the step on a non-default stream as bench.py runs it.  tests/_rccl_one_rank.py tells the reducer the world
+    has two ranks: every bucket must be half of the one-process gradients, within the run-to-run noise of the float atomics."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_rccl_one_rank.py")], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["buckets"] >= 3 and out["reduced"] == out["buckets"] and out["all_done"]
+    assert out["worst_over_bound"] <= 1.0, out
+    assert out["loss_finite"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fused_mlp", [False, True])
 def test_fused_swin_block_equals_per_op_blocks(fused_mlp, monkeypatch):
     """ops/swin_block.py (one autograd node per block) against backbone._block built from the individual ops.
