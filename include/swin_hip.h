@@ -347,6 +347,17 @@ int conv3x3_nhwc_bf16_gated(const void* x, const void* w, const float* bias, con
                             int Cin, int Cout, void* stream);
 int narrow_dgrad_gated_bf16(const void* dy, const void* w, const void* gate, void* dx, int64_t T, int K, int C, void* stream);
 
+/* conv3x3_splitk_workspace_bytes / conv3x3_nhwc_bf16_ws: the same convolutions for maps with so few 128 x 128 output tiles that one
+ *   launch leaves most CUs idle for the whole 9 * Cin contraction (the coarse pyramid levels of fpn.py:195-197 and rpn_head.py:43:
+ *   126 / 32 / 10 tiles at P4 / P5 / P6 of a 2 x 800 x 1280 batch, 40 us each whatever the size).  With `workspace` (device, at least
+ *   conv3x3_splitk_workspace_bytes(...) bytes; that function returns 0 for shapes that are not split) the contraction is split over
+ *   blockIdx.y into fp32 partial slabs and a second launch adds them and applies bias / ReLU / gate (gate != NULL: as
+ *   conv3x3_nhwc_bf16_gated, relu ignored).  workspace == NULL: exactly conv3x3_nhwc_bf16(_gated).  Same result up to the order of
+ *   the fp32 sum. */
+int64_t conv3x3_splitk_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int conv3x3_nhwc_bf16_ws(const void* x, const void* w, const float* bias, const void* gate, void* y, int N, int H, int W, int Cin,
+                         int Cout, int relu, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* conv_dgrad_layout_multi: for n 3x3 conv weights resident as (Cout,3,3,Cin) bf16, the (Cin,3,3,Cout) weights of their
  *   data-gradient convolutions (rot180, in/out swapped: what conv_transpose / the reference's cudnn backward-data use
  *   implicitly), all in one launch.  srcs / dsts / couts / cins are HOST arrays of n entries. */

@@ -59,6 +59,8 @@ SIGNATURES = {
     "swin_stream_create_low_priority": [_p],
     "conv3x3_nhwc_bf16_gated": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "narrow_dgrad_gated_bf16": [_p, _p, _p, _p, _i64, _i, _i, _p],
+    "conv3x3_splitk_workspace_bytes": [_i, _i, _i, _i, _i],
+    "conv3x3_nhwc_bf16_ws": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i64, _p],
     "swin_gemm_workspace_bytes": [],
     "swin_gemm_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p, _p],
     "swin_adamw_step": [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p],
@@ -90,7 +92,8 @@ SIGNATURES = {
 }
 _RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_gemm_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
             "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64, "det_bn_workspace_bytes": _i64,
-            "det_rpn_topk_decode_workspace_bytes": _i64, "nms_prepare_workspace_bytes": _i64}
+            "det_rpn_topk_decode_workspace_bytes": _i64, "nms_prepare_workspace_bytes": _i64,
+            "conv3x3_splitk_workspace_bytes": _i64}
 
 _lib = None
 

@@ -71,7 +71,7 @@ template <typename ALoader, bool RELU, int WM, int NBUF>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2 : 1)) : 1) void gemm_bf16_kernel(ALoader A, const bf16* __restrict__ Wt,
                                                                               const float* __restrict__ bias, bf16* __restrict__ C,
                                                                               int64_t M, int Nn, int K, int mtiles, int ntiles,
-                                                                              const bf16* __restrict__ gate) {
+                                                                              const bf16* __restrict__ gate, float* __restrict__ part, int ksplit) {
     constexpr int TM = 64 * WM;                                          // tile rows (pixels)
     extern __shared__ __attribute__((aligned(16))) uint4 lds_raw[];      // [buf][A: TM*8 | W: BN*8]
     auto ldsA = [&](int buf) { return lds_raw + (size_t)buf * (TM + BN) * 8; };
@@ -202,15 +202,23 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
         // tile kt+3.  No __syncthreads() here: with a DMA in flight its fence would drain the ring (guide section 5).
         constexpr int DPT = 4 + WI;
         static_assert(DPT == 8, "vmcnt literals below assume 8 DMA instructions per tile and wave");
+        // split K (small maps, gemm_launch): blockIdx.y owns K-tiles [kb, kb + nkl) and stores its fp32 partial tile in `part`;
+        // splitk_finish_kernel adds the slabs and applies bias / ReLU / gate.  The 36-tile chain of a 3x3 conv costs ~1.1 us per
+        // tile however few tiles the map has (DMA latency / 3 tiles in flight): P4..P6 all took 40 us on 126 / 32 / 10 CUs.
+        int kb = 0, nkl = nk;
+        if (ksplit > 1) {
+            kb = (int)((int64_t)nk * blockIdx.y / ksplit);
+            nkl = (int)((int64_t)nk * (blockIdx.y + 1) / ksplit) - kb;
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if (i < nk) dma_tile(i, i);
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (i < nkl) dma_tile(kb + i, i);
+        for (int kt = 0; kt < nkl; ++kt) {
+            if (kt + 2 < nkl) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (kt + 1 < nkl) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 3 < nk) dma_tile(kt + 3, (kt + 3) & 3);
+            if (kt + 3 < nkl) dma_tile(kb + kt + 3, (kt + 3) & 3);
             compute(kt & 3);
         }
     } else if constexpr (NBUF == 1) {
@@ -263,6 +271,25 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
             }
         }
         return;
+    }
+    if constexpr (NBUF == 4) {
+        if (ksplit > 1) {                          // fp32 partial tile of this K range, plain stores: slab [split][m][n]
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                int64_t m = m0 + wm * 64 + 32 * mt + c;
+                if (m >= M) continue;
+                float* prow = part + ((int64_t)blockIdx.y * M + m) * Nn;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        int n = n0 + wn * 64 + 32 * nt + 8 * gq + 4 * h;
+                        if (n >= Nn) continue;
+                        *(f32x4*)(prow + n) = f32x4{acc[nt][mt][4 * gq], acc[nt][mt][4 * gq + 1], acc[nt][mt][4 * gq + 2], acc[nt][mt][4 * gq + 3]};
+                    }
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -497,8 +524,51 @@ static int conv256_launch(ConvA A, const bf16* Wt, const float* bias, bf16* C, i
     return swin_launch_status();
 }
 
+// Second half of a split-K launch: C = bf16(relu?(sum over slabs + bias)), zeroed where gate is not positive.  One thread per four
+// consecutive output channels of a pixel (Nn % 4 == 0).
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, int64_t MN, int Nn,
+                                                            const float* __restrict__ bias, int relu, const bf16* __restrict__ gate,
+                                                            bf16* __restrict__ C) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= MN) return;
+    f32x4 v = *(const f32x4*)(part + i);
+    for (int s = 1; s < ksplit; ++s) {
+        const f32x4 u = *(const f32x4*)(part + (int64_t)s * MN + i);
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    const int n = (int)(i % Nn);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e] + (bias ? bias[n + e] : 0.f);
+        if (relu) x = fmaxf(x, 0.f);
+        o[e] = (bf16)x;
+    }
+    if (gate) {
+        const bf16x4 gt = *(const bf16x4*)(gate + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (!((float)gt[e] > 0.f)) o[e] = (bf16)0.f;
+    }
+    *(bf16x4*)(C + i) = o;
+}
+
+// K split of the few-tile shapes: as many K ranges as fill the chip once (256 CUs, one 128 KB block each), at least 3 K-tiles per
+// range.  1 = no split.  (P5: 32 tiles -> 8, P6: 10 -> 12.)  Kernel trace, 2 x 800 x 1280 batch: P5 40 -> 16.6 + 4.3 us (finish),
+// P6 40 -> 11.3 + 4.3 us.  P4 (126 tiles) with two ranges: 41 -> 31.4 + 5.6 us and 32 MB of slab traffic -- not worth a second
+// launch, hence the 64-tile limit.  A range costs ~9 us whatever its length (launch, per-lane border masks, first DMA latency).
+static int conv_ksplit(int64_t M, int Nn, int K) {
+    static const int off = getenv("SWIN_CONV_KSPLIT") ? atoi(getenv("SWIN_CONV_KSPLIT")) : -1;    // 0 / 1: never split; n > 1: forced
+    const int64_t blocks = ((M + 127) / 128) * ((Nn + BN - 1) / BN);
+    const int nk = K / BK;
+    if (off == 0 || off == 1 || blocks > (off > 1 ? 128 : 64) || Nn % 4 != 0) return 1;
+    int s = off > 1 ? off : (int)(256 / blocks);
+    if (s > nk / 3) s = nk / 3;
+    return s < 2 ? 1 : s;
+}
+
 template <typename ALoader, bool RELU, int WM, int NBUF>
-static int gemm_launch_wm(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, hipStream_t s, const bf16* gate) {
+static int gemm_launch_wm(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, hipStream_t s, const bf16* gate,
+                          float* part = nullptr, int ksplit = 1, int finish_relu = 0) {
     constexpr int TM = 64 * WM;
     const size_t lds_bytes = NBUF * (size_t)(TM + BN) * 8 * sizeof(uint4);
     static bool attr_set[16] = {};                           // per device
@@ -511,7 +581,15 @@ static int gemm_launch_wm(ALoader A, const bf16* Wt, const float* bias, bf16* C,
         attr_set[dev] = true;
     }
     int mtiles = (int)((M + TM - 1) / TM), ntiles = (Nn + BN - 1) / BN;
-    gemm_bf16_kernel<ALoader, RELU, WM, NBUF><<<mtiles * ntiles, 128 * WM, lds_bytes, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles, gate);
+    if (ksplit > 1) {                                // (always the RELU = false instantiation: bias / ReLU / gate belong to the finish)
+        gemm_bf16_kernel<ALoader, RELU, WM, NBUF><<<dim3(mtiles * ntiles, ksplit), 128 * WM, lds_bytes, s>>>(A, Wt, nullptr, C, M, Nn, K, mtiles,
+                                                                                                          ntiles, nullptr, part, ksplit);
+        if (int st = swin_launch_status()) return st;
+        const int64_t MN = M * Nn;
+        splitk_finish_kernel<<<(unsigned)((MN / 4 + 255) / 256), 256, 0, s>>>(part, ksplit, MN, Nn, bias, finish_relu, gate, C);
+        return swin_launch_status();
+    }
+    gemm_bf16_kernel<ALoader, RELU, WM, NBUF><<<mtiles * ntiles, 128 * WM, lds_bytes, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles, gate, nullptr, 1);
     return swin_launch_status();
 }
 
@@ -519,7 +597,7 @@ static int g_conv_wm = 0;     // 0: choose by size; 2 / 4: forced (A/B experimen
 
 template <typename ALoader>
 static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, int relu, hipStream_t s,
-                       const bf16* gate = nullptr) {
+                       const bf16* gate = nullptr, float* part = nullptr, int64_t part_bytes = 0) {
     static bool env_read = false;
     if (!env_read) { const char* e = getenv("SWIN_CONV_WM"); if (e) g_conv_wm = atoi(e); env_read = true; }
     if constexpr (std::is_same<ALoader, ConvA>::value) {
@@ -550,6 +628,13 @@ static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, in
         return gemm_launch_wm<ALoader, false, 2, 1>(A, Wt, bias, C, M, Nn, K, s, gate);
     }
     if (g_conv_wm == 3 || (g_conv_wm == 0 && blocks128 <= 256)) {      // at most one block per CU: 4-buffer DMA ring
+        if constexpr (std::is_same<ALoader, ConvA>::value) {
+            const int ks = part ? conv_ksplit(M, Nn, K) : 1;
+            if (ks > 1) {
+                if (part_bytes < (int64_t)ks * M * Nn * (int64_t)sizeof(float)) return SWIN_ERR_BAD_ARG;
+                return gemm_launch_wm<ALoader, false, 2, 4>(A, Wt, bias, C, M, Nn, K, s, gate, part, ks, relu);
+            }
+        }
         if (relu) return gemm_launch_wm<ALoader, true, 2, 4>(A, Wt, bias, C, M, Nn, K, s, gate);
         return gemm_launch_wm<ALoader, false, 2, 4>(A, Wt, bias, C, M, Nn, K, s, gate);
     }
@@ -565,6 +650,27 @@ extern "C" int conv3x3_nhwc_bf16(const void* x, const void* w, const float* bias
     int64_t M = (int64_t)N * H * W;
     ConvA A{(const bf16*)x, M, ConvGeom{N, H, W, Cin}, Cin / BK};
     return gemm_launch(A, (const bf16*)w, bias, (bf16*)y, M, Cout, 9 * Cin, relu, (hipStream_t)stream);
+}
+
+// Few-tile maps (the coarse pyramid levels): bytes of fp32 workspace with which conv3x3_nhwc_bf16_ws splits the contraction over
+// blockIdx.y (0: this shape is not split -- use the plain entry points).
+extern "C" int64_t conv3x3_splitk_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK != 0 || Cout % 4 != 0) return 0;
+    const int64_t M = (int64_t)N * H * W;
+    const int ks = conv_ksplit(M, Cout, 9 * Cin);
+    return ks > 1 ? (int64_t)ks * M * Cout * (int64_t)sizeof(float) : 0;
+}
+
+// conv3x3_nhwc_bf16 (gate == NULL) / conv3x3_nhwc_bf16_gated (gate != NULL, relu ignored) with a caller-provided workspace of
+// conv3x3_splitk_workspace_bytes(...) bytes; the result equals the unsplit kernel's up to the fp32 summation order.
+extern "C" int conv3x3_nhwc_bf16_ws(const void* x, const void* w, const float* bias, const void* gate, void* y, int N, int H, int W,
+                                    int Cin, int Cout, int relu, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (workspace && workspace_bytes <= 0)) return SWIN_ERR_BAD_ARG;
+    if (Cin % BK != 0 || Cout % 4 != 0) return SWIN_ERR_UNSUPPORTED;
+    int64_t M = (int64_t)N * H * W;
+    ConvA A{(const bf16*)x, M, ConvGeom{N, H, W, Cin}, Cin / BK};
+    return gemm_launch(A, (const bf16*)w, bias, (bf16*)y, M, Cout, 9 * Cin, gate ? 0 : relu, (hipStream_t)stream, (const bf16*)gate,
+                       (float*)workspace, workspace_bytes);
 }
 
 // The same convolution with its output zeroed wherever gate (N,H,W,Cout) bf16 is not positive: used for data gradients,

@@ -393,12 +393,27 @@ def upsample_add(fine, coarse):
 # --------------------------------------------------------------------------------------
 # 3x3 convolution (bf16, channels-last) on the MFMA implicit-GEMM kernel
 # --------------------------------------------------------------------------------------
-def _conv3x3_raw(x_cl, w_khwc, bias, relu):
-    """x_cl: (N,C,H,W) bf16 with channels_last strides; w_khwc: (Cout,3,3,Cin) bf16 contiguous."""
+_SPLITK_BYTES = {}
+
+
+def _conv3x3_raw(x_cl, w_khwc, bias, relu, gate=None):
+    """x_cl: (N,C,H,W) bf16 with channels_last strides; w_khwc: (Cout,3,3,Cin) bf16 contiguous.  gate (N,Cout,H,W) bf16
+    channels-last: the output is zeroed where gate <= 0 (a data gradient that includes the ReLU backward of the layer below).
+    Few-tile maps (coarse pyramid levels) go through the split-K entry with a workspace from the caching allocator."""
     N, Cin, H, W = x_cl.shape
     Cout = w_khwc.shape[0]
     y = torch.empty((N, Cout, H, W), device=x_cl.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
-    call("conv3x3_nhwc_bf16", _p(x_cl), _p(w_khwc), _p(bias), _p(y), N, H, W, Cin, Cout, int(relu), _s())
+    key = (N, H, W, Cin, Cout)
+    nb = _SPLITK_BYTES.get(key)
+    if nb is None:
+        nb = _SPLITK_BYTES[key] = int(_lib.lib().conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout))
+    if nb:
+        ws = torch.empty(nb, device=x_cl.device, dtype=torch.uint8)          # used on the current stream only
+        call("conv3x3_nhwc_bf16_ws", _p(x_cl), _p(w_khwc), _p(bias), _p(gate), _p(y), N, H, W, Cin, Cout, int(relu), _p(ws), nb, _s())
+    elif gate is not None:
+        call("conv3x3_nhwc_bf16_gated", _p(x_cl), _p(w_khwc), _p(bias), _p(gate), _p(y), N, H, W, Cin, Cout, _s())
+    else:
+        call("conv3x3_nhwc_bf16", _p(x_cl), _p(w_khwc), _p(bias), _p(y), N, H, W, Cin, Cout, int(relu), _s())
     return y
 
 
@@ -477,8 +492,7 @@ class _Conv3x3(torch.autograd.Function):
                                    lambda: weight.detach().to(torch.bfloat16).flip(2, 3).permute(1, 2, 3, 0).contiguous())
             if ctx.x_is_relu:
                 # x is the ReLU output of the layer below: its ReLU backward rides in this kernel's epilogue
-                dx = torch.empty((N, Cin, H, W), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
-                call("conv3x3_nhwc_bf16_gated", _p(dy), _p(wt), None, _p(x), _p(dx), N, H, W, Cout, Cin, _s())
+                dx = _conv3x3_raw(dy, wt, None, False, gate=x)
                 mixed.gated_mark(dx, x)
             else:
                 dx = _conv3x3_raw(dy, wt, None, False)

@@ -427,6 +427,45 @@ print("conv256 ok")
     assert r.returncode == 0 and "conv256 ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 32, 32, 256, 256), (2, 25, 40, 256, 256), (2, 13, 20, 256, 256), (1, 7, 9, 64, 128)])
+def test_conv3x3_split_k_small_maps(pkg, N, H, W, Cin, Cout):
+    """conv3x3_nhwc_bf16_ws on the coarse pyramid levels (P5 of a 1024 x 1024 batch, P5 / P6 of the bench batch and a one-tile map): the contraction split
+    over blockIdx.y + the finish launch against (a) an fp32 convolution of the same bf16 operands, with bias + ReLU and in the
+    gated data-gradient form, and (b) the unsplit kernel -- equal up to one bf16 rounding of the differently ordered fp32 sum."""
+    import torch.nn.functional as F
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    nb = int(_lib.lib().conv3x3_splitk_workspace_bytes(N, H, W, Cin, Cout))
+    assert nb > 0 and nb % (N * H * W * Cout * 4) == 0 and nb // (N * H * W * Cout * 4) >= 2
+    assert int(_lib.lib().conv3x3_splitk_workspace_bytes(2, 200, 320, 256, 256)) == 0       # many tiles: never split
+    assert int(_lib.lib().conv3x3_splitk_workspace_bytes(2, 50, 80, 256, 256)) == 0         # 126 tiles: measured, not worth it
+    torch.manual_seed(N * H + W)
+    x = torch.randn(N, Cin, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, 3, 3, Cin, device="cuda") * (2.0 / (9 * Cin)) ** 0.5).bfloat16()
+    b = torch.randn(Cout, device="cuda") * 0.1
+    gate = torch.relu(torch.randn(N, Cout, H, W, device="cuda")).bfloat16().contiguous(memory_format=torch.channels_last)
+    y = Fn._conv3x3_raw(x, w, b, True)                       # split (the host wrapper asks for the workspace size)
+    z = Fn._conv3x3_raw(x, w, None, False, gate=gate)
+    y0, z0 = torch.empty_like(y), torch.empty_like(z)        # unsplit kernel
+    Fn.call("conv3x3_nhwc_bf16", Fn._p(x), Fn._p(w), Fn._p(b), Fn._p(y0), N, H, W, Cin, Cout, 1, Fn._s())
+    Fn.call("conv3x3_nhwc_bf16_gated", Fn._p(x), Fn._p(w), None, Fn._p(gate), Fn._p(z0), N, H, W, Cin, Cout, Fn._s())
+    conv = F.conv2d(x.float(), w.float().permute(0, 3, 1, 2), None, padding=1)
+    ref = F.relu(conv + b.view(1, -1, 1, 1))
+    ref2 = conv * (gate > 0)
+    for got, unsplit, want, what in ((y, y0, ref, "fwd"), (z, z0, ref2, "gated")):
+        tol = 2 * 2.0 ** -8 * float(want.abs().max())
+        assert float((got.float() - want).abs().max()) <= tol, what
+        d = (got.float() - unsplit.float()).abs()
+        assert bool((d <= 2.0 ** -7 * torch.maximum(got.float().abs(), unsplit.float().abs()) + 1e-6).all()), (what, float(d.max()))
+    # too small a workspace is refused, none at all is the plain kernel
+    ws = torch.empty(nb - 4, device="cuda", dtype=torch.uint8)
+    with pytest.raises(Fn.SwinHipError):
+        Fn.call("conv3x3_nhwc_bf16_ws", Fn._p(x), Fn._p(w), Fn._p(b), None, Fn._p(y0), N, H, W, Cin, Cout, 1, Fn._p(ws), nb - 4, Fn._s())
+    y1 = torch.empty_like(y)
+    Fn.call("conv3x3_nhwc_bf16_ws", Fn._p(x), Fn._p(w), Fn._p(b), None, Fn._p(y1), N, H, W, Cin, Cout, 1, None, 0, Fn._s())
+    assert torch.equal(y1, y0)
+
+
 @pytest.mark.parametrize("N1,N2", [(288, 96), (384, 96), (96, 384), (96, 96)])
 def test_linear_wgrad_stage1_full_T(pkg, N1, N2):
     """wgrad_linear_bf16 at the stage-1 token count of the bench (T = 2*200*320 = 128 000: split-T, two k-groups)."""

@@ -61,7 +61,7 @@ def attn():
 
 
 def conv():
-    for (N, H, W) in [(2, 200, 320), (2, 100, 160), (2, 50, 80), (2, 25, 40), (200, 14, 14)]:
+    for (N, H, W) in [(2, 200, 320), (2, 100, 160), (2, 50, 80), (2, 25, 40), (2, 13, 20), (200, 14, 14)]:
         x = torch.randn(N, 256, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
         w = torch.randn(256, 3, 3, 256, device="cuda").bfloat16() * 0.02
         b = torch.zeros(256, device="cuda")
