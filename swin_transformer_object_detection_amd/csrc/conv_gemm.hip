@@ -53,6 +53,14 @@ struct ConvA {
         }
         return m;
     }
+    // K-tile cursor for loops that walk the K-tiles in order: no division per tile (one wave per SIMD pays every scalar instruction)
+    struct Cur { int tap, c, ty, tx; };
+    __device__ __forceinline__ void seek(int kt, Cur& q) const { q.tap = kt / cpt; q.c = kt - q.tap * cpt; q.ty = q.tap / 3; q.tx = q.tap - 3 * q.ty; }
+    __device__ __forceinline__ int64_t koff(const Cur& q) const { return ((int64_t)(q.ty - 1) * g.W + (q.tx - 1)) * g.Cin + q.c * BK; }
+    __device__ __forceinline__ int ktile(const Cur& q) const { return q.tap * cpt + q.c; }
+    __device__ __forceinline__ void next(Cur& q) const {
+        if (++q.c == cpt) { q.c = 0; ++q.tap; if (++q.tx == 3) { q.tx = 0; ++q.ty; } }
+    }
     __device__ __forceinline__ void kinfo(int kt, int64_t& koff, int& tap) const {
         tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * BK, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -63,6 +71,17 @@ struct ConvA {
 __device__ __forceinline__ int swz(int row, int piece) { return piece ^ ((row >> 1) & 7); }
 
 __device__ uint4 g_zero16[4];      // zero-initialised: source of padded 16-byte pieces
+
+// LDS-DMA as inline asm (M0 = wave-uniform LDS byte address, saved and restored): the BUILTIN form makes hipcc drain the DMA with
+// s_waitcnt vmcnt(0) in front of the next ds_read of the loop (it cannot tell which LDS bytes the DMA writes), which is exactly the
+// wait the counted schedules below exist to avoid.  An asm DMA is invisible to that bookkeeping; its completion is waited for by hand.
+__device__ __forceinline__ void glds16(uint64_t gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+// (Round 2: the 128-row kernel used the builtin until its ring of four buffers was found drained by such a compiler-inserted
+// vmcnt(0) at every K-tile -- the 1 us per K-tile floor of the small maps.)
 
 // WM = wave rows of the block: tile (64 WM) x 128 x 64 with 2 WM waves.  WM = 2 is the 128x128 tile (two blocks per
 // CU); WM = 4 doubles the pixel rows per weight tile (one 8-wave block per CU): 48 KB instead of 64 KB of operand
@@ -121,19 +140,21 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
         wptr[i] = (uint64_t)reinterpret_cast<uintptr_t>(Wt + (wok[i] ? (int64_t)n * K : 0) + piece * 8);
     }
     const int nk = K / BK;
-    auto dma_tile = [&](int kt, int buf) {
-        int64_t koff; int tap;
-        A.kinfo(kt, koff, tap);                                    // wave-uniform
-        const uint64_t abytes = (uint64_t)(koff * 2), wbytes = (uint64_t)kt * BK * 2;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);          // LDS destinations of the DMA live in SGPRs (M0)
+    typename ALoader::Cur cur_k;                                   // the next K-tile to stage (wave-uniform)
+    auto dma_tile = [&](int buf) {                                 // stages K-tile cur_k into LDS buffer buf and advances the cursor
+        const int tap = cur_k.tap;
+        const uint64_t abytes = (uint64_t)(A.koff(cur_k) * 2), wbytes = (uint64_t)A.ktile(cur_k) * BK * 2;
+        A.next(cur_k);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint64_t src = ((amask[i] >> tap) & 1u) ? aptr[i] + abytes : zero64;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ldsA(buf) + (32 * wave + 8 * i) * 8), 16, 0, 0);
+            glds16(src, (unsigned)(uintptr_t)(lptr_t)(ldsA(buf) + (32 * wave_u + 8 * i) * 8));
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const uint64_t src = wok[i] ? wptr[i] + wbytes : zero64;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ldsW(buf) + (WROWS * wave + 8 * i) * 8), 16, 0, 0);
+            glds16(src, (unsigned)(uintptr_t)(lptr_t)(ldsW(buf) + (WROWS * wave_u + 8 * i) * 8));
         }
     };
     // two MFMA forms: 32x32x16 (2x2 accumulator tiles per wave) and 16x16x32 (4x4 tiles, same 64 registers); the
@@ -172,22 +193,30 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
                         acc16[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc16[nt][mt], 0, 0, 0);
             }
         } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 wf[2], af[2];
+            // two fragment sets: the reads of k-step s+1 are in flight under the MFMAs of step s (these variants run one or two
+            // blocks per CU -- nothing else hides the LDS latency; with one set a K-tile took ~0.7 us of which 0.2 us MFMA)
+            bf16x8 wf[2][2], af[2][2];
+            auto frag = [&](int s, int b) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     int rw_ = wn * 64 + 32 * t + c, ra_ = wm * 64 + 32 * t + c;
                     uint4 u = Ws[rw_ * 8 + swz(rw_, 2 * s + h)];
                     uint4 v = As[ra_ * 8 + swz(ra_, 2 * s + h)];
-                    wf[t] = *(bf16x8*)&u;
-                    af[t] = *(bf16x8*)&v;
+                    wf[b][t] = *(bf16x8*)&u;
+                    af[b][t] = *(bf16x8*)&v;
                 }
+            };
+            frag(0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < 3) frag(s + 1, (s + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);         // (left alone, the scheduler folds the two sets back into one and serialises)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][nt], af[s & 1][mt], acc[nt][mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -210,33 +239,36 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
             kb = (int)((int64_t)nk * blockIdx.y / ksplit);
             nkl = (int)((int64_t)nk * (blockIdx.y + 1) / ksplit) - kb;
         }
+        A.seek(kb, cur_k);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if (i < nkl) dma_tile(kb + i, i);
+            if (i < nkl) dma_tile(i);
         for (int kt = 0; kt < nkl; ++kt) {
             if (kt + 2 < nkl) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if (kt + 1 < nkl) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 3 < nkl) dma_tile(kb + kt + 3, (kt + 3) & 3);
+            if (kt + 3 < nkl) dma_tile((kt + 3) & 3);
             compute(kt & 3);
         }
     } else if constexpr (NBUF == 1) {
         // one LDS buffer, two barriers per K-tile: 32 KB per block -> 4 blocks per CU overlap each other's DMA and MFMA
+        A.seek(0, cur_k);
         for (int kt = 0; kt < nk; ++kt) {
-            dma_tile(kt, 0);
+            dma_tile(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             compute(0);
             __syncthreads();
         }
     } else {
-        dma_tile(0, 0);
+        A.seek(0, cur_k);
+        dma_tile(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);       // lands while this tile feeds the MFMAs
+            if (kt + 1 < nk) dma_tile(cur ^ 1);               // lands while this tile feeds the MFMAs
             compute(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt+1 have landed
             __syncthreads();                                   // ... and everyone's; all reads of tile kt are done
@@ -330,15 +362,6 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
 // raised priority -- with a raw barrier after each, and the two pixel-half wave groups run one section apart (see the loop).
 // Shapes: M % 256 == 0, Nn % 256 == 0, K % 64 == 0 (the FPN / RPN convs at P2 and the mask-head convs).
 // ---------------------------------------------------------------------------------------------------------------------------
-// LDS-DMA as inline asm (M0 = wave-uniform LDS byte address, saved and restored): the BUILTIN form makes hipcc drain the DMA with
-// s_waitcnt vmcnt(0) in front of the next ds_read of the loop (it cannot tell which LDS bytes the DMA writes), which is exactly the
-// wait the counted schedule below exists to avoid.  An asm DMA is invisible to that bookkeeping; its completion is waited for by hand.
-__device__ __forceinline__ void glds16(uint64_t gsrc, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
-}
-
 template <bool RELU>
 __global__ __launch_bounds__(512) void conv256_kernel(ConvA A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
                                                       bf16* __restrict__ C, int64_t M, int Nn, int K, int mtiles, int ntiles,
