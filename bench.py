@@ -95,8 +95,8 @@ def attention_roofline(device, steps=30):
     # rocprofv3 --pmc runs of the same kernel and geometry, gfx950 correction applied); null if not collected
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_attn_traffic.json")) as f:
-            traffic = round(json.load(f)["kernels"]["win_attn_fwd_bf16@grid131328"]["hbm_bytes_per_launch_corrected"])
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_attn_traffic.json")) as f:
+            traffic = round(json.load(f)["kernels"]["win_attn_fwd_bf16@stage1_wpb3"]["hbm_bytes_per_launch_corrected"])
     except Exception:
         pass
     # the BASELINE metric also names "WindowAttn MFMA util%": the core is HBM-bound (AI ~ 24 flop/B, ridge ~ 310), so this is
@@ -316,7 +316,8 @@ def main():
         losses = model.forward_train(**batch)
         loss, log_vars = model.parse_losses(losses)
         reducer.mark_backward_start()
-        loss.backward()
+        with torch.autograd.set_multithreading_enabled(False):    # engine on this thread: 9.4 vs 9.4-10.2 ms of host time per step (tools/host_time.py engine)
+            loss.backward()
         comm["backward_issued_ms"] = round(reducer._now() * 1e3, 3)     # host time: every backward kernel has been issued
         reducer.finish()
         comm["finish_ms"] = round(reducer._now() * 1e3, 3)

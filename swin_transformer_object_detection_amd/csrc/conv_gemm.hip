@@ -638,7 +638,10 @@ static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, in
     }
     // large pixel counts: the 256-row tile (one 8-wave block per CU); otherwise the 128-row tile keeps the grid full
     const int64_t blocks128 = ((M + 127) / 128) * ((Nn + BN - 1) / BN);
-    const bool big = g_conv_wm == 4;   // (measured: no gain over the 128-row tile, kept for experiments)
+    // the 256-row tile (8 waves, one block per CU, two buffers): for maps of 257..512 128-row tiles (P3 of the bench batch: 250 blocks
+    // of 256 rows = one per CU) -- SWIN_CONV_MID=1; everywhere else it measured no better than the 128-row tile
+    static const int mid = getenv("SWIN_CONV_MID") ? atoi(getenv("SWIN_CONV_MID")) : 0;
+    const bool big = g_conv_wm == 4 || (g_conv_wm == 0 && mid && blocks128 > 256 && blocks128 <= 512);
     if (big) {
         if (relu) return gemm_launch_wm<ALoader, true, 4, 2>(A, Wt, bias, C, M, Nn, K, s, gate);
         return gemm_launch_wm<ALoader, false, 4, 2>(A, Wt, bias, C, M, Nn, K, s, gate);
@@ -646,7 +649,7 @@ static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, in
     // enough tiles for several blocks per CU: ONE LDS buffer (32 KB, two barriers per K-tile) at 4 blocks per CU -- the
     // co-resident blocks overlap each other's DMA and MFMA phases better than a block's own double buffer does
     // (P2 map: 535 -> 663 TFLOP/s, mask-head convs: 399 -> 593); few tiles: the double-buffered block hides more itself
-    if (g_conv_wm == 1 || (g_conv_wm == 0 && blocks128 > 512)) {
+    if (g_conv_wm == 1 || (g_conv_wm == 0 && blocks128 > 512)) {       // (SWIN_CONV_WM=2 forces the two-buffer variant below)
         if (relu) return gemm_launch_wm<ALoader, true, 2, 1>(A, Wt, bias, C, M, Nn, K, s, gate);
         return gemm_launch_wm<ALoader, false, 2, 1>(A, Wt, bias, C, M, Nn, K, s, gate);
     }

@@ -202,9 +202,15 @@ __device__ __forceinline__ void fwd_issue_loads(bf16x8 (&stg)[10], const FwdLane
 
 __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
     const bf16* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
-    bf16* __restrict__ out, float* __restrict__ lse, WinGeom g, float scale, int n_tasks) {
+    bf16* __restrict__ out, float* __restrict__ lse, WinGeom g, float scale, int n_tasks, int wpb) {
     __shared__ __attribute__((aligned(16))) bf16 lds[4][3][TILE][LROW];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // wpb = waves of the block that take tasks (3 when nH == 3, else 4).  With three heads and four working waves every second
+    // window has one head in another block -- usually on another XCD -- than the other two; the heads' 64-byte slices interleave
+    // in the token rows (q.h0|q.h1, q.h2|k.h0, ... share 128-byte lines), so that head's block fetches every shared line a second
+    // time from HBM: the 1.29x traffic of the stage-1 launch.  Three working waves keep a window's heads in one block (no block-wide
+    // barrier in this kernel: the fourth wave just leaves).
+    if (wave >= wpb) return;
     FwdLane L;
     L.lane = threadIdx.x & 63; L.c = L.lane & 31; L.h = L.lane >> 5;
     const int lane = L.lane, c = L.c, h = L.h;
@@ -216,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
         uint4* p = (uint4*)&lds[wave][0][0][0];
         for (int i = lane; i < 3 * TILE * LROW * 2 / 16; i += WAVE) p[i] = z;   // rows 49..63 stay zero
     }
-    const int n_waves = gridDim.x * 4;   // host guarantees n_waves % nH == 0
-    int task = blockIdx.x * 4 + wave;
+    const int n_waves = gridDim.x * wpb;   // host guarantees n_waves % nH == 0
+    int task = blockIdx.x * wpb + wave;
     if (task >= n_tasks) return;
     const int head = task % g.nH;
 
@@ -907,7 +913,9 @@ __device__ __forceinline__ void bwd2_issue_loads(bf16x8 (&stg)[7], const Bwd2Lan
 __global__ __launch_bounds__(512) void win_attn_bwd2_bf16_kernel(
     const bf16* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
     const float* __restrict__ lse, const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
-    float* __restrict__ dbias_ws, float* __restrict__ dbias_pad, WinGeom g, float scale, int n_tasks, int iters) {
+    float* __restrict__ dbias_ws, float* __restrict__ dbias_pad, WinGeom g, float scale, int n_tasks, int iters, int ppb) {
+    // ppb = wave pairs (tasks in flight) per block = blockDim.x / 128: 4, or 3 to keep the three heads of a window in one block
+    // when nH == 3 (see win_attn_fwd_bf16_kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = wave >> 1, w = wave & 1;
@@ -924,8 +932,8 @@ __global__ __launch_bounds__(512) void win_attn_bwd2_bf16_kernel(
         uint4* p = (uint4*)Lm;
         for (int i = lane + WAVE * w; i < (int)(sizeof(BwdLds2) / 16); i += 2 * WAVE) p[i] = z;
     }
-    const int n_pairs = gridDim.x * 4;
-    int task = blockIdx.x * 4 + pair;
+    const int n_pairs = gridDim.x * ppb;
+    int task = blockIdx.x * ppb + pair;
     float* const slab = dbias_ws + (size_t)task * SLAB;
     const int head = task % g.nH;                      // n_pairs % nH == 0: constant over the pair's tasks
     const int C3 = 3 * g.C;
@@ -1279,8 +1287,20 @@ static int round_blocks(int want, int n_tasks, int nH) {
     return b < all ? b : all;
 }
 
-static int attn_grid_blocks(int n_tasks, int nH) {
+// forward: working waves per block.  nH == 3 (stage 1 of Swin-T/S): 3, so that the three heads of a window share a block
+// (see the kernel); SWIN_ATTN_FWD_WPB=4 restores the four-wave mapping for comparison.
+static int attn_fwd_wpb(int nH) {
+    static const int forced = getenv("SWIN_ATTN_FWD_WPB") ? atoi(getenv("SWIN_ATTN_FWD_WPB")) : 0;
+    if (forced == 3 || forced == 4) return (forced == 3 && nH % 3 != 0) ? 4 : forced;
+    return nH == 3 ? 3 : 4;
+}
+
+static int attn_grid_blocks(int n_tasks, int nH, int wpb) {
     static const int forced = getenv("SWIN_ATTN_FWD_BLOCKS") ? atoi(getenv("SWIN_ATTN_FWD_BLOCKS")) : 0;   // development sweep
+    if (wpb == 3) {                                  // nH % 3 == 0: any block count keeps (waves % nH == 0)
+        const int all = (n_tasks + 2) / 3, want = forced > 0 ? forced : 512;        // swept: 480: 26.4 us, 512: 25.2, 640: 27.3 (stage 1)
+        return want < all ? want : all;
+    }
     return round_blocks(forced > 0 ? forced : 480, n_tasks, nH);
 }
 
@@ -1293,9 +1313,10 @@ extern "C" int swin_window_attn_fwd(const void* qkv, const float* qkv_bias, cons
     int n_tasks = B * g.nW * nH;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SWIN_BF16) {
-        int blocks = attn_grid_blocks(n_tasks, nH);
+        const int wpb = attn_fwd_wpb(nH);
+        int blocks = attn_grid_blocks(n_tasks, nH, wpb);
         win_attn_fwd_bf16_kernel<<<blocks, 256, 0, s>>>((const bf16*)qkv, qkv_bias, bias_exp, (bf16*)out, lse, g,
-                                                        scale, n_tasks);
+                                                        scale, n_tasks, wpb);
     } else {
         win_attn_fwd_f32_kernel<<<n_tasks, 64, 0, s>>>((const float*)qkv, qkv_bias, bias_exp, (float*)out, lse, g,
                                                        scale);
@@ -1325,8 +1346,21 @@ extern "C" int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int n
     return launch(stream);
 }
 
+// backward (two-wave kernel): wave pairs per block.  nH == 3: 3, so that a window's heads share a block as in the forward kernel
+// (stage 1: 73.4 -> 71.5 us with a quarter fewer waves); SWIN_ATTN_BWD_PPB=4 restores four pairs.
+static int attn_bwd_ppb(int nH) {
+    static const int forced = getenv("SWIN_ATTN_BWD_PPB") ? atoi(getenv("SWIN_ATTN_BWD_PPB")) : 0;
+    static const int one_wave = getenv("SWIN_ATTN_BWD_WAVES") ? atoi(getenv("SWIN_ATTN_BWD_WAVES")) == 1 : 0;
+    if (one_wave || forced == 4 || nH % 3 != 0) return 4;
+    return (forced == 3 || nH == 3) ? 3 : 4;
+}
+
 static int attn_bwd_blocks(int n_tasks, int nH) {
     static const int forced = getenv("SWIN_ATTN_BWD_BLOCKS") ? atoi(getenv("SWIN_ATTN_BWD_BLOCKS")) : 0;   // development sweep
+    if (attn_bwd_ppb(nH) == 3) {                     // any block count keeps (pairs % nH == 0); swept at stage 1: 240: 74.5 us, 256: 71.5, 320: 89
+        const int all = (n_tasks + 2) / 3, want = forced > 0 ? forced : 256;
+        return want < all ? want : all;
+    }
     if (forced > 0) return round_blocks(forced, n_tasks, nH);
     const bool many_rounds = n_tasks >= 6 * 960;                 // >= 6 rounds at 240 blocks
     // two-waves-per-task kernel, swept over 192..512 blocks (round 2): stage 1 (8004 tasks) 72.9 us at 240 (256: 73.2, 320+: 84-88);
@@ -1369,10 +1403,11 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
                                     (int)(4 * sizeof(BwdLds2))) != hipSuccess) return SWIN_ERR_LAUNCH;
             attr_set[dev] = true;
         }
+        const int ppb = attn_bwd_ppb(nH);
         if (two_waves) {
-            const int iters = (n_tasks + blocks * 4 - 1) / (blocks * 4);
-            win_attn_bwd2_bf16_kernel<<<blocks, 512, shm, s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
-                                                               (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks, iters);
+            const int iters = (n_tasks + blocks * ppb - 1) / (blocks * ppb);
+            win_attn_bwd2_bf16_kernel<<<blocks, 128 * ppb, ppb * sizeof(BwdLds2), s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
+                                                               (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks, iters, ppb);
         } else {
             win_attn_bwd_bf16_kernel<<<blocks, 256, shm, s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
                                                               (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks);
@@ -1381,7 +1416,7 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
         dim3 rgrid((n + 255) / 256, 16);
         // bias-gradient reduce: off the data-gradient chain (see csrc/abi.hip)
         auto launch = [=](void* st) {
-            dbias_slab_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)st>>>((const float*)workspace, dbias_exp, dqkv_bias_pad, blocks * 4, nH, C);
+            dbias_slab_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)st>>>((const float*)workspace, dbias_exp, dqkv_bias_pad, blocks * ppb, nH, C);
             return swin_launch_status();
         };
         if (!swin_aux_push(launch)) {

@@ -18,6 +18,7 @@ def step():
     loss, _ = model.parse_losses(model.forward_train(**batch)); loss.backward(); red.finish(); opt.step()
 
 
+torch.autograd.set_multithreading_enabled(False)      # backward on THIS thread, so that the profile sees it
 for _ in range(8): step()
 torch.cuda.synchronize()
 n = 20
@@ -29,7 +30,7 @@ torch.cuda.synchronize()
 for key in ("cumulative", "tottime"):
     s = io.StringIO()
     st = pstats.Stats(pr, stream=s).sort_stats(key)
-    st.print_stats(45)
+    st.print_stats(70)
     txt = s.getvalue()
     print(f"==== sorted by {key} (totals over {n} steps; divide by {n})")
     print("\n".join(l[:200] for l in txt.splitlines()[4:]))

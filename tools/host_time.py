@@ -22,6 +22,20 @@ def step():
 
 for _ in range(8): step()
 torch.cuda.synchronize()
+if len(sys.argv) > 1 and sys.argv[1] == "engine":
+    # A/B in ONE process (boxes differ by 30 % in host speed): autograd engine on its device thread (default) vs on the calling thread
+    for rep in range(3):
+        for single in (False, True):
+            with torch.autograd.set_multithreading_enabled(not single):
+                for _ in range(3): step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30): step()
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+            print(f"engine on the {'calling' if single else 'device '} thread: host enqueue {(t1 - t0) / 30 * 1e3:.2f} ms/step, until GPU done {(t2 - t0) / 30 * 1e3:.2f} ms/step", flush=True)
+    sys.exit(0)
 n = 30
 t0 = time.perf_counter()
 marks = []
