@@ -2,6 +2,7 @@
 #include <vector>
 
 #include "common.h"
+#include <cstdlib>
 extern "C" int swin_hip_abi_version(void) { return 1; }
 
 // ---- second stream for work that nothing on the main stream waits for ------------------------------------------------------
@@ -100,6 +101,20 @@ extern "C" int swin_stream_create_low_priority(void** out) {
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return SWIN_ERR_LAUNCH;
     hipStream_t s = nullptr;
+    // experiment (SWIN_SIDE_CU_DROP=D): a stream that may not use every D-th CU instead of a low-priority one -- priorities do not
+    // preempt, so a short kernel of the main stream otherwise waits for CUs behind 40-140 us weight-gradient workgroups
+    static const int drop = getenv("SWIN_SIDE_CU_DROP") ? atoi(getenv("SWIN_SIDE_CU_DROP")) : 0;
+    if (drop >= 2) {
+        uint32_t mask[16];
+        for (int w = 0; w < 16; ++w) {
+            uint32_t m = 0;
+            for (int b = 0; b < 32; ++b) if ((w * 32 + b) % drop != drop - 1) m |= 1u << b;
+            mask[w] = m;
+        }
+        if (hipExtStreamCreateWithCUMask(&s, 16, mask) != hipSuccess) return SWIN_ERR_LAUNCH;
+        *out = (void*)s;
+        return SWIN_OK;
+    }
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) return SWIN_ERR_LAUNCH;
     *out = (void*)s;
     return SWIN_OK;
