@@ -365,7 +365,8 @@ def test_nms_empty_and_batched(ops):
 # MFMA implicit-GEMM 3x3 convolution (bf16)
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,H,W,Cin,Cout,relu", [(2, 13, 20, 64, 64, False), (1, 25, 40, 256, 256, True),
-                                                  (3, 7, 9, 128, 192, False), (2, 50, 80, 256, 256, False)])
+                                                  (3, 7, 9, 128, 192, False), (2, 50, 80, 256, 256, False),
+                                                  (2, 100, 160, 256, 256, True)])      # P3: the 256-row tile (257..512 tiles of 128 rows)
 def test_conv3x3_bf16(ops, N, H, W, Cin, Cout, relu):
     """Oracle: fp32 F.conv2d on the CPU with the same bf16-rounded operands (fpn.py:195-197 semantics).
     Tolerance: bf16 output rounding (2^-8 relative) of sums of 9*Cin bf16 products accumulated in fp32."""
