@@ -36,6 +36,28 @@ if len(sys.argv) > 1 and sys.argv[1] == "engine":
                 t2 = time.perf_counter()
             print(f"engine on the {'calling' if single else 'device '} thread: host enqueue {(t1 - t0) / 30 * 1e3:.2f} ms/step, until GPU done {(t2 - t0) / 30 * 1e3:.2f} ms/step", flush=True)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "gc":
+    # A/B in one process: Python's cyclic collector as it comes vs frozen survivors + a generation-0 threshold far above a step's allocations
+    import gc
+    torch.autograd.set_multithreading_enabled(False)
+    for rep in range(3):
+        for tuned in (False, True):
+            if tuned:
+                gc.collect(); gc.freeze(); gc.set_threshold(200000, 50, 50)
+            else:
+                gc.unfreeze(); gc.set_threshold(700, 10, 10)
+            for _ in range(3): step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); marks = []
+            for _ in range(40):
+                step(); marks.append(time.perf_counter())
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            d = sorted((marks[i] - marks[i - 1]) * 1e3 for i in range(1, 40))
+            print(f"gc {'frozen, threshold 200000' if tuned else 'default                 '}: host enqueue {(t1 - t0) / 40 * 1e3:.2f} ms/step "
+                  f"(median {d[len(d) // 2]:.2f}, max {d[-1]:.2f}), until GPU done {(t2 - t0) / 40 * 1e3:.2f} ms/step", flush=True)
+    sys.exit(0)
 n = 30
 t0 = time.perf_counter()
 marks = []
