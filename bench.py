@@ -154,7 +154,6 @@ def gemm_rooflines(device, steps=20):
     lx = torch.randn(T, N2, generator=g).to(device=device, dtype=torch.bfloat16)
     ldw = torch.zeros(N1, N2, device=device)
     ldb = torch.zeros(N1, device=device)
-    Fn.ensure_scratch(device if device.index is not None else torch.device("cuda", torch.cuda.current_device()))
     Tm, Cm = PER_GPU_BATCH * (IMG_H // 4) * (IMG_W // 4), 96
     mx = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=torch.bfloat16)
     mdy = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=torch.bfloat16)

@@ -167,10 +167,6 @@ int conv3x3_nhwc_bf16(const void* x, const void* w, const float* bias, void* y, 
  * dbias (N1 | Cout) f32 += column sums of dy (the bias gradient), NULL to skip.
  * All outputs ACCUMULATE (the caller zeroes them, or passes the parameter's fp32 gradient buffer). */
 int wgrad_linear_bf16(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2, void* stream);
-/* swin_set_scratch: registers a caller-owned device buffer (current device) for the split-T partial tiles of the two
- *   weight-gradient entry points: with it they store partials plainly and reduce them in a second launch; without it they fall
- *   back to fp32 atomics (~4x lower byte rate).  Not part of the reference: autograd's accumulation has no counterpart. */
-int swin_set_scratch(void* ptr, int64_t bytes);
 int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W, int Cin,
                             int Cout, void* stream);
 

@@ -36,7 +36,6 @@ SIGNATURES = {
     "roi_align_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p],
     "conv3x3_nhwc_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "wgrad_linear_bf16": [_p, _p, _p, _p, _i64, _i, _i, _p],
-    "swin_set_scratch": [_p, _i64],
     "wgrad_conv3x3_nhwc_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "swin_nms_workspace_bytes": [_i64],
     "nms_sorted": [_p, _i64, _f, _i, _i, _p, _p, _p, _i, _p, _p],

@@ -35,18 +35,25 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, dev=False):
+    """dev=True (or SWIN_DEV_BUILD=1 in the environment): a -DSWIN_DEV build in lib/libswin_hip_dev.so -- the only build in which
+    the kernels' launchers read SWIN_* environment variables (geometry sweeps, A/B switches, ablation instantiations).  Select it
+    with SWIN_HIP_LIB=<path>; the shipped lib/libswin_hip.so never reads the environment."""
+    dev = dev or os.environ.get("SWIN_DEV_BUILD") == "1"
     hipcc = _hipcc()
-    os.makedirs(os.path.join(LIBDIR, "obj"), exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj_dev" if dev else "obj")
+    lib_path = os.path.join(LIBDIR, "libswin_hip_dev.so") if dev else LIB
+    flags = FLAGS + (["-DSWIN_DEV"] if dev else [])
+    os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     jobs = []
     objs = []
     for s in srcs:
-        o = os.path.join(LIBDIR, "obj", os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o])
+            jobs.append([hipcc] + flags + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -58,13 +65,13 @@ def build_library(force=False, verbose=False):
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _newer(LIB, objs):
+    if jobs or force or _newer(lib_path, objs):
         rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib")
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs +
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs +
             [f"-L{rocm_lib}", "-lhipblaslt", f"-Wl,-rpath,{rocm_lib}"])     # gemm_lt.hip: plain GEMMs on hipBLASLt
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
     import sys
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

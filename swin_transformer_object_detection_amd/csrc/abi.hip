@@ -103,7 +103,7 @@ extern "C" int swin_stream_create_low_priority(void** out) {
     hipStream_t s = nullptr;
     // experiment (SWIN_SIDE_CU_DROP=D): a stream that may not use every D-th CU instead of a low-priority one -- priorities do not
     // preempt, so a short kernel of the main stream otherwise waits for CUs behind 40-140 us weight-gradient workgroups
-    static const int drop = getenv("SWIN_SIDE_CU_DROP") ? atoi(getenv("SWIN_SIDE_CU_DROP")) : 0;
+    static const int drop = swin_dev_int("SWIN_SIDE_CU_DROP", 0);
     if (drop >= 2) {
         uint32_t mask[16];
         for (int w = 0; w < 16; ++w) {

@@ -83,7 +83,7 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     // work then overlaps the NEXT block's data-gradient chain instead of this one's.
     void* const side = const_cast<void*>(p[55]);
     void* const wst = side ? side : stream;
-    static const bool aux_on = !(getenv("SWIN_AUX_REDUCE") && atoi(getenv("SWIN_AUX_REDUCE")) == 0);      // development A/B
+    static const bool aux_on = swin_dev_int("SWIN_AUX_REDUCE", 1) != 0;      // development A/B (-DSWIN_DEV builds only)
     AuxScope aux(side && aux_on ? side : nullptr);
     const int B = (int)iv[0], H = (int)iv[1], W = (int)iv[2], C = (int)iv[3], nH = (int)iv[4], shift = (int)iv[5];
     const float scale = fv[0];

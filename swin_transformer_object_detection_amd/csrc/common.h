@@ -15,6 +15,16 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define WAVE 64
 
+// Development switches (launch-geometry sweeps, A/B toggles, ablations): the environment is read ONLY in a -DSWIN_DEV build
+// (SWIN_DEV_BUILD=1 python -m swin_transformer_object_detection_amd.build; tools/microbench.py).  The shipped library takes
+// the default and never looks at the environment, so a stray variable cannot change what a training process computes.
+#ifdef SWIN_DEV
+#include <cstdlib>
+static inline int swin_dev_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline constexpr int swin_dev_int(const char*, int dflt) { return dflt; }
+#endif
+
 static inline int swin_launch_status() {
     return hipGetLastError() == hipSuccess ? SWIN_OK : SWIN_ERR_LAUNCH;
 }

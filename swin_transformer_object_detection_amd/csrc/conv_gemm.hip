@@ -351,202 +351,6 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// 256 x 256 tile, 8 waves (2 x 4: 128 pixels x 64 output channels each), K-tile 64, FOUR phases per K-tile (round 2).
-// The 128^2 kernel above reads every operand byte from LDS once per 64 flops and drains its DMA at every K-step; its ceiling is
-// ~0.36 of the MFMA peak (guide, "the step-3 structure").  Here a wave's 128 x 64 output is walked as four quadrants (64 px x 32
-// cout, 16 MFMA 16x16x32 each); the fragments a quadrant needs are read right before it (phase 1: W-lo + A-lo, 2: W-hi, 3: A-hi,
-// 4: none), so every LDS half-tile is read in ONE known phase and can be restaged by LDS-DMA two phases later while the other
-// buffer is consumed: 128 KB of LDS hold two K-tiles but the prefetch runs 4-5 phases ahead, and the only DMA wait is a counted
-// `vmcnt(4)` per K-tile (never 0 inside the loop).  Every phase is two sections -- fragment reads (+ DMA issue), then 16 MFMAs at
-// raised priority -- with a raw barrier after each, and the two pixel-half wave groups run one section apart (see the loop).
-// Shapes: M % 256 == 0, Nn % 256 == 0, K % 64 == 0 (the FPN / RPN convs at P2 and the mask-head convs).
-// ---------------------------------------------------------------------------------------------------------------------------
-template <bool RELU>
-__global__ __launch_bounds__(512) void conv256_kernel(ConvA A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
-                                                      bf16* __restrict__ C, int64_t M, int Nn, int K, int mtiles, int ntiles,
-                                                      const bf16* __restrict__ gate, int stag, int abl) {
-    extern __shared__ __attribute__((aligned(16))) uint4 lds_raw[];      // [buf 2][A 256 rows | W 256 rows][8 slots]
-    const int nblk = mtiles * ntiles;
-    int id = blockIdx.x;
-    {
-        int q = nblk / 8, r = nblk % 8, xcd = id % 8;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
-    }
-    const int mt_ = id / ntiles, nt_ = id - mt_ * ntiles;
-    const int64_t m0 = (int64_t)mt_ * 256;
-    const int n0 = nt_ * 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;                   // wave -> pixels [128 wr, +128), cout [64 wc, +64)
-    const int fr = lane & 15, fq = lane >> 4;
-    auto ldsA = [&](int buf) { return lds_raw + (size_t)buf * 4096; };            // 256 rows x 8 slots
-    auto ldsW = [&](int buf) { return lds_raw + (size_t)buf * 4096 + 2048; };
-
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const uint64_t zero64 = (uint64_t)reinterpret_cast<uintptr_t>(g_zero16);
-    // DMA role: per half-tile (128 rows) wave w fills rows [16 w, 16 w + 16) with two instructions of 8 rows x 8 slots
-    uint64_t aptr[4], wptr[4]; unsigned amask[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                              // j = 2 * half + i
-        const int row = 128 * (j >> 1) + 16 * wave + 8 * (j & 1) + (lane >> 3);
-        const int piece = (lane & 7) ^ ((row >> 1) & 7);
-        int64_t base; int y, x;
-        A.prep(m0 + row, base, y, x);
-        amask[j] = A.tapmask(base, y, x);
-        aptr[j] = (uint64_t)reinterpret_cast<uintptr_t>(A.a + (base < 0 ? 0 : base) + piece * 8);
-        wptr[j] = (uint64_t)reinterpret_cast<uintptr_t>(Wt + (int64_t)(n0 + row) * K + piece * 8);
-    }
-    const int nk = K / BK;
-    auto dma_w = [&](int kt, int buf) {                        // both W halves of K-tile kt: 4 instructions per wave
-        const uint64_t wbytes = (uint64_t)kt * BK * 2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            glds16(wptr[j] + wbytes, (unsigned)(uintptr_t)(lptr_t)(ldsW(buf) + (128 * (j >> 1) + 16 * wave + 8 * (j & 1)) * 8));
-    };
-    auto dma_a = [&](int kt, int buf) {                        // both A halves
-        int64_t koff; int tap;
-        A.kinfo(kt, koff, tap);
-        const uint64_t abytes = (uint64_t)(koff * 2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint64_t src = ((amask[j] >> tap) & 1u) ? aptr[j] + abytes : zero64;
-            glds16(src, (unsigned)(uintptr_t)(lptr_t)(ldsA(buf) + (128 * (j >> 1) + 16 * wave + 8 * (j & 1)) * 8));
-        }
-    };
-    f32x4 acc[4][8];                                           // [cout tile][pixel tile]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0};
-    bf16x8 wf[4][2], af[4][2];                                 // W: [cout tile 0..3][k-step]; A: current pixel half [tile][k-step]
-    auto read_w = [&](const uint4* Ws, int nh) {               // cout tiles 2 nh, 2 nh + 1 of this wave
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int row = 64 * wc + 16 * (2 * nh + t) + fr;
-                const uint4 u = Ws[row * 8 + swz(row, 4 * s + fq)];
-                wf[2 * nh + t][s] = *(const bf16x8*)&u;
-            }
-    };
-    auto read_a = [&](const uint4* As, int mh) {               // pixel tiles 4 mh .. 4 mh + 3 of this wave
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int row = 128 * wr + 16 * (4 * mh + t) + fr;
-                const uint4 u = As[row * 8 + swz(row, 4 * s + fq)];
-                af[t][s] = *(const bf16x8*)&u;
-            }
-    };
-    auto quad = [&](int nh, int mh) {                          // 16 MFMAs: 2 cout tiles x 4 pixel tiles x 2 k-steps
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    acc[2 * nh + t][4 * mh + m] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * nh + t][s], af[m][s], acc[2 * nh + t][4 * mh + m], 0, 0, 0);
-    };
-
-    // prologue: tiles 0 and 1 in flight (issue order W0 A0 W1 A1, 4 instructions per wave each); tile 0 has landed at vmcnt(8)
-    dma_w(0, 0); dma_a(0, 0);
-    if (nk > 1) { dma_w(1, 1); dma_a(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // Two wave groups (pixel halves wr = 0 / 1: one wave of each per SIMD) run the same sequence of sections -- R: DMA issue +
-    // fragment reads, M: 16 MFMAs -- separated by barriers, group 1 ONE SECTION BEHIND group 0: while one wave of a SIMD computes,
-    // the other reads.  Consequences for the hazards (guide: "one barrier more when two wave groups run staggered"):
-    //   WAR  a half-tile read in phase p (by group 1 one section later) is restaged no earlier than phase p + 2:
-    //        W halves (read in phases 1, 2) in phase 4, A halves (read in phases 1, 3) in phase 1 of the NEXT tile;
-    //   RAW  tile kt+1 is first read in the R section of its phase 1; the counted wait that retires it stands at the end of BOTH
-    //        sections of tile kt's phase 4 (group 0 passes it one section before its read, group 1 two), behind it only the four
-    //        W(kt+2) instructions issued in that phase may be outstanding.
-    __builtin_amdgcn_s_barrier();                              // tile 0: every wave's part has landed (its vmcnt above) -> visible to all
-    const int grp = stag == 1 ? (wave >> 2) : stag == 2 ? (wave & 1) : stag == 3 ? ((wave >> 1) & 1) : -1;     // -1: no stagger
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-#define SECTION_END() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define MFMA_SECTION(nh, mh) do { __builtin_amdgcn_s_setprio(1); if (!(abl & 2)) quad(nh, mh); else { asm volatile("" :: "v"(wf[0][0]), "v"(af[0][0]), "v"(wf[3][1]), "v"(af[3][1])); } __builtin_amdgcn_s_setprio(0); } while (0)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const uint4* As = ldsA(buf);
-        const uint4* Ws = ldsW(buf);
-        const bool more_w = kt + 2 < nk;
-        // ---- phase 1
-        if (kt >= 1 && kt + 1 < nk && !(abl & 1)) dma_a(kt + 1, buf ^ 1);    // A halves of the other buffer: last read in phase 3 of tile kt-1
-        read_w(Ws, 0); read_a(As, 0);
-        SECTION_END();
-        MFMA_SECTION(0, 0);
-        SECTION_END();
-        // ---- phase 2
-        read_w(Ws, 1);
-        SECTION_END();
-        MFMA_SECTION(1, 0);
-        SECTION_END();
-        // ---- phase 3
-        read_a(As, 1);
-        SECTION_END();
-        MFMA_SECTION(1, 1);
-        SECTION_END();
-        // ---- phase 4
-        if (more_w && !(abl & 1)) dma_w(kt + 2, buf);                        // W halves of this buffer: last read in phase 2
-        if (more_w) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SECTION_END();
-        MFMA_SECTION(0, 1);
-        if (more_w) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SECTION_END();
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-#undef SECTION_END
-#undef MFMA_SECTION
-
-    // epilogue: lane = pixel (fr), registers = 4 consecutive output channels (4 fq + j)
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        const int64_t m = m0 + 128 * wr + 16 * mt + fr;
-        if (m >= M) continue;
-        bf16* crow = C + m * Nn;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + 64 * wc + 16 * nt + 4 * fq;
-            if (n >= Nn) continue;
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = acc[nt][mt][e] + (bias ? bias[n + e] : 0.f);
-                if (RELU) v = fmaxf(v, 0.f);
-                o[e] = (bf16)v;
-            }
-            if (gate) {
-                const bf16x4 gt = *(const bf16x4*)(gate + m * Nn + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (!((float)gt[e] > 0.f)) o[e] = (bf16)0.f;
-            }
-            *(bf16x4*)(crow + n) = o;
-        }
-    }
-}
-
-template <bool RELU>
-static int conv256_launch(ConvA A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, hipStream_t s,
-                          const bf16* gate) {
-    const size_t lds_bytes = 2 * 4096 * sizeof(uint4);        // 128 KB
-    static bool attr_set[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
-    if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)conv256_kernel<RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return SWIN_ERR_LAUNCH;
-        attr_set[dev] = true;
-    }
-    const int mtiles = (int)(M / 256), ntiles = Nn / 256;
-    static const int stag = getenv("SWIN_CONV_STAG") ? atoi(getenv("SWIN_CONV_STAG")) : 1;      // development: wave-group stagger
-    static const int abl = getenv("SWIN_CONV_ABL") ? atoi(getenv("SWIN_CONV_ABL")) : 0;          // development: ablations (wrong results)
-    conv256_kernel<RELU><<<mtiles * ntiles, 512, lds_bytes, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles, gate, stag, abl);
-    return swin_launch_status();
-}
-
 // Second half of a split-K launch: C = bf16(relu?(sum over slabs + bias)), zeroed where gate is not positive.  One thread per four
 // consecutive output channels of a pixel (Nn % 4 == 0).
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, int64_t MN, int Nn,
@@ -580,7 +384,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 // P6 40 -> 11.3 + 4.3 us.  P4 (126 tiles) with two ranges: 41 -> 31.4 + 5.6 us and 32 MB of slab traffic -- not worth a second
 // launch, hence the 64-tile limit.  A range costs ~9 us whatever its length (launch, per-lane border masks, first DMA latency).
 static int conv_ksplit(int64_t M, int Nn, int K) {
-    static const int off = getenv("SWIN_CONV_KSPLIT") ? atoi(getenv("SWIN_CONV_KSPLIT")) : -1;    // 0 / 1: never split; n > 1: forced
+    static const int off = swin_dev_int("SWIN_CONV_KSPLIT", -1);    // 0 / 1: never split; n > 1: forced
     const int64_t blocks = ((M + 127) / 128) * ((Nn + BN - 1) / BN);
     const int nk = K / BK;
     if (off == 0 || off == 1 || blocks > (off > 1 ? 128 : 64) || Nn % 4 != 0) return 1;
@@ -622,26 +426,15 @@ template <typename ALoader>
 static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, int64_t M, int Nn, int K, int relu, hipStream_t s,
                        const bf16* gate = nullptr, float* part = nullptr, int64_t part_bytes = 0) {
     static bool env_read = false;
-    if (!env_read) { const char* e = getenv("SWIN_CONV_WM"); if (e) g_conv_wm = atoi(e); env_read = true; }
-    if constexpr (std::is_same<ALoader, ConvA>::value) {
-        // 256 x 256 four-phase schedule: whole 256-row / 256-column tiles and at least ~3/4 of the CUs busy in one round.
-        // OFF by default (SWIN_CONV_256=1 enables it): correct (the P2 parity test passes with it), 185 us against 192 us at P2 in
-        // isolation, but no gain inside the training step (11.85 / 11.87 ms with, 11.70 / 12.00 without) -- it takes a whole CU's
-        // LDS, so nothing from the weight-gradient stream can share that CU.  Ablations on one box (P2, 196 us in full): without the
-        // in-loop DMA 153 us, without the MFMAs 127 us, without both 89 us -- reads + barriers, DMA issue and MFMAs still ADD UP
-        // instead of overlapping.
-        static const int c256 = getenv("SWIN_CONV_256") ? atoi(getenv("SWIN_CONV_256")) : 0;
-        if (c256 && M % 256 == 0 && Nn % 256 == 0 && K % BK == 0 && (M / 256) * (Nn / 256) >= 160) {
-            if (relu) return conv256_launch<true>(A, Wt, bias, C, M, Nn, K, s, gate);
-            return conv256_launch<false>(A, Wt, bias, C, M, Nn, K, s, gate);
-        }
-    }
+    if (!env_read) { g_conv_wm = swin_dev_int("SWIN_CONV_WM", 0); env_read = true; }
+    // (A 256 x 256 four-phase kernel with hand-placed LDS-DMA existed in round 2: 185 us against 192 us at P2 in isolation, no gain
+    // inside the training step -- DESIGN section 9.2; removed in round 3, git history has it.)
     // large pixel counts: the 256-row tile (one 8-wave block per CU); otherwise the 128-row tile keeps the grid full
     const int64_t blocks128 = ((M + 127) / 128) * ((Nn + BN - 1) / BN);
     // the 256-row tile (8 waves, one block per CU, two buffers): for maps of 257..512 128-row tiles (P3 of the bench batch: 250 blocks
     // of 256 rows = one per CU): 56.6 us against 61-66 alone, 72 against 87 us inside the step (kernel trace); SWIN_CONV_MID=0
     // turns it off.  Everywhere else it measured no better than the 128-row tile.
-    static const int mid = getenv("SWIN_CONV_MID") ? atoi(getenv("SWIN_CONV_MID")) : 1;
+    static const int mid = swin_dev_int("SWIN_CONV_MID", 1);
     const bool big = g_conv_wm == 4 || (g_conv_wm == 0 && mid && blocks128 > 256 && blocks128 <= 512);
     if (big) {
         if (relu) return gemm_launch_wm<ALoader, true, 4, 2>(A, Wt, bias, C, M, Nn, K, s, gate);

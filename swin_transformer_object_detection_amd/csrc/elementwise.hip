@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_cols_kernel(const T* __rest
 static inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 static int gelu_cap() {                                     // SWIN_GELU_BLOCKS: development sweep (default 2048)
-    static const int n = getenv("SWIN_GELU_BLOCKS") ? atoi(getenv("SWIN_GELU_BLOCKS")) : 2048;
+    static const int n = swin_dev_int("SWIN_GELU_BLOCKS", 2048);
     return n < 1 ? 1 : n;
 }
 

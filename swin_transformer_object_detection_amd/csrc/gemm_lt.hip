@@ -43,7 +43,7 @@ const size_t kWorkspace = 32u << 20;
 // shape, during warm-up; SWIN_GEMM_TUNE=0 keeps the heuristic's first choice.
 static const int kMaxCandidates = 64;
 static int candidates() {                                    // SWIN_GEMM_CANDIDATES: development sweep (default 12)
-    static const int n = getenv("SWIN_GEMM_CANDIDATES") ? atoi(getenv("SWIN_GEMM_CANDIDATES")) : 12;
+    static const int n = swin_dev_int("SWIN_GEMM_CANDIDATES", 12);
     return n < 1 ? 1 : (n > kMaxCandidates ? kMaxCandidates : n);
 }
 
@@ -110,7 +110,7 @@ Plan* get_plan(int64_t M, int N, int K, int layout, int bias, const void* a = nu
         hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &dummy, sizeof(dummy));
     }
     hipblasLtMatmulHeuristicResult_t cand[kMaxCandidates];
-    static const bool tune = !(getenv("SWIN_GEMM_TUNE") && getenv("SWIN_GEMM_TUNE")[0] == '0');
+    static const bool tune = swin_dev_int("SWIN_GEMM_TUNE", 1) != 0;
     const int want = (tune && a && b && c && workspace) ? candidates() : 1;
     hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.c, pref, want, cand, &found);
     hipblasLtMatmulPreferenceDestroy(pref);

@@ -59,7 +59,7 @@ template <typename T> static LnLaunch ln_plan(int64_t rows, int C) {
     for (int a : allowed) if (a >= NV) { nv2 = a; break; }
     LnLaunch p; p.G = G; p.NV = nv2; p.rows_per_block = 256 / G;
     int64_t nb = (rows + p.rows_per_block - 1) / p.rows_per_block;
-    static const int cap = getenv("SWIN_LN_BLOCKS") ? atoi(getenv("SWIN_LN_BLOCKS")) : 2048;      // development sweep
+    static const int cap = swin_dev_int("SWIN_LN_BLOCKS", 2048);      // development sweep
     p.blocks = (int)(nb < cap ? nb : cap);
     return p;
 }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
 }
 
 static int ln_bwd_cap() {                                   // SWIN_LN_BWD_BLOCKS: development sweep; 768: 33.3 -> 29.9 us at stage 1 vs 512
-    static const int n = getenv("SWIN_LN_BWD_BLOCKS") ? atoi(getenv("SWIN_LN_BWD_BLOCKS")) : 768;
+    static const int n = swin_dev_int("SWIN_LN_BWD_BLOCKS", 768);
     return n < 1 ? 1 : n;
 }
 template <typename T> static int ln_bwd_blocks(int64_t rows, int C) {

@@ -396,7 +396,8 @@ extern "C" int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1,
     hipStream_t s = (hipStream_t)stream;
     switch (C) {
         case 96: {
-            static const int abl = getenv("SWIN_MLP_ABL") ? atoi(getenv("SWIN_MLP_ABL")) : 0;     // development ablations
+#ifdef SWIN_DEV      // ablation instantiations (some compute WRONG results on purpose): development builds only
+            static const int abl = swin_dev_int("SWIN_MLP_ABL", 0);     // development ablations
             if (abl == 1) return launch_fwd<96, 8, 128, 2, 1>(x, w1, b1, w2, b2, y, T, s);
             if (abl == 2) return launch_fwd<96, 4, 128, 1, 0>(x, w1, b1, w2, b2, y, T, s);
             if (abl == 3) return launch_fwd<96, 4, 64, 1, 0>(x, w1, b1, w2, b2, y, T, s);
@@ -407,6 +408,7 @@ extern "C" int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1,
             if (abl == 4) return launch_fwd<96, 4, 32, 3, 0>(x, w1, b1, w2, b2, y, T, s);
             if (abl == 5) return launch_fwd<96, 4, 32, 4, 0>(x, w1, b1, w2, b2, y, T, s);
             if (abl == 6) return launch_fwd<96, 4, 32, 2, 0>(x, w1, b1, w2, b2, y, T, s);
+#endif
             return launch_fwd<96, 8, 128, 2>(x, w1, b1, w2, b2, y, T, s);
         }
         case 192: return launch_fwd<192, 4, 64, 1>(x, w1, b1, w2, b2, y, T, s);

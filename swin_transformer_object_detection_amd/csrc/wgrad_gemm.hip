@@ -77,7 +77,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t0, int col0, in
 template <typename XLoader, int WKG>
 __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(const bf16* __restrict__ dy, XLoader X, float* __restrict__ dw,
                                                          float* __restrict__ dbias, int64_t T, int N1, int N2,
-                                                         int64_t t_per_split, int mode, float* __restrict__ slab, int g2, int g1,
+                                                         int64_t t_per_split, int mode, int g2, int g1,
                                                          int splits) {
     extern __shared__ __attribute__((aligned(16))) bf16 lds_all[];         // [WKG][dY|X][WT * WROW]: 40 KB per group
     // XCD-aware block -> (tile, split) map.  Hardware deals consecutive block ids round-robin over the 8 XCDs (private L2s).
@@ -244,20 +244,8 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
     if (grp != 0) return;
     // D[row n1][col n2]: lane = n2 column, registers = n1 rows -> 32 consecutive n2 per half-wave: 128-B segments.
     // mode 0: this block owns the tile (one split): plain read-modify-write.  mode 1: contiguous fp32 atomics.
-    // mode 2: the whole 128x128 partial tile goes to this split's slab with plain stores; wgrad_reduce_kernel adds the slabs
-    // into dw (float atomics run at ~1.3 TB/s chip-wide against ~6 TB/s for stores: blocks x 64 KB of atomics were 20 of the
-    // 38 us of a stage-3 Linear weight gradient and 33 of 275 us of the P2 conv weight gradient).
-    if (mode == 2) {
-        float* tile = slab + (((int64_t)bz * (g2 > 0 ? g1 : (int)gridDim.y) + by) * (g2 > 0 ? g2 : (int)gridDim.x) + bx) * (WN * WN);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    tile[(w1 * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h) * WN + w2 * 64 + 32 * j + c] = acc[i][j][reg];
-        return;
-    }
+    // (A third form -- plain-stored partial slabs + a reduce launch -- measured slower on every shape, round 2,
+    // profiles/r02_wgrad_modes.txt: the atomics overlap the other resident blocks' MFMAs, a reduce launch does not.)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -274,30 +262,6 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
             }
         }
 }
-
-// dw[n1][n2] += sum over splits of the slab tiles written by wgrad_kernel (mode 2).  grid (g2, g1, 8): a block takes 16 rows
-// of a 128x128 tile; consecutive threads read consecutive columns of every slab (coalesced) and own their dw elements.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int N1, int N2,
-                                                           int splits) {
-    const int64_t tiles = (int64_t)gridDim.x * gridDim.y;
-    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const int n1_0 = blockIdx.y * WN, n2_0 = blockIdx.x * WN;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int idx = blockIdx.z * 2048 + k * 256 + threadIdx.x;
-        const int r = idx >> 7, cc = idx & 127;
-        const int n1 = n1_0 + r, n2 = n2_0 + cc;
-        if (n1 >= N1 || n2 >= N2) continue;
-        const float* sp = slab + tile * (WN * WN) + idx;
-        float a = 0.f;
-        for (int z = 0; z < splits; ++z) a += sp[(int64_t)z * tiles * (WN * WN)];
-        dw[(int64_t)n1 * N2 + n2] += a;
-    }
-}
-
-// Scratch for the split partials, registered once per device by the host (swin_set_scratch): no allocation in the launch path.
-static void* g_scratch[16] = {};
-static int64_t g_scratch_bytes[16] = {};
 
 template <typename XLoader> static inline void set_stage_step(XLoader&, int) {}
 template <> inline void set_stage_step<ConvX>(ConvX& X, int dt) { X.qd = dt / X.W; X.rd = dt % X.W; }
@@ -325,7 +289,7 @@ static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, i
     // blocks to aim for: 512 wave-quads for the two-k-group form (256 blocks of 8 waves); 384 for the many-tile form,
     // of the Linear layers, where fewer splits (less atomic traffic) outweigh the fuller chip (47 -> 42 us at 1536x384;
     // the conv form, 36 big-K tiles, prefers the 512: 303 vs 340 us at P2)
-    static const int forced = getenv("SWIN_WGRAD_BLOCKS") ? atoi(getenv("SWIN_WGRAD_BLOCKS")) : 0;      // development sweep
+    static const int forced = swin_dev_int("SWIN_WGRAD_BLOCKS", 0);      // development sweep
     // ConvX (36 tiles): swept again with the overlapped loads -- 640 blocks for the long contractions (P2 291 -> 275 us, mask
     // head convs 112 -> 104 us), 384 for the short ones (T < 24000: P4 42 -> 40 us)
     const int many = XLoader::kBlocksManyTiles == 512 ? (T >= 24000 ? 640 : 384) : XLoader::kBlocksManyTiles;
@@ -335,7 +299,7 @@ static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, i
     if (splits > max_splits) splits = (int)max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
-    static const int xcd_map = getenv("SWIN_WGRAD_XCD") ? atoi(getenv("SWIN_WGRAD_XCD")) : 1;           // development A/B
+    static const int xcd_map = swin_dev_int("SWIN_WGRAD_XCD", 1);           // development A/B
     // the XCD-aware map below keeps a split's tiles on one XCD: it needs the splits to spread evenly over the 8 XCDs
     // measured (profiles/r02_wgrad_modes.txt): +7 % on the P2 conv weight gradient (36 tiles x 16 splits), neutral to negative on the
     // Linear shapes (few tiles or short t ranges: there balance over the CUs matters more than L2 reuse) -> conv, long t only
@@ -352,23 +316,13 @@ static int wgrad_launch_kg(const bf16* dy, XLoader X, float* dw, float* dbias, i
     dim3 grid(g2, g1, splits);
     int dev = 0;
     hipGetDevice(&dev);
-    static const int force_mode = getenv("SWIN_WGRAD_MODE") ? atoi(getenv("SWIN_WGRAD_MODE")) : -1;      // development A/B
-    const int64_t slab_bytes = (int64_t)splits * g1 * g2 * WN * WN * (int64_t)sizeof(float);
-    // Measured on MI355X (tools/microbench.py wgrad, profiles/r02_wgrad_modes.txt): the fp32 atomics of the split partials are
-    // fire-and-forget and overlap the other blocks' MFMAs -- 36-40 us per backbone Linear and 272 us for the P2 conv against
-    // 54-195 us / 295 us with slabs + reduce launch, and 80 vs 88 us for the one-split read-modify-write.  The byte-rate model
-    // (1.3 TB/s of atomics) overstates their cost here, so atomics stay the default; SWIN_WGRAD_MODE=2 selects the slab form.
-    int mode = 1;
-    if (force_mode == 2 && dev >= 0 && dev < 16 && g_scratch[dev] && g_scratch_bytes[dev] >= slab_bytes) mode = 2;
-    if (force_mode == 0 && splits == 1) mode = 0;
-    float* slab = mode == 2 ? (float*)g_scratch[dev] : nullptr;
+    const int mode = 1;            // contiguous fp32 atomics (mode 0, plain read-modify-write for one-split shapes, measured slower: 88 vs 80 us)
     if (use_xcd && splits % 8 == 0) {
         const unsigned nblk = 8u * (unsigned)(g1 * g2) * (unsigned)((splits + 7) / 8);
-        wgrad_kernel<XLoader, WKG><<<nblk, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, mode, slab, g2, g1, splits);
+        wgrad_kernel<XLoader, WKG><<<nblk, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, mode, g2, g1, splits);
     } else {
-        wgrad_kernel<XLoader, WKG><<<grid, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, mode, slab, 0, g1, splits);
+        wgrad_kernel<XLoader, WKG><<<grid, 256 * WKG, lds_bytes, s>>>(dy, X, dw, dbias, T, N1, N2, per, mode, 0, g1, splits);
     }
-    if (mode == 2) wgrad_reduce_kernel<<<dim3(g2, g1, 8), 256, 0, s>>>(slab, dw, N1, N2, splits);
     return swin_launch_status();
 }
 
@@ -377,7 +331,7 @@ static int wgrad_launch(const bf16* dy, XLoader X, float* dw, float* dbias, int6
     // few output tiles and a long t axis: the split-T atomics dominate -> two k-groups per block (half the atomic bytes);
     // many tiles: two independent 4-wave blocks per CU overlap each other's barriers better
     const int tiles = ((N1 + WN - 1) / WN) * ((N2 + WN - 1) / WN);
-    static const int kg2_tiles = getenv("SWIN_WGRAD_KG2_TILES") ? atoi(getenv("SWIN_WGRAD_KG2_TILES")) : 16;      // development sweep
+    static const int kg2_tiles = swin_dev_int("SWIN_WGRAD_KG2_TILES", 16);      // development sweep
     if (tiles <= kg2_tiles) return wgrad_launch_kg<XLoader, 2>(dy, X, dw, dbias, T, N1, N2, s);
     return wgrad_launch_kg<XLoader, 1>(dy, X, dw, dbias, T, N1, N2, s);
 }
@@ -400,15 +354,4 @@ extern "C" int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw,
     int64_t T = (int64_t)N * H * W;
     ConvX X{(const bf16*)x, T, H, W, Cin, 0, 0};
     return wgrad_launch((const bf16*)dy, X, dw, dbias, T, Cout, 9 * Cin, (hipStream_t)stream);
-}
-
-// Register a device scratch buffer (>= a few tens of MB) for the current device: the weight-gradient kernels then write
-// their split-T partial tiles there with plain stores and reduce them in a second launch instead of using float atomics.
-// The buffer must outlive every later call; contents never outlive one call on one stream.  NULL / 0 unregisters.
-extern "C" int swin_set_scratch(void* ptr, int64_t bytes) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
-    g_scratch[dev] = ptr;
-    g_scratch_bytes[dev] = ptr ? bytes : 0;
-    return SWIN_OK;
 }

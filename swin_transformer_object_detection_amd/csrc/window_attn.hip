@@ -520,343 +520,12 @@ __device__ __forceinline__ bf16x8 lds_tr_frag_lin(const bf16* tile, int row0, in
     return f;
 }
 
-struct BwdLds {
-    bf16 t[4][TILE][LROW];     // Q, K, V, dO head slices
-    bf16 p[TILE][PROW];        // P        [query][key]
-    bf16 ds[TILE][PROW];       // scale*dS [query][key]
-    float padacc[3 * HD + 32]; // gradient reaching qkv.bias through this wave's padded tokens (q|k|v x 32), padded to 16 B
-};
 #define SLAB (TILE * TILE + 3 * HD + 32)   // floats per wave in the workspace: dbias tile + pad-token bias gradient
 
-struct BwdLane {
-    int lane, c, h, tokr, which, part;
-    unsigned ld_off[13];       // interior path: element offset of staged piece i (qkv stride 3C or dout stride C)
-    unsigned st_off[2];        // interior path: element offset (x 3C) of this lane's token per token tile
-};
-
-template <bool INTERIOR>
-__device__ __forceinline__ void bwd_issue_loads(bf16x8 (&stg)[13], const BwdLane& L, const WinGeom& g, const bf16* __restrict__ qkv,
-                                                const bf16* __restrict__ dout, const float* __restrict__ qkv_bias, int head,
-                                                int b, int wr, int wc) {
-    const int C3 = 3 * g.C;
-    const bool is_do = L.which == 3;
-    const int ch = is_do ? head * HD + L.part * 8 : L.which * g.C + head * HD + L.part * 8;
-    if (INTERIOR) {
-        const size_t wbase = (size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift;
-        const bf16* pb = is_do ? dout + wbase * g.C + ch : qkv + wbase * C3 + ch;
-#pragma unroll
-        for (int i = 0; i < 13; ++i) stg[i] = *(const bf16x8*)(pb + L.ld_off[i]);    // unpredicated: see fwd_issue_loads
-    } else {
-        // general path (windows touching the wrap-around or the padding): padded tokens read qkv.bias (their q|k|v)
-        // or zero (dO of a cropped row).  Loads go to a clamped address and are fixed up by VALUE.
-        bf16x8 padv;
-        if (is_do) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) padv[e] = (bf16)0.f;
-        } else padv = bias_to_bf16x8(qkv_bias + ch);
-        const bf16* pb = is_do ? dout + ch : qkv + ch;
-        const int stride = is_do ? g.C : C3;
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            int t = 4 * i + L.tokr; if (t >= NTOK) t = NTOK - 1;
-            const int src = token_src(g, b, wr, wc, t);
-            const bf16x8 v = *(const bf16x8*)(pb + (size_t)(src >= 0 ? src : 0) * stride);
-            stg[i] = src >= 0 ? v : padv;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(
-    const bf16* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_exp,
-    const float* __restrict__ lse, const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
-    float* __restrict__ dbias_ws, float* __restrict__ dbias_pad, WinGeom g, float scale, int n_tasks) {
-    // dbias_ws: one (64,64) fp32 slab per persistent wave, fully written (plain stores) and summed per head by
-    // dbias_slab_reduce_kernel -- hundreds of waves adding into the same 2401 addresses with atomics serialise
-    // at the memory side (measured: 0.9 ms per launch, almost all of it the final atomic flush)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    BwdLds* Lm = reinterpret_cast<BwdLds*>(smem_raw) + wave;
-    BwdLane L;
-    L.lane = threadIdx.x & 63; L.c = L.lane & 31; L.h = L.lane >> 5;
-    const int lane = L.lane, c = L.c, h = L.h;
-    bf16(*Qs)[LROW] = Lm->t[0];
-    bf16(*Ks)[LROW] = Lm->t[1];
-    bf16(*Vs)[LROW] = Lm->t[2];
-    bf16(*Ds)[LROW] = Lm->t[3];
-    {
-        uint4 z = {0, 0, 0, 0};
-        uint4* p = (uint4*)Lm;
-        for (int i = lane; i < (int)(sizeof(BwdLds) / 16); i += WAVE) p[i] = z;
-    }
-    const int n_waves = gridDim.x * 4;
-    int task = blockIdx.x * 4 + wave;
-    float* const slab = dbias_ws + (size_t)task * SLAB;
-    if (task >= n_tasks) {                      // idle wave: its slab must still read as zero
-        for (int i = lane; i < SLAB; i += WAVE) slab[i] = 0.f;
-        return;
-    }
-    const int head = task % g.nH;
-    const int C3 = 3 * g.C;
-
-    float biasr[2][2][16], dbacc[2][2][16];
-    {
-        const float* bp = bias_exp + (size_t)head * TILE * TILE;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    biasr[kt][qt][reg] = bp[key * TILE + 32 * qt + c] * LOG2E;
-                    dbacc[kt][qt][reg] = 0.f;
-                }
-    }
-    uint64_t mrow = 0, mcol = 0;
-    if (g.shift > 0) lane_mask_bits(lane, mrow, mcol);
-    const float sl2 = scale * LOG2E;
-
-    // staging: 4 tokens per round, 16 pieces per token (q|k|v|dO x 4 pieces of 16 B)
-    L.tokr = lane >> 4;
-    L.which = (lane & 15) >> 2; L.part = lane & 3;
-    {
-        const int stride = L.which == 3 ? g.C : C3;
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            int t = 4 * i + L.tokr; if (t >= NTOK) t = NTOK - 1;
-            L.ld_off[i] = (unsigned)(((t / 7) * g.W + (t % 7)) * stride);
-        }
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            int q = 32 * tt + c; if (q >= NTOK) q = NTOK - 1;
-            L.st_off[tt] = (unsigned)(((q / 7) * g.W + (q % 7)) * C3);
-        }
-    }
-    const int which = L.which, part = L.part, tokr = L.tokr;
-
-    WinPos cur = win_decode(g, task / g.nH);
-    WinStride stride;
-    {
-        const WinPos d = win_decode(g, n_waves / g.nH);          // n_waves % nH == 0
-        stride.db = d.b; stride.dwr = d.wr; stride.dwc = d.wc;
-    }
-    WinPos nxt = cur;
-    win_advance(nxt, stride, g);
-
-    bf16x8 stg[13];
-    float lse_n[2];
-    {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int q = 32 * qt + c;
-            lse_n[qt] = lse[(size_t)task * TILE + (q < NTOK ? q : 0)];
-        }
-        if (win_interior(g, cur)) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, cur.b, cur.wr, cur.wc);
-        else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, cur.b, cur.wr, cur.wc);
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    for (; task < n_tasks; task += n_waves, cur = nxt, win_advance(nxt, stride, g)) {
-        const int b = cur.b, wr = cur.wr, wc = cur.wc;
-        const bool interior = win_interior(g, cur);
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            int t = 4 * i + tokr;
-            if (i < 12 || tokr == 0) *(bf16x8*)&Lm->t[which][t][part * 8] = stg[i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // this task's log-sum-exp rows were loaded WITH its q|k|v|dO pieces, one iteration ahead: the load counter is in
-        // order, so a load issued after the 13 prefetch loads and consumed in phase A meant s_waitcnt vmcnt(0) there --
-        // a wait for the whole prefetch in the middle of the task
-        const float lse_q[2] = {lse_n[0], lse_n[1]};
-        if (task + n_waves < n_tasks) {
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const int q = 32 * qt + c;
-                lse_n[qt] = lse[(size_t)(task + n_waves) * TILE + (q < NTOK ? q : 0)];
-            }
-            if (win_interior(g, nxt)) bwd_issue_loads<true>(stg, L, g, qkv, dout, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
-            else bwd_issue_loads<false>(stg, L, g, qkv, dout, qkv_bias, head, nxt.b, nxt.wr, nxt.wc);
-        }
-
-        // ---------------- phase A -------------------------------------------------------------
-        const bool edge = g.shift > 0 && (wr == g.nWh - 1 || wc == g.nWw - 1);
-        uint64_t mbits = 0;
-        if (edge) {
-            if (wr == g.nWh - 1) mbits |= mrow;
-            if (wc == g.nWw - 1) mbits |= mcol;
-        }
-        bf16x8 kf[2][2], vf[2][2];
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                kf[t2][s] = *(const bf16x8*)&Ks[32 * t2 + c][16 * s + 8 * h];
-                vf[t2][s] = *(const bf16x8*)&Vs[32 * t2 + c][16 * s + 8 * h];
-            }
-        f32x16 dq[2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {           // one 32-query tile at a time (register budget)
-            bf16x8 qf[2], df[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                qf[s] = *(const bf16x8*)&Qs[32 * qt + c][16 * s + 8 * h];
-                df[s] = *(const bf16x8*)&Ds[32 * qt + c][16 * s + 8 * h];
-            }
-            f32x16 pacc[2], dpacc[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                f32x16 a = {0}, d = {0};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], a, 0, 0, 0);   // S^T
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], df[s], d, 0, 0, 0);   // dP^T
-                }
-                pacc[kt] = a;
-                dpacc[kt] = d;
-            }
-            const int q = 32 * qt + c;
-            const bool qv = q < NTOK;
-            const float l2 = lse_q[qt] * LOG2E;
-            float d4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    if (kt == 1 && reg >= 9) { pacc[kt][reg] = 0.f; continue; }   // keys 49..63 (padding) for every lane: P = 0
-                    float v = fmaf(pacc[kt][reg], sl2, biasr[kt][qt][reg]);
-                    if (edge && ((mbits >> ((kt * 2 + qt) * 16 + reg)) & 1)) v += -100.0f * LOG2E;
-                    float p = qv ? __builtin_amdgcn_exp2f(v - l2) : 0.f;   // padded query columns carry garbage
-                    pacc[kt][reg] = p;
-                    d4[reg & 3] = fmaf(p, dpacc[kt][reg], d4[reg & 3]);
-                }
-            const float delta = half_swap_sum((d4[0] + d4[1]) + (d4[2] + d4[3]));
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    bf16x4 p4, s4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int reg = 4 * gq + e;
-                        if (kt == 1 && reg >= 9) { dpacc[kt][reg] = 0.f; p4[e] = (bf16)0.f; s4[e] = (bf16)0.f; continue; }   // padded keys
-                        float ds = pacc[kt][reg] * (dpacc[kt][reg] - delta);
-                        dbacc[kt][qt][reg] += ds;
-                        ds *= scale;                              // scale * dS^T from here on
-                        dpacc[kt][reg] = ds;
-                        p4[e] = (bf16)pacc[kt][reg];
-                        s4[e] = (bf16)ds;
-                    }
-                    // [query][key] tiles: this lane's 4 consecutive keys
-                    *(bf16x4*)&Lm->p[q][32 * kt + 8 * gq + 4 * h] = p4;
-                    *(bf16x4*)&Lm->ds[q][32 * kt + 8 * gq + 4 * h] = s4;
-                }
-            // dQ^T = K^T (scale dS^T)
-            f32x16 dqa = {0};
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    bf16x8 kc = lds_tr_frag_perm(Ks, 32 * kt + 16 * s, lane);
-                    bf16x8 sf;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) sf[j] = (bf16)dpacc[kt][8 * s + j];
-                    dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, sf, dqa, 0, 0, 0);
-                }
-            dq[qt] = dqa;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        // ---------------- phase B: dV^T = dO^T P ,  dK^T = Q^T (scale dS) ----------------------
-        f32x16 dv[2] = {{0}, {0}}, dk[2] = {{0}, {0}};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {          // k-steps of 16 queries
-            bf16x8 doc = lds_tr_frag_lin<LROW>(&Ds[0][0], 16 * ks, 0, lane);   // A = dO^T : rows d, k = query
-            bf16x8 qc = lds_tr_frag_lin<LROW>(&Qs[0][0], 16 * ks, 0, lane);    // A = Q^T
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                bf16x8 pb = lds_tr_frag_lin<PROW>(&Lm->p[0][0], 16 * ks, 32 * kt, lane);    // B[k=query][col=key]
-                bf16x8 sb = lds_tr_frag_lin<PROW>(&Lm->ds[0][0], 16 * ks, 32 * kt, lane);
-                dv[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doc, pb, dv[kt], 0, 0, 0);
-                dk[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qc, sb, dk[kt], 0, 0, 0);
-            }
-        }
-
-        // ---------------- write dq | dk | dv for this lane's token ------------------------------
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            int tok = 32 * tt + c;
-            bool pad = false;
-            if (tok < NTOK) {
-                bf16* op = nullptr;
-                if (interior) {
-                    op = dqkv + ((size_t)(b * g.H + wr * 7 + g.shift) * g.W + wc * 7 + g.shift) * C3 + L.st_off[tt] + head * HD + 4 * h;
-                } else {
-                    int src = token_src(g, b, wr, wc, tok);
-                    if (src >= 0) op = dqkv + (size_t)src * C3 + head * HD + 4 * h;
-                    else pad = true;
-                }
-                if (op) {
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        bf16x4 a, bb, cc;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            a[e] = (bf16)dq[tt][4 * gq + e];
-                            bb[e] = (bf16)dk[tt][4 * gq + e];
-                            cc[e] = (bf16)dv[tt][4 * gq + e];
-                        }
-                        *(bf16x4*)(op + 8 * gq) = a;
-                        *(bf16x4*)(op + g.C + 8 * gq) = bb;
-                        *(bf16x4*)(op + 2 * g.C + 8 * gq) = cc;
-                    }
-                }
-            }
-            // padded tokens: their q|k|v ARE qkv.bias, so the gradient lands on the bias.  The padded tokens of this
-            // 32-lane half are summed with lane shuffles and added to the wave's LDS accumulator by one lane per half.
-            // (History: global atomics from every padded token onto 3C addresses serialised at the memory side, ~1 ms
-            // per launch; LDS atomics from the 32 lanes of a half onto the SAME address serialise too -- 48 of them
-            // per token tile made every edge window several times slower than an interior one, and with persistent
-            // waves the slowest wave sets the kernel time.)
-            if (__ballot(pad)) {                               // wave-uniform
-                float* bp = Lm->padacc + 4 * h;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float a = pad ? dq[tt][r] : 0.f, bq = pad ? dk[tt][r] : 0.f, cv = pad ? dv[tt][r] : 0.f;
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) {
-                        a += __shfl_xor(a, o); bq += __shfl_xor(bq, o); cv += __shfl_xor(cv, o);
-                    }
-                    if (c == 0) {
-                        const int d = (r & 3) + 8 * (r >> 2);
-                        bp[d] += a; bp[HD + d] += bq; bp[2 * HD + d] += cv;
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    // this wave's partial relative-position-bias gradient -> its private slab
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                slab[key * TILE + 32 * qt + c] = dbacc[kt][qt][reg];
-            }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < 3 * HD + 32; i += WAVE) slab[TILE * TILE + i] = i < 3 * HD ? Lm->padacc[i] : 0.f;
-}
-
 // ------------------------------------------------------------------------------------
-// bf16 backward, TWO waves per (window, head) task (round 2).  The one-wave kernel above holds 476 VGPRs and 38.5 KB of LDS
-// per wave: one wave per SIMD, so nothing hides a task's MFMA -> VALU -> LDS dependency chain.  Here a task belongs to a
+// bf16 backward, TWO waves per (window, head) task (round 2).  The first version ran one wave per task with 476 VGPRs and 38.5 KB
+// of LDS per wave (one wave per SIMD, nothing hid a task's MFMA -> VALU -> LDS dependency chain: 94 us at stage 1 against 73 us
+// here; removed in round 3, git history has it).  Here a task belongs to a
 // PAIR of waves sharing one BwdLds2:
 //   staging : each wave loads half of the task's q|k|v|dO rows (8 tokens per round over the pair, 7 rounds)
 //   phase A : wave w owns query tile w (32 queries x 64 keys): S^T, dP^T, P, delta, dS, dQ -- independent per query tile, so
@@ -1290,13 +959,13 @@ static int round_blocks(int want, int n_tasks, int nH) {
 // forward: working waves per block.  nH == 3 (stage 1 of Swin-T/S): 3, so that the three heads of a window share a block
 // (see the kernel); SWIN_ATTN_FWD_WPB=4 restores the four-wave mapping for comparison.
 static int attn_fwd_wpb(int nH) {
-    static const int forced = getenv("SWIN_ATTN_FWD_WPB") ? atoi(getenv("SWIN_ATTN_FWD_WPB")) : 0;
+    static const int forced = swin_dev_int("SWIN_ATTN_FWD_WPB", 0);
     if (forced == 3 || forced == 4) return (forced == 3 && nH % 3 != 0) ? 4 : forced;
     return nH == 3 ? 3 : 4;
 }
 
 static int attn_grid_blocks(int n_tasks, int nH, int wpb) {
-    static const int forced = getenv("SWIN_ATTN_FWD_BLOCKS") ? atoi(getenv("SWIN_ATTN_FWD_BLOCKS")) : 0;   // development sweep
+    static const int forced = swin_dev_int("SWIN_ATTN_FWD_BLOCKS", 0);   // development sweep
     if (wpb == 3) {                                  // nH % 3 == 0: any block count keeps (waves % nH == 0)
         const int all = (n_tasks + 2) / 3, want = forced > 0 ? forced : 512;        // swept: 480: 26.4 us, 512: 25.2, 640: 27.3 (stage 1)
         return want < all ? want : all;
@@ -1349,14 +1018,13 @@ extern "C" int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int n
 // backward (two-wave kernel): wave pairs per block.  nH == 3: 3, so that a window's heads share a block as in the forward kernel
 // (stage 1: 73.4 -> 71.5 us with a quarter fewer waves); SWIN_ATTN_BWD_PPB=4 restores four pairs.
 static int attn_bwd_ppb(int nH) {
-    static const int forced = getenv("SWIN_ATTN_BWD_PPB") ? atoi(getenv("SWIN_ATTN_BWD_PPB")) : 0;
-    static const int one_wave = getenv("SWIN_ATTN_BWD_WAVES") ? atoi(getenv("SWIN_ATTN_BWD_WAVES")) == 1 : 0;
-    if (one_wave || forced == 4 || nH % 3 != 0) return 4;
+    static const int forced = swin_dev_int("SWIN_ATTN_BWD_PPB", 0);
+    if (forced == 4 || nH % 3 != 0) return 4;
     return (forced == 3 || nH == 3) ? 3 : 4;
 }
 
 static int attn_bwd_blocks(int n_tasks, int nH) {
-    static const int forced = getenv("SWIN_ATTN_BWD_BLOCKS") ? atoi(getenv("SWIN_ATTN_BWD_BLOCKS")) : 0;   // development sweep
+    static const int forced = swin_dev_int("SWIN_ATTN_BWD_BLOCKS", 0);   // development sweep
     if (attn_bwd_ppb(nH) == 3) {                     // any block count keeps (pairs % nH == 0); swept at stage 1: 240: 74.5 us, 256: 71.5, 320: 89
         const int all = (n_tasks + 2) / 3, want = forced > 0 ? forced : 256;
         return want < all ? want : all;
@@ -1366,8 +1034,6 @@ static int attn_bwd_blocks(int n_tasks, int nH) {
     // two-waves-per-task kernel, swept over 192..512 blocks (round 2): stage 1 (8004 tasks) 72.9 us at 240 (256: 73.2, 320+: 84-88);
     // stage 2 (4140) 56.5 at 256 (240: 58.4, 384: 57.9); stages 3 / 4 (2304 / 1152 tasks: whole rounds at 768 pairs) 42.0 / 39.5 at
     // 192 (256: 49.1 / 40.3, 384: 45.2 / 40.9).  One block per CU (158 KB of LDS): more blocks than CUs only add a second wave of blocks.
-    static const int one_wave = getenv("SWIN_ATTN_BWD_WAVES") ? atoi(getenv("SWIN_ATTN_BWD_WAVES")) == 1 : 0;
-    if (one_wave) return round_blocks(many_rounds ? 240 : 384, n_tasks, nH);
     return round_blocks(many_rounds ? 240 : (n_tasks <= 2400 ? 192 : 256), n_tasks, nH);
 }
 
@@ -1392,26 +1058,17 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
         if (!workspace) return SWIN_ERR_BAD_ARG;
         int blocks = attn_bwd_blocks(n_tasks, nH);
         static bool attr_set[16] = {};                       // per device: the attribute belongs to the device's code object
-        static const int two_waves = getenv("SWIN_ATTN_BWD_WAVES") ? atoi(getenv("SWIN_ATTN_BWD_WAVES")) != 1 : 1;   // 1: the one-wave-per-task kernel (A/B)
-        size_t shm = two_waves ? 4 * sizeof(BwdLds2) : 4 * sizeof(BwdLds);
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute((const void*)win_attn_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(4 * sizeof(BwdLds))) != hipSuccess) return SWIN_ERR_LAUNCH;
             if (hipFuncSetAttribute((const void*)win_attn_bwd2_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(4 * sizeof(BwdLds2))) != hipSuccess) return SWIN_ERR_LAUNCH;
             attr_set[dev] = true;
         }
         const int ppb = attn_bwd_ppb(nH);
-        if (two_waves) {
-            const int iters = (n_tasks + blocks * ppb - 1) / (blocks * ppb);
-            win_attn_bwd2_bf16_kernel<<<blocks, 128 * ppb, ppb * sizeof(BwdLds2), s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
-                                                               (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks, iters, ppb);
-        } else {
-            win_attn_bwd_bf16_kernel<<<blocks, 256, shm, s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
-                                                              (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks);
-        }
+        const int iters = (n_tasks + blocks * ppb - 1) / (blocks * ppb);
+        win_attn_bwd2_bf16_kernel<<<blocks, 128 * ppb, ppb * sizeof(BwdLds2), s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
+                                                           (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks, iters, ppb);
         int n = nH * (TILE * TILE + 3 * HD);
         dim3 rgrid((n + 255) / 256, 16);
         // bias-gradient reduce: off the data-gradient chain (see csrc/abi.hip)

@@ -414,7 +414,7 @@ class _RpnHeads(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         from ._lib import call
-        from .ops.functional import _p, _s, ensure_scratch, gemm_bf16
+        from .ops.functional import _p, _s, gemm_bf16
         tok, w_cat = ctx.saved_tensors
         head = ctx.head
         A = head.num_anchors
@@ -433,7 +433,6 @@ class _RpnHeads(torch.autograd.Function):
         key = head.rpn_cls.weight
         dwb = mixed.step_buffer(key, 'rpn_dw', (N1, C), tok.device)
         dbb = mixed.step_buffer(key, 'rpn_db', (N1,), tok.device)
-        ensure_scratch(tok.device)
         parts = ((head.rpn_cls.weight, dwb[:A].view(A, C, 1, 1)), (head.rpn_reg.weight, dwb[A:5 * A].view(4 * A, C, 1, 1)),
                  (head.rpn_cls.bias, dbb[:A]), (head.rpn_reg.bias, dbb[A:5 * A]))
         sinks = [mixed.grad_sink(p) for p, _ in parts]

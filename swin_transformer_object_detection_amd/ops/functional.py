@@ -57,22 +57,6 @@ def _f32(t):
     return t
 
 
-_LIB_SCRATCH = {}
-_LIB_SCRATCH_BYTES = int(os.environ.get("SWIN_SCRATCH_MB", "96")) << 20
-
-
-def ensure_scratch(device):
-    """Register (once per device) the scratch buffer the weight-gradient kernels use for their split-T partial tiles
-    (swin_set_scratch): plain stores + a reduce launch instead of fp32 atomics.  96 MB covers the largest shape of the
-    step (the P2 3x3 conv: 18 splits x 256 x 2304 fp32 = 42 MB)."""
-    k = device.index if device.index is not None else torch.cuda.current_device()
-    if k not in _LIB_SCRATCH and _LIB_SCRATCH_BYTES > 0:
-        with torch.cuda.device(k):
-            t = torch.empty(_LIB_SCRATCH_BYTES, device=device, dtype=torch.uint8)
-            call("swin_set_scratch", _p(t), t.numel())
-        _LIB_SCRATCH[k] = t
-
-
 def _grad_buf(param):
     """(fp32 buffer a kernel ACCUMULATES param's gradient into, value to return through autograd, notify()).
 
@@ -513,7 +497,6 @@ class _Conv3x3(torch.autograd.Function):
             dbf = None
             if need_b:
                 dbf = bs[0] if bs is not None else torch.zeros(Cout, device=x.device, dtype=torch.float32)
-            ensure_scratch(x.device)
             if ws is not None:
                 # sink mode: nothing on the main stream reads the result before the reducer -> weight-gradient stream
                 last = mixed.use_end(w_master) == 0
@@ -636,7 +619,6 @@ class _LinearBf16(torch.autograd.Function):
             dbf = None
             if need_b:
                 dbf = bs[0] if bs is not None else torch.zeros(N1, device=x.device, dtype=torch.float32)
-            ensure_scratch(x2.device)
             sst = mixed.fork_to_side(x2.device, dy2, x2) if ws is not None and (bs is not None or not need_b) else None
             call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2,
                  ctypes.c_void_p(sst) if sst is not None else _s())

@@ -13,7 +13,7 @@ import torch
 
 from .. import _lib, mixed
 from .._lib import SWIN_BF16, call
-from .functional import LN_EPS, _f32, _ln_ws, _p, _s, ensure_scratch, gemm_bf16, rel_bias_expand
+from .functional import LN_EPS, _f32, _ln_ws, _p, _s, gemm_bf16, rel_bias_expand
 
 
 def _weight_grads(dy2, x2, w, w_master, b_master, need_w, need_b):
@@ -30,7 +30,6 @@ def _weight_grads(dy2, x2, w, w_master, b_master, need_w, need_b):
     dbf = None
     if need_b:
         dbf = bs[0] if bs is not None else torch.zeros(N1, device=x2.device, dtype=torch.float32)
-    ensure_scratch(x2.device)
     call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2, _s())
     dw = db = None
     if ws is not None:
@@ -379,7 +378,9 @@ class _SwinBlockFn(torch.autograd.Function):
             ws_attn = torch.empty(max(lib.swin_window_attn_bwd_workspace_bytes(B, H, W, nH, SWIN_BF16), 16), device=dev, dtype=torch.uint8)
             ws_ln2 = torch.empty(max(ln_bytes, 16), device=dev, dtype=torch.uint8)
             ws_ln3 = torch.empty(max(ln_bytes, 16), device=dev, dtype=torch.uint8) if has_next else ws_ln2
-            mixed.side_keep(flat, qkv, n1, dx2, dnn if has_next else None, ws_attn, ws_ln2, ws_ln3, dbexp, mean2, lse)
+            # dy2 is a tensor of its own (not a slice of `flat`) when the block has no next norm and DropPath scales dx2; the fc2
+            # weight gradient reads it on the side stream after backward() has returned
+            mixed.side_keep(flat, qkv, n1, dx2, dy2, dnn if has_next else None, ws_attn, ws_ln2, ws_ln3, dbexp, mean2, lse)
             mixed.side_mark(dev)
         ptrs = (ctypes.c_void_p * 56)(
             _ptr(n1), _ptr(qkv), _ptr(bias_exp), _ptr(lse), _ptr(o), _ptr(x1), _ptr(mean2), _ptr(rstd2), _ptr(n2), _ptr(hpre),
@@ -391,7 +392,6 @@ class _SwinBlockFn(torch.autograd.Function):
             side.cuda_stream if side is not None else None)
         iv = (ctypes.c_int64 * 7)(B, H, W, C, nH, shift, 1 if getattr(ctx, 'fused_mlp', False) else 0)
         fv = (ctypes.c_float * 1)(scale)
-        ensure_scratch(dev)
         call("swin_block_bwd", ptrs, iv, fv, _s())
         g_bq = f_bqkv()
         g_pad = f_bpad()

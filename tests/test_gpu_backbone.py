@@ -331,6 +331,48 @@ def test_weight_gradient_stream_gives_the_same_gradients(pkg):
         sh.release()
 
 
+def test_weight_gradient_stream_with_a_stage_that_has_no_output_norm(pkg):
+    """The last block of a stage that is NOT in out_indices has no next norm: with DropPath on, its fc2 weight gradient reads
+    dx2 * dp1 -- a tensor of its own, not a slice of the block's carved backward buffer -- on the second stream AFTER
+    backward() has returned.  It must be kept alive until the join (round-2 advisor finding): three unsynchronised steps,
+    second stream on vs off, every bucket gradient equal."""
+    from swin_transformer_object_detection_amd import ddp, mixed
+    torch.manual_seed(0)
+    m = pkg.backbone.SwinTransformer(embed_dim=96, depths=[2, 2], num_heads=[3, 6], drop_path_rate=0.3, out_indices=(1,),
+                                     compute_dtype=torch.bfloat16).cuda().train()
+    sh = mixed.ShadowParams(m, torch.bfloat16)
+    red = ddp.BucketedGradReducer(m.parameters(), leaf_of=sh.leaf_of)
+    img = torch.randn(2, 3, 224, 256, generator=torch.Generator().manual_seed(3)).cuda()
+    was = mixed.side_enabled()
+
+    def run(on):
+        mixed.set_side_enabled(on)
+        outs = []
+        for it in range(3):
+            torch.manual_seed(200 + it)                     # the same DropPath draws in both runs
+            red.zero_grad()
+            (o,) = m(img)
+            o.float().square().mean().backward()
+            # allocations right behind backward: they would take over a freed dy2 while the side stream still read it
+            junk = [torch.full((2, 56 * 64, 96), float(k), device="cuda", dtype=torch.bfloat16) for k in range(8)]
+            red.finish()
+            del junk
+            outs.append([b['flat'].clone() for b in red.buckets])
+        torch.cuda.synchronize()
+        return outs
+    try:
+        ref, again, got = run(False), run(False), run(True)
+        assert mixed.side_stream(torch.device("cuda", 0)) is not None
+        for it in range(3):
+            for fr, fa, fg in zip(ref[it], again[it], got[it]):
+                scale, noise = float(fr.abs().max()), float((fr - fa).abs().max())
+                assert float((fr - fg).abs().max()) <= 4 * noise + 2e-3 * scale + 1e-7, (it, noise, scale)
+    finally:
+        mixed.set_side_enabled(was)
+        red.release()
+        sh.release()
+
+
 def test_side_join_really_makes_the_current_stream_wait(pkg):
     """mixed.on_side / fork_to_side / side_join order the streams on the DEVICE: a long chain on the second stream, then a
     join, then a copy on the current (default: handle 0) stream must see the chain's final result; and the fork direction:
