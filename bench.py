@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the whole step as ONE hipGraph launch (graph_step.GraphedTrainStep).  auto: on one GPU (the "
+                         "multi-rank step, whose all-reduces overlap backward, is issued eagerly)")
     ap.add_argument("--workload", default="mask_rcnn_swin_t", choices=sorted(WORKLOADS),
                     help="default: BASELINE.json configs[1] (the headline metric); the others are the BASELINE parity configurations, "
                          "timed for DESIGN.md only")
@@ -330,12 +333,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # One hipGraph launch per step: the ~570 launches of a step cost the host as much time as the GPU needs to
+    # run them, so the eager rate follows the host's speed.  The graph holds the same launches; learning rates / bias
+    # corrections / sampler seeds are refreshed in device memory before every replay.
+    launch_mode, graph_note = "eager", None
+    if args.graph == "on" or (args.graph == "auto" and world == 1 and dtype != torch.float32):
+        try:
+            from swin_transformer_object_detection_amd.graph_step import GraphedTrainStep
+            gstep = GraphedTrainStep(model, reducer, optim, warmup=3, capture_collectives=world > 1)
+            gstep(batch)                        # 3 eager steps, capture, first replay
+            step = lambda: gstep(batch)         # noqa: E731
+            launch_mode = "hipgraph"
+        except Exception as e:                  # noqa: BLE001 -- report and measure the eager step instead
+            graph_note = f"capture failed, eager step measured: {type(e).__name__}: {e}"[:400]
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         log_vars = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         log_vars = step()
+    t_enq = time.perf_counter() - t0          # host time to ISSUE the K steps (nothing waited for yet)
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -372,6 +391,10 @@ def main():
             "value": round(gb * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            # how the step was issued, and the host's share of it: host_enqueue_ms = host time to issue one step (no waiting),
+            # ms_per_step = until the GPU has finished it.  host_enqueue_ms ~ ms_per_step means the host, not the GPU, set the rate.
+            "launch_mode": launch_mode, "graph_note": graph_note,
+            "host_enqueue_ms": round(1000 * t_enq / args.steps, 3), "gpu_ms": round(1000 * elapsed / args.steps, 3),
             "config": {"workload": workload_desc,
                        "global_batch": gb, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
             "losses": {k: round(v, 4) for k, v in logs.items()},

@@ -38,7 +38,7 @@ extern "C" {
 #define SWIN_HEAD_DIM 32        /* C / num_heads in Swin-T/S/B */
 #define SWIN_ATTN_TILE 64       /* 49 tokens padded to the MFMA tile */
 
-/* ABI version, bumped on any signature change. */
+/* ABI version, bumped on any signature change (2: det_random_sample gained seed_dev; swin_set_scratch removed). */
 int swin_hip_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
@@ -235,7 +235,11 @@ int det_max_iou_assign(const float* bboxes, int64_t n, const float* gt_bboxes, i
                        int64_t* assigned_labels, void* workspace, void* stream);
 int64_t det_random_sample_workspace_bytes(void);
 int det_random_sample(const int64_t* assigned_gt_inds, int64_t n, int num, int num_pos_max, uint64_t seed,
-                      int64_t* out_inds, uint8_t* out_flags, void* workspace, void* stream);
+                      const uint64_t* seed_dev, int64_t* out_inds, uint8_t* out_flags, void* workspace, void* stream);
+/* seed_dev (nullable): DEVICE pointer to a 64-bit word that the kernels mix into `seed`.  A training step captured in a hipGraph
+ * freezes the host seed of each call into the graph; the device word (rewritten before every replay: swin_set_u64) keeps the
+ * samples different from step to step, as RandomSampler's torch.randperm does (random_sampler.py:54). */
+int swin_set_u64(void* dst, uint64_t value, void* stream);
 
 /* det_bbox_targets: targets of a fixed-size sample -- the gathers of anchor_head.py:221-247 / bbox_head.py:140-186 plus
  *   DeltaXYWHBBoxCoder.encode (delta_xywh_bbox_coder.py:82-130).  means / stds are HOST pointers to 4 floats.
@@ -277,6 +281,17 @@ int swin_adamw_step(const void* segs, const void* chunks, int n_chunks, const fl
                     int n_groups, float beta1, float beta2, float eps, float bias_correction1,
                     float bias_correction2, void* stream);
 int swin_adamw_chunk_elems(void);
+/* The same step with every per-step scalar in DEVICE memory, so that the launch's arguments never change and it can sit inside a
+ * captured hipGraph (and so that fp16 loss scaling can skip a step without a host round trip).  state: 32 floats --
+ *   [0..7] lr per group, [8..15] weight decay per group, [16] bias_correction1, [17] sqrt(bias_correction2),
+ *   [18] grad_scale (every gradient is multiplied by it: 1 / loss scale), [19] skip (!= 0: parameters and moments untouched),
+ *   [20] loss scale, [21] clean steps since the scale last changed, [22..31] reserved.
+ * swin_adamw_set_state writes [0..17] from its ARGUMENTS with a one-block kernel (no host->device copy); the caller initialises
+ * [18..21] (1, 0, 1, 0 without loss scaling). */
+int swin_adamw_set_state(void* state, const float* lr, const float* weight_decay, int n_groups, float bias_correction1,
+                         float bias_correction2, void* stream);
+int swin_adamw_step_dev(const void* segs, const void* chunks, int n_chunks, const void* state, float beta1, float beta2,
+                        float eps, void* stream);
 
 /* swin_gemm_bf16: the plain GEMMs of the path (nn.Linear forward / data gradient, swin_transformer.py:33-36,129,151,296;
  * 1x1 convs; head FCs) on hipBLASLt with cached plans -- one library launch per call, no framework dispatch.
@@ -285,6 +300,13 @@ int swin_adamw_chunk_elems(void);
 int64_t swin_gemm_workspace_bytes(void);
 int swin_gemm_bf16(const void* a, const void* b, const void* bias, void* c, int64_t M, int N, int K, int b_layout,
                    void* workspace, void* stream);
+/* A plan's algorithm is chosen by timing the library's candidates on first use, so two data-parallel ranks may choose
+ * differently.  swin_gemm_plans_export: records of 6 int64 {M, N, K, b_layout, has_bias, chosen candidate index} of the current
+ * device's plans into HOST memory `out` (capacity `cap` records); returns the number of plans.  swin_gemm_plans_import: select the
+ * recorded candidate for every plan that exists here; returns the number of plans changed.  (Rank 0 exports after warm-up, the
+ * records are broadcast, every rank imports: ddp.sync_gemm_plans.) */
+int swin_gemm_plans_export(int64_t* out, int cap);
+int swin_gemm_plans_import(const int64_t* in, int n);
 
 /* ---- loss kernels of the detector heads (csrc/det_losses.hip): value + input gradients, fixed-size samples ----------
  * det_rpn_loss_*:  AnchorHead.loss_single (anchor_head.py:375-434): sigmoid CE over the sampled anchors + L1 (beta 0) or

@@ -45,7 +45,8 @@ SIGNATURES = {
     "det_assign_workspace_bytes": [_i64, _i],
     "det_max_iou_assign": [_p, _i64, _p, _i, _p, _f, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p],
     "det_random_sample_workspace_bytes": [],
-    "det_random_sample": [_p, _i64, _i, _i, ctypes.c_uint64, _p, _p, _p, _p],
+    "det_random_sample": [_p, _i64, _i, _i, ctypes.c_uint64, _p, _p, _p, _p, _p],
+    "swin_set_u64": [_p, ctypes.c_uint64, _p],
     "det_bbox_targets": [_p, _p, _p, _p, _p, _i, _p, _i64, _p, _p, _i, _p, _p, _p, _p, _p],
     "det_roi_targets_pack": [_p, _p, _p, _p, _p, _i, _p, _i64, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f,
                              _p, _p, _p, _p, _p],
@@ -64,6 +65,10 @@ SIGNATURES = {
     "swin_gemm_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p, _p],
     "swin_adamw_step": [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _p],
     "swin_adamw_chunk_elems": [],
+    "swin_adamw_set_state": [_p, _p, _p, _i, _f, _f, _p],
+    "swin_adamw_step_dev": [_p, _p, _i, _p, _f, _f, _f, _p],
+    "swin_gemm_plans_export": [_p, _i],
+    "swin_gemm_plans_import": [_p, _i],
     "det_rpn_loss_fwd": [_p, _p, _i, _i64, _i, _p, _p, _p, _f, _p, _i, _p],
     "det_rpn_loss_bwd": [_p, _p, _i, _i64, _i, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p],
     "det_bbox_loss_fwd": [_p, _p, _i, _i, _p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _i, _p],

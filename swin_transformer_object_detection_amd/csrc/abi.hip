@@ -3,7 +3,7 @@
 
 #include "common.h"
 #include <cstdlib>
-extern "C" int swin_hip_abi_version(void) { return 1; }
+extern "C" int swin_hip_abi_version(void) { return 2; }
 
 // ---- second stream for work that nothing on the main stream waits for ------------------------------------------------------
 // Per device: while an auxiliary stream is set, the entry points that end in a small REDUCTION nobody on the main stream

@@ -121,10 +121,21 @@ __device__ __forceinline__ unsigned sample_key(unsigned idx, unsigned s0, unsign
     return h;
 }
 
+// seed_dev (nullable): a device-resident 64-bit step seed mixed into the call's own seed -- under hipGraph replay the host seed is
+// frozen into the graph while the device word is rewritten before every replay, so every step still draws a fresh sample.
+__device__ __forceinline__ void mix_seed(unsigned& s0, unsigned& s1, const unsigned long long* __restrict__ seed_dev) {
+    if (seed_dev) {
+        const unsigned long long d = *seed_dev;
+        s0 ^= (unsigned)(d & 0xFFFFFFFFull) * 0x9E3779B1u;
+        s1 ^= (unsigned)(d >> 32) * 0x85EBCA77u + 0x165667B1u;
+    }
+}
+
 __global__ __launch_bounds__(256) void sample_hist_kernel(const int64_t* __restrict__ assigned, int n, unsigned s0, unsigned s1,
-                                                          SampleWs* __restrict__ ws) {
+                                                          const unsigned long long* __restrict__ seed_dev, SampleWs* __restrict__ ws) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
+    mix_seed(s0, s1, seed_dev);
     const int64_t a = assigned[idx];
     if (a < 0) return;
     const unsigned bin = sample_key((unsigned)idx, s0, s1) >> 20;
@@ -163,7 +174,8 @@ __device__ __forceinline__ int find_threshold_bin(const unsigned* __restrict__ h
 }
 
 __global__ __launch_bounds__(256) void sample_collect_kernel(const int64_t* __restrict__ assigned, int n, unsigned s0, unsigned s1,
-                                                             int num, int num_pos_max, SampleWs* __restrict__ ws) {
+                                                             const unsigned long long* __restrict__ seed_dev, int num, int num_pos_max,
+                                                             SampleWs* __restrict__ ws) {
     __shared__ int scratch[257];
     __shared__ int tb;
     int tot_pos, tot_neg;
@@ -178,6 +190,7 @@ __global__ __launch_bounds__(256) void sample_collect_kernel(const int64_t* __re
     if (idx >= n) return;
     const int64_t a = assigned[idx];
     if (a < 0) return;
+    mix_seed(s0, s1, seed_dev);
     const unsigned key = sample_key((unsigned)idx, s0, s1);
     const int bin = (int)(key >> 20);
     const unsigned long long item = ((unsigned long long)key << 32) | (unsigned)idx;
@@ -368,9 +381,10 @@ extern "C" int64_t det_random_sample_workspace_bytes(void) { return (int64_t)siz
 // RandomSampler.sample with a fixed-size result: out_inds (num) i64, out_flags (num) u8 (bit 0 = slot used,
 // bit 1 = positive); positives first.  A uniformly random subset of min(#pos, num_pos_max) positives and of
 // min(#neg, num - #taken_pos) negatives, drawn from the counter-based hash of (seed, box index): deterministic
-// for a given seed.  n <= 2^22, num <= 2048 (candidate capacity).
+// for a given seed.  n <= 2^22, num <= 2048 (candidate capacity).  seed_dev (nullable): device pointer to a 64-bit word mixed
+// into `seed` by the kernels (a per-step seed that lives on the device: hipGraph replay).
 extern "C" int det_random_sample(const int64_t* assigned_gt_inds, int64_t n, int num, int num_pos_max, uint64_t seed,
-                                 int64_t* out_inds, uint8_t* out_flags, void* workspace, void* stream) {
+                                 const uint64_t* seed_dev, int64_t* out_inds, uint8_t* out_flags, void* workspace, void* stream) {
     if (num <= 0) return SWIN_OK;
     if (n < 0 || !out_inds || !out_flags || !workspace || (n > 0 && !assigned_gt_inds) || num_pos_max < 0) return SWIN_ERR_BAD_ARG;
     if (n > (1 << 22) || num > DS_CAP / 2) return SWIN_ERR_UNSUPPORTED;
@@ -380,8 +394,9 @@ extern "C" int det_random_sample(const int64_t* assigned_gt_inds, int64_t n, int
     const unsigned s0 = (unsigned)(seed & 0xFFFFFFFFull), s1 = (unsigned)(seed >> 32);
     if (n > 0) {
         const int blocks = (int)((n + 255) / 256);
-        sample_hist_kernel<<<blocks, 256, 0, s>>>(assigned_gt_inds, (int)n, s0, s1, ws);
-        sample_collect_kernel<<<blocks, 256, 0, s>>>(assigned_gt_inds, (int)n, s0, s1, num, num_pos_max, ws);
+        sample_hist_kernel<<<blocks, 256, 0, s>>>(assigned_gt_inds, (int)n, s0, s1, (const unsigned long long*)seed_dev, ws);
+        sample_collect_kernel<<<blocks, 256, 0, s>>>(assigned_gt_inds, (int)n, s0, s1, (const unsigned long long*)seed_dev, num,
+                                                     num_pos_max, ws);
     }
     sample_select_kernel<<<1, 1024, 0, s>>>(ws, num, num_pos_max, out_inds, out_flags);
     return swin_launch_status();

@@ -8,6 +8,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 #include <unordered_map>
 
 #include "common.h"
@@ -17,6 +18,8 @@ struct Plan {
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
     hipblasLtMatmulHeuristicResult_t algo;
+    std::vector<hipblasLtMatmulHeuristicResult_t> cand;      // the heuristic's candidate list the algorithm was chosen from
+    int chosen = 0;                                          // index of `algo` in `cand`
     bool ok = false;
 };
 struct Key {
@@ -124,6 +127,8 @@ Plan* get_plan(int64_t M, int N, int K, int layout, int bias, const void* a = nu
         }
     }
     p.algo = cand[best];
+    p.cand.assign(cand, cand + found);
+    p.chosen = best;
     p.ok = true;
     return &p;
 }
@@ -151,4 +156,43 @@ extern "C" int swin_gemm_bf16(const void* a, const void* b, const void* bias, vo
                              kWorkspace, (hipStream_t)stream);
     }
     return st == HIPBLAS_STATUS_SUCCESS ? SWIN_OK : SWIN_ERR_LAUNCH;
+}
+
+// The algorithm of a plan is picked by timing on first use, so two processes can pick differently for the same shape.  Data-parallel
+// ranks exchange rank 0's choices after warm-up so that every rank runs the same GEMM kernels:
+//   swin_gemm_plans_export: up to `cap` records of 6 int64 {M, N, K, b_layout, has_bias, chosen candidate index} for the current
+//     device's plans -> `out` (HOST memory); returns the number of plans (may exceed cap: call again with a larger buffer).
+//   swin_gemm_plans_import: for every record whose plan exists on the current device and whose candidate list is long enough,
+//     select that candidate; returns the number of plans changed.  Plans not built yet are left to their own first use.
+extern "C" int swin_gemm_plans_export(int64_t* out, int cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    int n = 0;
+    for (auto& kv : g_plans) {
+        if (kv.first.dev != dev || !kv.second.ok) continue;
+        if (out && n < cap) {
+            int64_t* r = out + 6 * (int64_t)n;
+            r[0] = kv.first.M; r[1] = kv.first.N; r[2] = kv.first.K; r[3] = kv.first.layout; r[4] = kv.first.bias; r[5] = kv.second.chosen;
+        }
+        ++n;
+    }
+    return n;
+}
+
+extern "C" int swin_gemm_plans_import(const int64_t* in, int n) {
+    if (n < 0 || (n > 0 && !in)) return -1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    int changed = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* r = in + 6 * (int64_t)i;
+        auto it = g_plans.find(Key{r[0], (int)r[1], (int)r[2], (int)r[3], (int)r[4], dev});
+        if (it == g_plans.end() || !it->second.ok) continue;
+        Plan& p = it->second;
+        const int idx = (int)r[5];
+        if (idx >= 0 && idx < (int)p.cand.size() && idx != p.chosen) { p.algo = p.cand[idx]; p.chosen = idx; ++changed; }
+    }
+    return changed;
 }

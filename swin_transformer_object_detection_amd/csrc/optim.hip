@@ -14,20 +14,32 @@ struct AdamHyper { float lr[8], wd[8]; };
 
 #define ADAM_CHUNK 4096     // elements per block
 
+// Device-resident step state (swin_adamw_set_state writes it with a one-thread kernel, i.e. from kernel ARGUMENTS: no host->device
+// copy, and under hipGraph replay the optimizer launch inside the graph reads this step's values).  32 floats:
+//   [0..7] lr per group  [8..15] weight decay per group  [16] bias_correction1  [17] sqrt(bias_correction2)
+//   [18] grad_scale: every gradient is multiplied by it (1 / loss scale; 1 without loss scaling)
+//   [19] skip: != 0 -> the step leaves parameters and moments untouched (a non-finite gradient under fp16 loss scaling)
+//   [20] loss scale  [21] clean steps since the last change of the scale  [22..31] reserved
+struct AdamState { float lr[8], wd[8], bc1, bc2_sqrt, grad_scale, skip, loss_scale, good_steps, pad[10]; };
+
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamSeg* __restrict__ segs, const int2* __restrict__ chunks,
                                                     AdamHyper hp, float beta1, float beta2, float eps, float bc1,
-                                                    float bc2_sqrt) {
+                                                    float bc2_sqrt, const AdamState* __restrict__ st) {
     const int2 ck = chunks[blockIdx.x];                 // (segment, chunk index within the segment)
     const AdamSeg s = segs[ck.x];
     const int64_t base = (int64_t)ck.y * ADAM_CHUNK;
-    const float lr = hp.lr[s.group], wd = hp.wd[s.group];
+    float lr = hp.lr[s.group], wd = hp.wd[s.group], gscale = 1.f;
+    if (st) {                                           // this step's values live on the device
+        if (st->skip != 0.f) return;
+        lr = st->lr[s.group]; wd = st->wd[s.group]; bc1 = st->bc1; bc2_sqrt = st->bc2_sqrt; gscale = st->grad_scale;
+    }
     const float step_size = lr / bc1;
     const float decay = 1.f - lr * wd;
 #pragma unroll 4
     for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
         const int64_t i = base + k * 256 + threadIdx.x;
         if (i >= s.n) break;
-        const float g = s.g[i];
+        const float g = s.g[i] * gscale;
         float p = s.p[i] * decay;                        // decoupled weight decay
         const float m = beta1 * s.m[i] + (1.f - beta1) * g;
         const float v = beta2 * s.v[i] + (1.f - beta2) * g * g;
@@ -51,7 +63,45 @@ extern "C" int swin_adamw_step(const void* segs, const void* chunks, int n_chunk
     AdamHyper hp;
     for (int i = 0; i < 8; ++i) { hp.lr[i] = i < n_groups ? lr[i] : 0.f; hp.wd[i] = i < n_groups ? weight_decay[i] : 0.f; }
     adamw_kernel<<<n_chunks, 256, 0, (hipStream_t)stream>>>((const AdamSeg*)segs, (const int2*)chunks, hp, beta1, beta2, eps,
-                                                            bias_correction1, sqrtf(bias_correction2));
+                                                            bias_correction1, sqrtf(bias_correction2), nullptr);
+    return swin_launch_status();
+}
+
+__global__ void adamw_set_state_kernel(AdamState* st, AdamHyper hp, float bc1, float bc2_sqrt) {
+    if (threadIdx.x < 8) { st->lr[threadIdx.x] = hp.lr[threadIdx.x]; st->wd[threadIdx.x] = hp.wd[threadIdx.x]; }
+    if (threadIdx.x == 8) { st->bc1 = bc1; st->bc2_sqrt = bc2_sqrt; }
+}
+
+// this step's learning rates / weight decays / bias corrections -> the device-resident state (layout above; the loss-scaling
+// fields 18..21 are left alone: swin_loss_scale_* own them).  Arguments travel as kernel arguments.
+extern "C" int swin_adamw_set_state(void* state, const float* lr, const float* weight_decay, int n_groups, float bias_correction1,
+                                    float bias_correction2, void* stream) {
+    if (!state || !lr || !weight_decay || n_groups <= 0 || n_groups > 8 || bias_correction1 <= 0.f || bias_correction2 <= 0.f)
+        return SWIN_ERR_BAD_ARG;
+    AdamHyper hp;
+    for (int i = 0; i < 8; ++i) { hp.lr[i] = i < n_groups ? lr[i] : 0.f; hp.wd[i] = i < n_groups ? weight_decay[i] : 0.f; }
+    adamw_set_state_kernel<<<1, 64, 0, (hipStream_t)stream>>>((AdamState*)state, hp, bias_correction1, sqrtf(bias_correction2));
+    return swin_launch_status();
+}
+
+// swin_adamw_step with every per-step scalar read from the device-resident state: the launch's arguments never change, so it can
+// sit inside a captured hipGraph.
+extern "C" int swin_adamw_step_dev(const void* segs, const void* chunks, int n_chunks, const void* state, float beta1, float beta2,
+                                   float eps, void* stream) {
+    if (n_chunks == 0) return SWIN_OK;
+    if (!segs || !chunks || n_chunks < 0 || !state) return SWIN_ERR_BAD_ARG;
+    AdamHyper hp = {};
+    adamw_kernel<<<n_chunks, 256, 0, (hipStream_t)stream>>>((const AdamSeg*)segs, (const int2*)chunks, hp, beta1, beta2, eps, 1.f, 1.f,
+                                                            (const AdamState*)state);
+    return swin_launch_status();
+}
+
+__global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
+
+// *dst (device, 8-byte aligned) = value, as a kernel launch (no host->device copy: the per-step seed of the samplers)
+extern "C" int swin_set_u64(void* dst, uint64_t value, void* stream) {
+    if (!dst) return SWIN_ERR_BAD_ARG;
+    set_u64_kernel<<<1, 1, 0, (hipStream_t)stream>>>((unsigned long long*)dst, (unsigned long long)value);
     return swin_launch_status();
 }
 

@@ -46,6 +46,42 @@ def _next_seed():
     return int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64))
 
 
+# Device-resident step seed (one int64 word per device).  None = off: every call's randomness is its host seed.  A training step
+# that is captured in a hipGraph (graph_step.py) turns it on: the host seeds of the captured calls are frozen into the graph, the
+# device word is rewritten before every replay (set_step_seed) and the kernels mix the two.
+_STEP_SEED = {}
+
+
+def step_seed_tensor(device, create=False):
+    k = device.index if device.index is not None else torch.cuda.current_device()
+    t = _STEP_SEED.get(k)
+    if t is None and create:
+        t = _STEP_SEED[k] = torch.zeros(1, dtype=torch.int64, device=device)
+    return t
+
+
+def set_step_seed(device, value=None):
+    """Write this step's seed word on ``device`` (one tiny launch, the value travels as a kernel argument: no host->device copy).
+    value None: drawn from torch's CPU generator."""
+    t = step_seed_tensor(device, create=True)
+    v = _next_seed() if value is None else int(value)
+    with torch.cuda.device(t.device):
+        call("swin_set_u64", _p(t), ctypes.c_uint64(v & (2 ** 64 - 1)), _s())
+    return t
+
+
+def disable_step_seed(device=None):
+    if device is None:
+        _STEP_SEED.clear()
+    else:
+        _STEP_SEED.pop(device.index if device.index is not None else torch.cuda.current_device(), None)
+
+
+def _seed_dev(device):
+    t = step_seed_tensor(device)
+    return None if t is None else _p(t)
+
+
 def random_sample(assigned_gt_inds, num, pos_fraction, seed=None):
     """RandomSampler.sample (random_sampler.py:31-78, neg_pos_ub=-1) with a fixed-size result.
 
@@ -60,7 +96,8 @@ def random_sample(assigned_gt_inds, num, pos_fraction, seed=None):
     flags = torch.empty(num, dtype=torch.uint8, device=a.device)
     ws = torch.empty(_lib.lib().det_random_sample_workspace_bytes(), dtype=torch.uint8, device=a.device)
     call("det_random_sample", _p(a) if a.numel() else None, a.numel(), int(num), int(num * pos_fraction),
-         _next_seed() if seed is None else int(seed), _p(inds), _p(flags), _p(ws), _s())
+         _next_seed() if seed is None else int(seed), _seed_dev(a.device) if seed is None else None, _p(inds), _p(flags), _p(ws),
+         _s())
     return inds, flags >= 2, flags >= 1
 
 
@@ -81,7 +118,8 @@ def random_sample_raw(assigned_gt_inds, num, pos_fraction, seed=None, out=None):
         flags = torch.empty(num, dtype=torch.uint8, device=a.device)
     ws = torch.empty(_lib.lib().det_random_sample_workspace_bytes(), dtype=torch.uint8, device=a.device)
     call("det_random_sample", _p(a) if a.numel() else None, a.numel(), int(num), int(num * pos_fraction),
-         _next_seed() if seed is None else int(seed), _p(inds), _p(flags), _p(ws), _s())
+         _next_seed() if seed is None else int(seed), _seed_dev(a.device) if seed is None else None, _p(inds), _p(flags), _p(ws),
+         _s())
     return inds, flags
 
 

@@ -35,6 +35,8 @@ class FusedAdamW:
         self._partial_done = set()
         self.step_count = 0
         self._tables = None
+        self._state = None                  # device-resident per-step scalars (32 floats, include/swin_hip.h: swin_adamw_step_dev)
+        self._prepared = False
 
     # -- tables: built on the first step (gradients must exist), rebuilt if any pointer moved --------------------
     def _signature(self):
@@ -85,6 +87,55 @@ class FusedAdamW:
         self._tables = (seg_t, ck_t, len(chunks))
         self._sig = self._signature()
 
+    def state_tensor(self, device):
+        """The 32-float device block the kernel reads its per-step scalars from (lr / weight decay per group, bias corrections,
+        gradient scale, skip flag, loss-scale state) -- created on first use: grad_scale 1, skip 0, loss scale 1."""
+        if self._state is None or self._state.device != device:
+            st = torch.zeros(32, dtype=torch.float32)
+            st[18] = 1.0
+            st[20] = 1.0
+            self._state = st.to(device)
+        return self._state
+
+    def _launch_dev(self, stream):
+        seg_t, ck_t, n_chunks = self._tables
+        g0 = self.param_groups[0]
+        b1, b2 = g0['betas']
+        call("swin_adamw_step_dev", seg_t.data_ptr(), ck_t.data_ptr(), n_chunks, self.state_tensor(seg_t.device).data_ptr(),
+             float(b1), float(b2), float(g0['eps']), stream)
+
+    @torch.no_grad()
+    def prepare_step(self):
+        """First half of step(): (re)build the pointer tables if anything moved, advance the step count and write this step's
+        learning rates / weight decays / bias corrections into the device-resident state (one tiny launch, the values travel as
+        kernel arguments).  A training step captured in a hipGraph calls this BEFORE each replay and has apply_step() inside the
+        graph: the captured optimizer launch then reads this step's scalars."""
+        if self._tables is None or self._sig != self._signature():
+            self._build()
+        self.step_count += 1
+        seg_t = self._tables[0]
+        if seg_t is None:
+            return
+        g0 = self.param_groups[0]
+        b1, b2 = g0['betas']
+        ng = len(self.param_groups)
+        lr = (ctypes.c_float * ng)(*[float(g['lr']) for g in self.param_groups])
+        wd = (ctypes.c_float * ng)(*[float(g['weight_decay']) for g in self.param_groups])
+        with torch.cuda.device(seg_t.device):
+            call("swin_adamw_set_state", self.state_tensor(seg_t.device).data_ptr(), lr, wd, ng, 1.0 - b1 ** self.step_count,
+                 1.0 - b2 ** self.step_count, torch.cuda.current_stream().cuda_stream)
+        self._prepared = True
+
+    @torch.no_grad()
+    def apply_step(self):
+        """Second half of step(): the AdamW launch itself (+ the bf16 shadow refresh), every scalar read from device memory."""
+        if self._tables is None:
+            raise SwinHipError("FusedAdamW.apply_step before prepare_step")
+        if self._tables[2]:
+            self._launch_dev(torch.cuda.current_stream().cuda_stream)
+        self._prepared = False
+        mixed.shadows_refreshed()
+
     def _launch(self, ck_t, n_chunks, step_no, stream):
         seg_t = self._tables[0]
         g0 = self.param_groups[0]
@@ -126,6 +177,10 @@ class FusedAdamW:
     @torch.no_grad()
     def step(self):
         done = self._partial_done
+        if not done:
+            if not self._prepared:
+                self.prepare_step()
+            return self.apply_step()
         if self._tables is None or (not done and self._sig != self._signature()):
             self._build()                       # (with early partial steps in flight the tables are by construction the current ones)
         seg_t, ck_t, n_chunks = self._tables

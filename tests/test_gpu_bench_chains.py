@@ -369,12 +369,14 @@ def _bf16_tol(ref, ulps):
     return float(ulps * 2.0 ** -8 * max(ref.detach().abs().max().item(), 1e-3))
 
 
-def test_conv3x3_p2_full_size(pkg):
-    """FPN / RPN 3x3 conv at P2 of 2x800x1280 (2x256x200x320): the many-tile single-buffer schedule (forward and data
-    gradient) and the implicit-im2col weight gradient, against fp32 autograd on the CPU on the same bf16-rounded operands."""
+@pytest.mark.parametrize("H,W", [(200, 320), (256, 256)])
+def test_conv3x3_p2_full_size(pkg, H, W):
+    """FPN / RPN 3x3 conv at P2 of 2x800x1280 (2x256x200x320: BASELINE configs[1] / [3]) and of 2x1024x1024 (2x256x256x256:
+    configs[4]): the many-tile single-buffer schedule (forward and data gradient) and the implicit-im2col weight gradient,
+    against fp32 autograd on the CPU on the same bf16-rounded operands."""
     from swin_transformer_object_detection_amd import ops
     torch.set_num_threads(max(torch.get_num_threads(), 8))
-    N, C, H, W = 2, 256, 200, 320
+    N, C = 2, 256
     g = torch.Generator().manual_seed(17)
     x = torch.randn(N, C, H, W, generator=g).bfloat16().float()
     w = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).bfloat16().float()
@@ -456,12 +458,13 @@ def test_conv3x3_split_k_small_maps(pkg, N, H, W, Cin, Cout):
     assert torch.equal(y1, y0)
 
 
-@pytest.mark.parametrize("N1,N2", [(288, 96), (384, 96), (96, 384), (96, 96)])
-def test_linear_wgrad_stage1_full_T(pkg, N1, N2):
-    """wgrad_linear_bf16 at the stage-1 token count of the bench (T = 2*200*320 = 128 000: split-T, two k-groups)."""
+# Swin-T stage 1 at 2x800x1280 (T = 128 000); Swin-S stage 1 at 2x1024x1024 (T = 131 072); Swin-B stage 1 (C = 128) at 2x800x1280
+@pytest.mark.parametrize("T,N1,N2", [(128000, 288, 96), (128000, 384, 96), (128000, 96, 384), (128000, 96, 96), (131072, 288, 96),
+                                     (131072, 96, 384), (128000, 384, 128), (128000, 512, 128), (128000, 128, 512)])
+def test_linear_wgrad_stage1_full_T(pkg, T, N1, N2):
+    """wgrad_linear_bf16 at the stage-1 token counts of the BASELINE configurations (split-T, two k-groups)."""
     from swin_transformer_object_detection_amd._lib import call
     from swin_transformer_object_detection_amd.ops.functional import _p, _s
-    T = 128000
     g = torch.Generator().manual_seed(N1 + N2)
     dy = (torch.randn(T, N1, generator=g) * 0.1).bfloat16()
     x = torch.randn(T, N2, generator=g).bfloat16()
@@ -476,13 +479,17 @@ def test_linear_wgrad_stage1_full_T(pkg, N1, N2):
     _close(db, refb, 2e-3 * float(refb.abs().max()) + 1e-3, "db")
 
 
-@pytest.mark.parametrize("shift", [0, 3])
-def test_window_attention_bwd_stage1_full(pkg, shift):
-    """win_attn_bwd (fp32 and bf16 kernels) at the bench's stage-1 geometry (B=2, 200x320 tokens, C=96, 3 heads) against
-    autograd through the oracle's attention on the natural grid (pad -> roll -> partition -> core -> reverse -> crop)."""
+# (H, W, heads, shift): stage 1 of Swin-T at 2x800x1280 (configs[1]); stage 1 of Swin-S at 2x1024x1024 (configs[4]: 256x256 tokens
+# padded to 259x259, 2 738 windows); stages 1 / 2 of Swin-B at 2x800x1280 (configs[3]: C = 128 / 256, 4 / 8 heads -- the four-wave
+# block map instead of the three-heads one)
+@pytest.mark.parametrize("H,W,nH,shift", [(200, 320, 3, 0), (200, 320, 3, 3), (256, 256, 3, 3), (256, 256, 3, 0), (200, 320, 4, 3),
+                                          (100, 160, 8, 3)])
+def test_window_attention_bwd_stage1_full(pkg, H, W, nH, shift):
+    """win_attn fwd + bwd (fp32 and bf16 kernels) at the first-stage geometries of the BASELINE configurations against autograd
+    through the oracle's attention on the natural grid (pad -> roll -> partition -> core -> reverse -> crop)."""
     from swin_transformer_object_detection_amd import ops
-    B, H, W, nH, C = 2, 200, 320, 3, 96
-    g = torch.Generator().manual_seed(31 + shift)
+    B, C = 2, 32 * nH
+    g = torch.Generator().manual_seed(31 + shift + H + nH)
     qkv = (torch.randn(B, H * W, 3 * C, generator=g) * 0.7).bfloat16().float()
     qb = (torch.randn(3 * C, generator=g) * 0.2)
     table = torch.randn(169, nH, generator=g) * 0.5

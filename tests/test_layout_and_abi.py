@@ -37,7 +37,7 @@ def test_header_symbols_exported(built_lib):
 def test_ctypes_table_matches_header(built_lib):
     from swin_transformer_object_detection_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
-    assert _lib.lib().swin_hip_abi_version() == 1          # pure host call
+    assert _lib.lib().swin_hip_abi_version() == 2          # pure host call
 
 
 def test_header_cites_reference_for_every_entry_point():
