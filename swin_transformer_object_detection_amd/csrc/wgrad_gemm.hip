@@ -338,10 +338,19 @@ static int wgrad_launch(const bf16* dy, XLoader X, float* dw, float* dbias, int6
 
 // dw (N1, N2) f32 += dy(T, N1)^T x(T, N2);  dbias (N1) f32 += column sums of dy (NULL to skip).
 // N1 % 8 == 0, N2 % 8 == 0.  ACCUMULATES (caller zeroes).
+// csrc/wgrad_dma.hip: the LDS-DMA ring kernel (round 3); SWIN_ERR_UNSUPPORTED = not its shape
+int wgrad2_linear(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2, void* stream);
+int wgrad2_conv3x3(const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W, int Cin, int Cout, void* stream);
+
 extern "C" int wgrad_linear_bf16(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2,
                                  void* stream) {
     if (!dy || !x || !dw || T <= 0 || N1 <= 0 || N2 <= 0) return SWIN_ERR_BAD_ARG;
     if (N1 % 8 || N2 % 8) return SWIN_ERR_UNSUPPORTED;
+    const int gen = swin_dev_int("SWIN_WGRAD_GEN", 2);          // development A/B: 1 = the register-staged kernel below
+    if (gen == 2) {
+        const int st = wgrad2_linear(dy, x, dw, dbias, T, N1, N2, stream);
+        if (st != SWIN_ERR_UNSUPPORTED) return st;
+    }
     PlainX X{(const bf16*)x, T, N2};
     return wgrad_launch((const bf16*)dy, X, dw, dbias, T, N1, N2, (hipStream_t)stream);
 }
@@ -351,6 +360,11 @@ extern "C" int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw,
                                        int Cout, void* stream) {
     if (!dy || !x || !dw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SWIN_ERR_BAD_ARG;
     if (Cin % 8 || Cout % 8) return SWIN_ERR_UNSUPPORTED;
+    const int gen = swin_dev_int("SWIN_WGRAD_GEN", 2);
+    if (gen == 2) {
+        const int st = wgrad2_conv3x3(dy, x, dw, dbias, N, H, W, Cin, Cout, stream);
+        if (st != SWIN_ERR_UNSUPPORTED) return st;
+    }
     int64_t T = (int64_t)N * H * W;
     ConvX X{(const bf16*)x, T, H, W, Cin, 0, 0};
     return wgrad_launch((const bf16*)dy, X, dw, dbias, T, Cout, 9 * Cin, (hipStream_t)stream);
