@@ -169,6 +169,16 @@ int conv3x3_nhwc_bf16(const void* x, const void* w, const float* bias, void* y, 
 int wgrad_linear_bf16(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2, void* stream);
 int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W, int Cin,
                             int Cout, void* stream);
+/* Grouped Linear weight gradients.  swin_wgrad_record has wgrad_linear_bf16's meaning but only RECORDS the problem (per device);
+ * swin_wgrad_flush launches everything recorded as a few grouped kernels on `stream` -- a stage's worth of the backbone's
+ * four-per-block weight gradients in one launch needs no or few splits of t (hence few float atomics) and streams long loops instead
+ * of paying a latency chain per launch.  The caller keeps every recorded operand alive and unmodified until the flush, orders `stream`
+ * behind their producers, and does not read the accumulators before the flush.  swin_wgrad_pending: recorded problems (and, through
+ * *tiles, their 128 x 128 output tiles).  swin_block_bwd records its four weight gradients instead of launching them when iv[7] != 0.
+ * Not in the reference: autograd computes each Linear's weight gradient where its backward node runs. */
+int swin_wgrad_record(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2);
+int swin_wgrad_pending(int64_t* tiles);
+int swin_wgrad_flush(void* stream);
 
 /* ------------------------------------------------------------------------------------
  * mmcv.ops.RoIAlign / roi_align ('avg', aligned flag) -- call sites

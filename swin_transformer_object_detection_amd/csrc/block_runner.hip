@@ -66,7 +66,7 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
 //  55 weight-gradient stream (a hipStream_t, or null = `stream`): the four weight-gradient GEMMs are enqueued there, each
 //     after an event recorded on `stream` behind the kernel that produced its dY operand; the caller joins the two
 //     streams before anything reads the accumulators and keeps the operands alive until then.
-// ints: B, H, W, C, nH, shift, fused_mlp;  floats: scale
+// ints: B, H, W, C, nH, shift, fused_mlp, record_wgrads;  floats: scale
 // fused_mlp != 0: 9 (hpre) and 10 (h) were not saved; swin_mlp_bwd_bf16 recomputes them from n2 (8), writes dn2 (32) and, as
 // temporaries for the two weight-gradient GEMMs, h into 30 and dhpre into 31; db1 (43) then comes from the dW1 launch.
 struct AuxScope {                 // the auxiliary stream is set (and its launches collected) for the duration of one block backward
@@ -120,7 +120,8 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     // private copy (33): dx (26) is handed to autograd, which adds a second gradient into it IN PLACE when x has two consumers
     // (the first block of a stage: x also feeds norm1) -- while the proj weight gradient would still be reading it on the other
     // stream (found by test_weight_gradient_stream_gives_the_same_gradients: 30 % error on those four proj.weight gradients).
-    const bool own_dy = p[14] || side;
+    const bool record = iv[7] != 0;
+    const bool own_dy = p[14] || side || record;        // (recorded weight gradients read dy long after dx was handed to autograd)
     CHK(swin_layernorm_bwd(p[32], p[5], (const float*)p[20], (const float*)p[6], (const float*)p[7], dx1, M(26), own_dy ? M(33) : nullptr,
                            (const float*)p[14], L, (float*)p[46], (float*)p[47], T, C, SWIN_BF16, M(52), stream));
     const void* dy = own_dy ? p[33] : p[26];
@@ -137,6 +138,13 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     // ---- off the chain: one fork, then the collected reductions and the weight gradients (dW += dY^T X, db += colsum dY)
     if (aux.on) CHK(swin_aux_flush(stream, side));
     else if (side) CHK(swin_fork_stream(stream, side));
+    if (record) {                 // iv[7]: recorded for the caller's next grouped launch (swin_wgrad_flush) instead of four launches here
+        if (p[44]) CHK(swin_wgrad_record(dy2, hbuf, (float*)p[44], (float*)p[45], T, C, 4 * C));
+        if (p[42]) CHK(swin_wgrad_record(p[31], p[8], (float*)p[42], iv[6] ? (float*)p[43] : nullptr, T, 4 * C, C));
+        if (p[40]) CHK(swin_wgrad_record(dy, p[4], (float*)p[40], (float*)p[41], T, C, C));
+        if (p[37]) CHK(swin_wgrad_record(p[35], p[0], (float*)p[37], (float*)p[38], T, 3 * C, C));
+        return SWIN_OK;
+    }
     if (p[44]) CHK(wgrad_linear_bf16(dy2, hbuf, (float*)p[44], (float*)p[45], T, C, 4 * C, wst));                           // fc2
     if (p[42]) CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], iv[6] ? (float*)p[43] : nullptr, T, 4 * C, C, wst));       // fc1
     if (p[40]) CHK(wgrad_linear_bf16(dy, p[4], (float*)p[40], (float*)p[41], T, C, C, wst));                                // proj

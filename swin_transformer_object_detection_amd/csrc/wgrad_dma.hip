@@ -18,6 +18,9 @@
 // X is a plain (T, N2) matrix (nn.Linear: swin_transformer.py:33,36,129,151,296) or the implicit im2col of a channels-last
 // activation for a 3x3 / pad 1 convolution (fpn.py:195-197, rpn_head.py:43, fcn_mask_head.py:119-121) with Cin % 128 == 0, so
 // that a 128-column tile lies inside ONE filter tap: the tap's pixel offset is block-uniform and the border test is per row.
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -32,7 +35,10 @@ constexpr int DPT = 8;               // DMA instructions per wave and stage (4 p
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_d;
 typedef __attribute__((address_space(3))) void* lptr_d;
 
-__device__ uint4 g_zero_line[4];     // zero-initialised: the source of every masked 16-byte piece
+// zero-initialised: the source of every masked 16-byte piece.  4096 lines, each lane reading its own: with one shared line a shape whose
+// N is not a multiple of the tile (96, 288: a quarter to three quarters of the DMA lanes masked) sent all those lanes of all CUs to
+// the same L2 channel (measured: 67 us against 26 us for the register-staged kernel at 96 x 96).
+__device__ uint4 g_zero_line[4096];
 
 __device__ __forceinline__ void glds16(uint64_t gsrc, unsigned lds_addr) {      // see csrc/conv_gemm.hip: asm, so that hipcc does not drain it
     unsigned keep;
@@ -109,13 +115,12 @@ template <> __device__ __forceinline__ void wait_vm<16>() { asm volatile("s_wait
 // WKG-th stage of the block's t range with its own ring, folded through LDS before the atomics (halves the atomic bytes at the
 // same number of resident waves: the float-atomic rate is a chip-wide byte rate, guide G12).
 template <typename XSrc, int NBUF, int WKG>
-__global__ __launch_bounds__(256 * WKG, (NBUF * WKG <= 2) ? 2 : 1) void wgrad2_kernel(const bf16* __restrict__ dy, XSrc X, float* __restrict__ dw,
-                                                                                   float* __restrict__ dbias, int64_t T, int N1, int N2,
-                                                                                   int64_t t_per_split, int g2, int g1, int splits, int xcd_map) {
-    extern __shared__ __attribute__((aligned(16))) char lds2[];          // [WKG][NBUF][dY tile | X tile]
+__device__ __forceinline__ void wgrad2_body(char* lds2, const int block_id, const bf16* __restrict__ dy, XSrc X, float* __restrict__ dw,
+                                            float* __restrict__ dbias, int64_t T, int N1, int N2, int64_t t_per_split, int g2, int g1,
+                                            int splits, int xcd_map) {
     int bx, by, bz;
     {
-        int L = blockIdx.x;
+        int L = block_id;
         const int tiles = g1 * g2;
         if (xcd_map) {                      // a split's tiles on ONE XCD (blocks b and b + 8 share one): its dY / X rows are fetched into that
             const int xcd = L & 7, q = L >> 3;      // L2 once and hit by the other tiles.  splits % 8 == 0 (host).
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256 * WKG, (NBUF * WKG <= 2) ? 2 : 1) void wgrad2_k
     }
     typename XSrc::St xs;
     X.init(xs, t_first, n2_0, row, chunk);
-    const uint64_t zero64 = (uint64_t)reinterpret_cast<uintptr_t>(g_zero_line);
+    const uint64_t zero64 = (uint64_t)reinterpret_cast<uintptr_t>(g_zero_line + ((block_id * 256 + tid) & 4095));
     int64_t t_stage = t_first;                                       // first row of the next stage to issue
     auto dma_stage = [&](int buf) {
         const int left = (int)min((int64_t)ST, t_end - t_stage);     // rows of this stage inside the split's range (<= 0: none)
@@ -312,6 +317,33 @@ __global__ __launch_bounds__(256 * WKG, (NBUF * WKG <= 2) ? 2 : 1) void wgrad2_k
     }
 }
 
+template <typename XSrc, int NBUF, int WKG>
+__global__ __launch_bounds__(256 * WKG, (NBUF * WKG <= 2) ? 2 : 1) void wgrad2_kernel(const bf16* __restrict__ dy, XSrc X, float* __restrict__ dw,
+                                                                                   float* __restrict__ dbias, int64_t T, int N1, int N2,
+                                                                                   int64_t t_per_split, int g2, int g1, int splits, int xcd_map) {
+    extern __shared__ __attribute__((aligned(16))) char lds2[];          // [WKG][NBUF][dY tile | X tile]
+    wgrad2_body<XSrc, NBUF, WKG>(lds2, (int)blockIdx.x, dy, X, dw, dbias, T, N1, N2, t_per_split, g2, g1, splits, xcd_map);
+}
+
+// ---- several Linear weight gradients in ONE launch.  The backward of the backbone produces four of them per block, each a
+// 10-40 us launch that is bound by its own latency chain and by splits x |dW| bytes of float atomics (stage 3: 11-15 splits to fill the
+// chip with one problem's 27-36 tiles).  Deferred and grouped (mixed.wgrad_flush: a stage's worth at a time) the launch has hundreds of
+// tiles, so a problem needs no or few splits, the loops are long enough for the DMA ring to stream, and the tail of one problem
+// overlaps the next.  Block -> (problem, split, tile): first_block[] is the running block count.
+constexpr int GMAX = 32;
+struct GProb { const bf16* dy; const bf16* x; float* dw; float* db; int64_t T, per; int N1, N2, g1, g2, splits, pad; };
+struct GTab { int n; int first_block[GMAX + 1]; GProb p[GMAX]; };
+
+__global__ __launch_bounds__(256, 2) void wgrad2_group_kernel(const GTab tab) {
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+    int pi = 0;
+    const int id = (int)blockIdx.x;
+    while (pi + 1 < tab.n && id >= tab.first_block[pi + 1]) ++pi;        // block-uniform scalar search over <= 32 entries
+    const GProb& q = tab.p[pi];
+    PlainSrc X{q.x, q.N2};
+    wgrad2_body<PlainSrc, 2, 1>(lds2, id - tab.first_block[pi], q.dy, X, q.dw, q.db, q.T, q.N1, q.N2, q.per, q.g2, q.g1, q.splits, 0);
+}
+
 template <typename XSrc> inline void set_step(XSrc&, int) {}
 template <> inline void set_step<ConvSrc>(ConvSrc& X, int dt) { X.qd = dt / X.W; X.rd = dt % X.W; }
 
@@ -390,12 +422,261 @@ int dispatch2(const bf16* dy, XSrc X, float* dw, float* dbias, int64_t T, int N1
     return launch2<XSrc, 2, 1>(dy, X, dw, dbias, T, N1, N2, blocks, p.xcd, s);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Third form (Linear layers with MANY output tiles and a short t axis: stages 3-4 of the backbone, the heads' fully connected
+// layers): 64 x 64 output tiles, and the block's 8 waves split the CONTRACTION instead of the tile.  With 128 x 128 tiles those shapes
+// need 7-15 splits of t to fill the chip, and splits x |dW| bytes of float atomics (26 MB per launch at 1536 x 384 = 20 us at the
+// chip-wide 1.3 TB/s, PMC) -- four times as many tiles need a quarter of the splits.  Every wave owns the WHOLE tile (2 x 2
+// accumulators) and every 8th 32-row slice of the block's t range, with a ring of two 8 KB stage buffers of its own: it reads only
+// what its own DMA wrote, so the loop has NO block-level barrier -- a counted s_waitcnt vmcnt orders a wave's ds_reads behind its
+// own LDS-DMA.  The eight partial tiles are folded through LDS once at the end (each wave sums and adds one eighth of the tile).
+// LDS row (256 B) = [dY 64 columns | X 64 columns] with the same 16-chunk XOR as above.
+constexpr int S3 = 32;               // rows of t per wave-stage
+constexpr int W3 = 8;                // waves per block (k-split)
+constexpr int T3 = 64;               // tile width (n1 and n2)
+constexpr int STAGE3 = S3 * ROWB;    // 8 KB
+
+__global__ __launch_bounds__(64 * W3, 2) void wgrad3_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ dw,
+                                                           float* __restrict__ dbias, int64_t T, int N1, int N2, int64_t t_per_split,
+                                                           int g2, int g1, int splits) {
+    extern __shared__ __attribute__((aligned(16))) char lds3[];          // [W3][2][32 rows x 256 B] = 128 KB; reused for the fold
+    int bx, by, bz;
+    {
+        // XCD-aware order (blocks b and b + 8 share an XCD): every XCD gets a contiguous run of (split, tile) pairs, n2 tiles fastest,
+        // so the blocks that share an L2 read the same dY column block and neighbouring X column blocks of the same t range
+        const int nblk = g1 * g2 * splits;
+        int id = blockIdx.x;
+        const int q = nblk / 8, r = nblk % 8, xcd = id % 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
+        const int tiles = g1 * g2;
+        bz = id / tiles; id -= bz * tiles;
+        // the SHORTER tile axis runs fastest: an XCD's run of tiles then spans a near-square patch of the tile grid, i.e. the fewest
+        // operand column blocks per tile (768 x 3072: 12 x 6 tiles = 18 column blocks per XCD instead of 1.5 x 48 = 49.5)
+        if (g1 <= g2) { bx = id / g1; by = id - bx * g1; }
+        else { by = id / g2; bx = id - by * g2; }
+    }
+    const int n1_0 = by * T3, n2_0 = bx * T3;
+    const int64_t t_begin = (int64_t)bz * t_per_split;
+    const int64_t t_end = min(T, t_begin + t_per_split);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* ring = lds3 + (size_t)wave * 2 * STAGE3;
+    const unsigned ring_addr = (unsigned)(uintptr_t)(lptr_d)ring;
+
+    // ---- DMA sources: instruction i (0..7) of a stage covers rows 4 i + (lane >> 4); the lane's chunk position lane & 15 holds chunk
+    // (lane & 15) ^ f(row), f(row) = ((lane >> 4) << 2) | (i & 3): instructions i and i + 4 read the same chunk 16 rows apart
+    uint64_t ptr[4]; unsigned rs16[4]; bool cok[4];
+    const int r0 = lane >> 4;
+    const int64_t t_first = t_begin + (int64_t)wave * S3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = (lane & 15) ^ ((r0 << 2) | i);
+        const bool isx = ch >= 8;
+        const int n = (isx ? n2_0 : n1_0) + (ch & 7) * 8, N = isx ? N2 : N1;
+        cok[i] = n < N;
+        const bf16* base = isx ? x : dy;
+        ptr[i] = (uint64_t)reinterpret_cast<uintptr_t>(base + (t_first + 4 * i + r0) * (int64_t)N + (cok[i] ? n : 0));
+        rs16[i] = (unsigned)N * 32u;                                  // bytes per 16 rows
+    }
+    const uint64_t zero64 = (uint64_t)reinterpret_cast<uintptr_t>(g_zero_line + ((blockIdx.x * 512 + threadIdx.x) & 4095));
+    int64_t t_stage = t_first;
+    auto dma_stage = [&](int buf) {
+        const int left = (int)min((int64_t)S3, t_end - t_stage);
+        const unsigned dst = ring_addr + buf * STAGE3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = i & 3;
+            const bool ok = cok[k] && (4 * i + r0) < left;
+            glds16(ok ? ptr[k] + (uint64_t)((i >> 2) * rs16[k]) : zero64, dst + i * (4 * ROWB));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ptr[k] += (uint64_t)rs16[k] * (uint64_t)(W3 * S3 / 16);
+        t_stage += W3 * S3;
+    };
+
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int rlo = 8 * (g >> 1) + q;
+    auto frag_off = [&](int col0, int hi) {
+        const int r = rlo + 4 * hi;
+        const int c0 = (col0 + 16 * (g & 1)) >> 3;
+        const int f = ((r & 3) << 2) | ((r >> 2) & 3);
+        return r * ROWB + 16 * ((c0 + (p >> 1)) ^ f) + 8 * (p & 1);
+    };
+    int a_off[2][2], b_off[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            a_off[i][hi] = frag_off(32 * i, hi);
+            b_off[i][hi] = frag_off(64 + 32 * i, hi);
+        }
+    f32x16 acc[2][2], accb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        accb[a] = f32x16{0};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
+    }
+    const bool do_bias = dbias != nullptr && bx == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+    const int64_t slices = (t_end - t_begin + S3 - 1) / S3;
+    const int iters = (int)((slices - wave + W3 - 1) / W3);             // this wave's slices: wave, wave + 8, ...
+    if (iters > 0) dma_stage(0);
+    if (iters > 1) dma_stage(1);
+    for (int it = 0; it < iters; ++it) {
+        if (it + 1 < iters) wait_vm<8>(); else wait_vm<0>();            // this wave's own DMA of stage `it` has landed
+        const char* st = ring + (it & 1) * STAGE3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = tr_frag2(st + a_off[i][0], st + a_off[i][1], s);
+                bfr[i] = tr_frag2(st + b_off[i][0], st + b_off[i][1], s);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+        // every ds_read of this buffer has returned (the MFMAs consumed them): it may be overwritten
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (it + 2 < iters) dma_stage(it & 1);
+    }
+    // ---- fold the 8 partial tiles through LDS: part[wave][row][col] fp32 (8 x 16 KB = the whole ring)
+    const int c = lane & 31, h = lane >> 5;
+    __syncthreads();                                                    // every wave is done with its ring
+    float* part = reinterpret_cast<float*>(lds3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                part[(wave * T3 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h) * T3 + 32 * j + c] = acc[i][j][reg];
+    __syncthreads();
+    {
+        const int col = lane, n2 = n2_0 + col;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = 8 * wave + r, n1 = n1_0 + row;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < W3; ++w) v += part[(w * T3 + row) * T3 + col];
+            if (n1 < N1 && n2 < N2) atomicAdd(dw + (int64_t)n1 * N2 + n2, v);
+        }
+    }
+    if (do_bias && c == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int n1 = n1_0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (n1 < N1) atomicAdd(dbias + n1, accb[i][reg]);
+            }
+    }
+}
+
+int launch3(const bf16* dy, const bf16* x, float* dw, float* dbias, int64_t T, int N1, int N2, hipStream_t s) {
+    const size_t lds_bytes = (size_t)W3 * 2 * STAGE3;
+    static bool attr_set[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return SWIN_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    const int g1 = (N1 + T3 - 1) / T3, g2 = (N2 + T3 - 1) / T3;
+    const int64_t tiles = (int64_t)g1 * g2;
+    const int64_t slices = (T + S3 - 1) / S3;
+    // one 128 KB block per CU: as many splits as fill the chip once (development: SWIN_WGRAD3_BLOCKS), every wave with >= 2 slices
+    const int want = swin_dev_int("SWIN_WGRAD3_BLOCKS", 256);
+    int64_t splits = (want + tiles - 1) / tiles;
+    const int64_t max_splits = (slices + 2 * W3 - 1) / (2 * W3);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int64_t per = (slices + splits - 1) / splits;
+    per = ((per + W3 - 1) / W3) * W3 * S3;
+    splits = (T + per - 1) / per;
+    if (splits * tiles > (int64_t)1 << 30) return SWIN_ERR_UNSUPPORTED;
+    wgrad3_kernel<<<(unsigned)(splits * tiles), 64 * W3, lds_bytes, s>>>(dy, x, dw, dbias, T, N1, N2, per, g2, g1, (int)splits);
+    return swin_launch_status();
+}
+
+
+// ---- recorded problems (swin_wgrad_record), per device; swin_wgrad_flush launches them as grouped kernels (<= GMAX problems each).
+// The caller keeps every operand alive and unmodified until the flush and does not read the accumulators before it.
+struct Pending { const bf16* dy; const bf16* x; float* dw; float* db; int64_t T; int N1, N2; };
+std::vector<Pending> g_pending[16];
+
+int cur_device() {
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? dev : -1;
+}
+
+int launch_group(const Pending* pp, int n, hipStream_t s) {
+    static bool attr_set[16] = {};
+    const int dev = cur_device();
+    if (dev < 0) return SWIN_ERR_UNSUPPORTED;
+    const size_t lds_bytes = 2 * STAGEB;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)wgrad2_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return SWIN_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    // splits: every block should walk about the same number of stages, and the launch should have >= ~768 blocks (1.5 rounds of
+    // two per CU) unless the problems are too short for that
+    int64_t work = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t tiles = (int64_t)((pp[i].N1 + TN - 1) / TN) * ((pp[i].N2 + TN - 1) / TN);
+        work += tiles * ((pp[i].T + ST - 1) / ST);
+    }
+    const int want_blocks = swin_dev_int("SWIN_WGRADG_BLOCKS", 768);
+    int64_t L = work / want_blocks;
+    if (L < 6) L = 6;                                   // stages per block to aim for
+    GTab tab;
+    tab.n = n;
+    int64_t nblk = 0;
+    for (int i = 0; i < n; ++i) {
+        GProb& q = tab.p[i];
+        q.dy = pp[i].dy; q.x = pp[i].x; q.dw = pp[i].dw; q.db = pp[i].db; q.T = pp[i].T; q.N1 = pp[i].N1; q.N2 = pp[i].N2;
+        q.g1 = (q.N1 + TN - 1) / TN; q.g2 = (q.N2 + TN - 1) / TN; q.pad = 0;
+        const int64_t stages = (q.T + ST - 1) / ST;
+        int64_t splits = (stages + L - 1) / L;
+        if (splits < 1) splits = 1;
+        int64_t per = (stages + splits - 1) / splits * ST;
+        splits = (q.T + per - 1) / per;
+        q.per = per; q.splits = (int)splits;
+        tab.first_block[i] = (int)nblk;
+        nblk += splits * q.g1 * q.g2;
+        if (nblk > (int64_t)1 << 30) return SWIN_ERR_UNSUPPORTED;
+    }
+    tab.first_block[n] = (int)nblk;
+    wgrad2_group_kernel<<<(unsigned)nblk, 256, lds_bytes, s>>>(tab);
+    return swin_launch_status();
+}
+
 }  // namespace
 
 // Called by the C ABI entry points of csrc/wgrad_gemm.hip; SWIN_ERR_UNSUPPORTED = not this kernel's shape (the caller falls
 // back to the register-staged kernel).
 int wgrad2_linear(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2, void* stream) {
     if (N1 % 8 || N2 % 8 || T < 1) return SWIN_ERR_UNSUPPORTED;
+    // many output tiles, short t: the 64 x 64 / wave-private-ring form (a quarter of the float-atomic bytes)
+    const int form = swin_dev_int("SWIN_WGRAD_FORM", 0);            // development: 2 / 3 force a form
+    const int64_t tiles128 = (int64_t)((N1 + TN - 1) / TN) * ((N2 + TN - 1) / TN);
+    if (form == 3 || (form == 0 && tiles128 > 16 && T <= 16384))
+        return launch3((const bf16*)dy, (const bf16*)x, dw, dbias, T, N1, N2, (hipStream_t)stream);
     PlainSrc X{(const bf16*)x, N2};
     return dispatch2((const bf16*)dy, X, dw, dbias, T, N1, N2, false, (hipStream_t)stream);
 }
@@ -405,4 +686,40 @@ int wgrad2_conv3x3(const void* dy, const void* x, float* dw, float* dbias, int N
     const int64_t T = (int64_t)N * H * W;
     ConvSrc X{(const bf16*)x, H, W, Cin, 0, 0};
     return dispatch2((const bf16*)dy, X, dw, dbias, T, Cout, 9 * Cin, true, (hipStream_t)stream);
+}
+
+// ---- recording API (include/swin_hip.h)
+extern "C" int swin_wgrad_record(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2) {
+    if (!dy || !x || !dw || T <= 0 || N1 <= 0 || N2 <= 0) return SWIN_ERR_BAD_ARG;
+    if (N1 % 8 || N2 % 8) return SWIN_ERR_UNSUPPORTED;
+    const int dev = cur_device();
+    if (dev < 0) return SWIN_ERR_UNSUPPORTED;
+    g_pending[dev].push_back(Pending{(const bf16*)dy, (const bf16*)x, dw, dbias, T, N1, N2});
+    return SWIN_OK;
+}
+
+// problems recorded and not launched yet on the current device; *tiles (nullable) = their 128 x 128 output tiles in total
+extern "C" int swin_wgrad_pending(int64_t* tiles) {
+    const int dev = cur_device();
+    if (dev < 0) return 0;
+    if (tiles) {
+        int64_t t = 0;
+        for (const Pending& q : g_pending[dev]) t += (int64_t)((q.N1 + TN - 1) / TN) * ((q.N2 + TN - 1) / TN);
+        *tiles = t;
+    }
+    return (int)g_pending[dev].size();
+}
+
+extern "C" int swin_wgrad_flush(void* stream) {
+    const int dev = cur_device();
+    if (dev < 0) return SWIN_ERR_UNSUPPORTED;
+    std::vector<Pending>& v = g_pending[dev];
+    int rc = SWIN_OK;
+    for (size_t i = 0; i < v.size(); i += GMAX) {
+        const int n = (int)std::min((size_t)GMAX, v.size() - i);
+        const int st = launch_group(v.data() + i, n, (hipStream_t)stream);
+        if (st != SWIN_OK && rc == SWIN_OK) rc = st;
+    }
+    v.clear();
+    return rc;
 }

@@ -78,6 +78,8 @@ class BucketedGradReducer:
                 table[id(p)] = (v, (lambda b=b, i=i: self._on_direct(b, i)))
         mixed.register_sinks(table)
         self._sink_ids = list(table)
+        mixed.wgrad_group_enable(True)          # Linear weight gradients may be recorded and launched in groups: finish() / every
+                                                # bucket launch flushes them (mixed.side_join / fork_into)
 
     def _make_bucket(self, plist):
         n = sum(p.numel() for p in plist)
@@ -279,6 +281,7 @@ class BucketedGradReducer:
 
     def release(self):
         from . import mixed
+        mixed.wgrad_group_enable(False)
         mixed.clear_sinks(self._sink_ids)
         for h in self._hooks:
             h.remove()

@@ -206,6 +206,7 @@ def fork_into(device, target, home=None):
     """``target`` (a torch stream) waits for everything enqueued so far on ``home`` (default: the current stream) and on every
     auxiliary stream with outstanding work; none of them waits for anything.  Marks ``target`` as having work to join."""
     from ._lib import call
+    wgrad_flush()                       # recorded weight gradients write the buckets this fork is about to gather
     i = _dev_index(device)
     tp = target.cuda_stream
     hp = home.cuda_stream if home is not None else _raw_current(i)
@@ -220,8 +221,71 @@ def fork_into(device, target, home=None):
             _SIDE_DIRTY.add(k)
 
 
+# ---- grouped Linear weight gradients (csrc/wgrad_dma.hip: swin_wgrad_record / swin_wgrad_flush) ----------------------------------
+# Inside a training step with gradient sinks (ddp.BucketedGradReducer) the Linear layers do not launch their weight-gradient GEMM in
+# their own backward: they RECORD it, and a stage's worth is launched as one grouped kernel -- hundreds of output tiles per launch, so
+# no (or few) splits of the token axis and few float atomics, long loops that stream, and ~60 launches fewer per step.  Recorded
+# operands are kept alive here until the flush; every join of the streams and every bucket launch flushes first.
+_WG_ON = os.environ.get("SWIN_WGRAD_GROUP", "1") != "0"      # 0: every weight gradient in its own launch (A/B)
+_WG_ENABLED = [0]     # > 0 while a reducer with gradient sinks is alive (someone flushes before the gradients are read)
+_WG_PENDING = {}      # device index -> [problems, 128x128 tiles]
+_WG_KEEP = []
+_WG_FLUSH_TILES = int(os.environ.get("SWIN_WGRAD_GROUP_TILES", "600"))
+
+
+def wgrad_group_active():
+    return _WG_ON and _WG_ENABLED[0] > 0
+
+
+def wgrad_group_enable(on):
+    """Reference-counted by the reducers: recording is only safe while someone will flush before the gradients are read."""
+    if not on:
+        wgrad_flush()
+    _WG_ENABLED[0] = max(0, _WG_ENABLED[0] + (1 if on else -1))
+
+
+def wgrad_record(dy2, x2, dwf, dbf, *keep):
+    """Record dw += dy2^T x2 (db += column sums of dy2) for the next grouped launch; keeps the operands alive."""
+    from ._lib import call
+    N1, N2 = dy2.shape[1], x2.shape[1]
+    call("swin_wgrad_record", ctypes.c_void_p(dy2.data_ptr()), ctypes.c_void_p(x2.data_ptr()), ctypes.c_void_p(dwf.data_ptr()),
+         ctypes.c_void_p(dbf.data_ptr()) if dbf is not None else None, dy2.shape[0], N1, N2)
+    wgrad_note(dy2.device, 1, ((N1 + 127) // 128) * ((N2 + 127) // 128), dy2, x2, dwf, dbf, *keep)
+
+
+def wgrad_note(device, problems, tiles, *keep):
+    """``problems`` weight gradients (``tiles`` output tiles) were recorded on ``device`` (by wgrad_record or by swin_block_bwd);
+    ``keep``: what they read and write.  Flushes once a launch's worth has accumulated."""
+    i = _dev_index(device)
+    ent = _WG_PENDING.setdefault(i, [0, 0])
+    ent[0] += problems
+    ent[1] += tiles
+    _WG_KEEP.extend(t for t in keep if t is not None)
+    if ent[1] >= _WG_FLUSH_TILES or ent[0] >= 30:
+        wgrad_flush()
+
+
+def wgrad_flush():
+    """Launch everything recorded: on the weight-gradient stream behind the current one (fork), or on the current stream."""
+    if not _WG_PENDING:
+        return
+    from ._lib import call
+    for i, ent in list(_WG_PENDING.items()):
+        if ent[0] == 0:
+            continue
+        dev = torch.device("cuda", i)
+        with torch.cuda.device(i):
+            sp = fork_to_side(dev)                       # None: feature off -> the current stream
+            call("swin_wgrad_flush", ctypes.c_void_p(sp if sp is not None else _raw_current(i)))
+        if sp is not None:
+            side_keep(*_WG_KEEP)                         # the side stream reads them: alive until the next join
+    _WG_PENDING.clear()
+    _WG_KEEP.clear()
+
+
 def side_join():
     """The current stream of every device with outstanding side-stream work waits for it."""
+    wgrad_flush()
     if _SIDE_DIRTY:
         from ._lib import call
         for k in _SIDE_DIRTY:

@@ -619,9 +619,13 @@ class _LinearBf16(torch.autograd.Function):
             dbf = None
             if need_b:
                 dbf = bs[0] if bs is not None else torch.zeros(N1, device=x.device, dtype=torch.float32)
-            sst = mixed.fork_to_side(x2.device, dy2, x2) if ws is not None and (bs is not None or not need_b) else None
-            call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2,
-                 ctypes.c_void_p(sst) if sst is not None else _s())
+            sinks_only = ws is not None and (bs is not None or not need_b)      # nothing of it is returned through autograd
+            if sinks_only and mixed.wgrad_group_active():
+                mixed.wgrad_record(dy2, x2, dwf, dbf)                    # launched with the next group (mixed.wgrad_flush)
+            else:
+                sst = mixed.fork_to_side(x2.device, dy2, x2) if sinks_only else None
+                call("wgrad_linear_bf16", _p(dy2), _p(x2), _p(dwf), _p(dbf), dy2.shape[0], N1, N2,
+                     ctypes.c_void_p(sst) if sst is not None else _s())
             if ws is not None:
                 def finalize(ws=ws, bs=bs, w_master=w_master):
                     mixed.set_pending(w_master, None)

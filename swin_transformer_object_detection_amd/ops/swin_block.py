@@ -367,11 +367,15 @@ class _SwinBlockFn(torch.autograd.Function):
         # weight-gradient stream: only when every weight / bias accumulator of the four GEMMs is a reducer sink (a fresh
         # buffer returned through autograd would be read on the main stream)
         side = mixed.side_stream(dev)
-        if side is not None:
-            for q_ in (m_wqkv, m_wproj, m_w1, m_w2, bqkv, bproj, b1, b2, n2w, n2b, table) + ((nnw, nnb) if has_next else ()):
-                if q_ is not None and q_.requires_grad and mixed.grad_sink(q_) is None:
-                    side = None
-                    break
+        all_sinks = True
+        for q_ in (m_wqkv, m_wproj, m_w1, m_w2, bqkv, bproj, b1, b2, n2w, n2b, table) + ((nnw, nnb) if has_next else ()):
+            if q_ is not None and q_.requires_grad and mixed.grad_sink(q_) is None:
+                all_sinks = False
+                break
+        if not all_sinks:
+            side = None
+        # the four weight-gradient GEMMs are RECORDED for the next grouped launch (mixed.wgrad_flush) instead of launched here
+        record = all_sinks and mixed.wgrad_group_active() and all(a_ is not None for a_ in (a_wqkv, a_wproj, a_w1, a_w2))
         if side is not None:
             # the reductions behind attention / LayerNorm backward run on the side stream too (csrc/abi.hip): their workspaces
             # must not be the shared scratch (the next block's kernels would overwrite it under them)
@@ -390,9 +394,12 @@ class _SwinBlockFn(torch.autograd.Function):
             _ptr(a_wqkv), _ptr(a_bqkv), _ptr(a_bpad), _ptr(a_wproj), _ptr(a_bproj), _ptr(a_w1), _ptr(a_b1), _ptr(a_w2), _ptr(a_b2),
             _ptr(a_n2w), _ptr(a_n2b), _ptr(a_nnw), _ptr(a_nnb), _ptr(a_tab), _ptr(ws_attn), _ptr(ws_ln2), _ptr(ws_ln3), _ptr(gws),
             side.cuda_stream if side is not None else None)
-        iv = (ctypes.c_int64 * 7)(B, H, W, C, nH, shift, 1 if getattr(ctx, 'fused_mlp', False) else 0)
+        iv = (ctypes.c_int64 * 8)(B, H, W, C, nH, shift, 1 if getattr(ctx, 'fused_mlp', False) else 0, 1 if record else 0)
         fv = (ctypes.c_float * 1)(scale)
         call("swin_block_bwd", ptrs, iv, fv, _s())
+        if record:
+            t128 = lambda a_, b_: ((a_ + 127) // 128) * ((b_ + 127) // 128)      # noqa: E731
+            mixed.wgrad_note(dev, 4, t128(3 * C, C) + t128(C, C) + 2 * t128(4 * C, C), flat, n1, o, n2, h, dx2, dy2)
         g_bq = f_bqkv()
         g_pad = f_bpad()
         if g_pad is not None:

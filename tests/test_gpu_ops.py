@@ -424,6 +424,44 @@ def test_linear_wgrad_bf16(ops, T, N1, N2):
     close(b1.grad, b0.grad, bf16_tol(b0.grad, 2), msg="db")
 
 
+def test_linear_wgrad_grouped_launch(ops):
+    """swin_wgrad_record / swin_wgrad_flush: several Linear weight gradients of different shapes and token counts in ONE launch
+    (csrc/wgrad_dma.hip) -- widths that are not multiples of the 128-wide tile, token counts that are not multiples of the 64-row
+    stage, a problem without bias gradient, two problems accumulating into the SAME dw, and more problems than one launch's table
+    holds -- against fp32 matmuls."""
+    import ctypes
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops.functional import _p, _s, call
+    shapes = [(8000, 1536, 384), (8000, 384, 384), (2000, 768, 3072), (5003, 288, 96), (777, 96, 96), (33, 1024, 1024),
+              (8000, 384, 1536), (4100, 256, 48), (64, 8, 8)]
+    shapes = shapes + [(1500 + 7 * k, 128 + 8 * (k % 5), 96 + 8 * (k % 3)) for k in range(30)]        # > 32 problems: two launches
+    g = torch.Generator(device="cuda").manual_seed(11)
+    probs, refs = [], []
+    for k, (T, N1, N2) in enumerate(shapes):
+        dy = (torch.randn(T, N1, device="cuda", generator=g) * 0.1).bfloat16()
+        x = torch.randn(T, N2, device="cuda", generator=g).bfloat16()
+        dw = torch.zeros(N1, N2, device="cuda")
+        db = torch.zeros(N1, device="cuda") if k != 1 else None
+        probs.append((dy, x, dw, db))
+        refs.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+    # the same accumulator twice (a layer applied to two inputs)
+    dy2 = (torch.randn(900, 1536, device="cuda", generator=g) * 0.1).bfloat16()
+    x2 = torch.randn(900, 384, device="cuda", generator=g).bfloat16()
+    probs.append((dy2, x2, probs[0][2], probs[0][3]))
+    refs[0] = (refs[0][0] + dy2.float().t() @ x2.float(), refs[0][1] + dy2.float().sum(0))
+    for dy, x, dw, db in probs:
+        call("swin_wgrad_record", _p(dy), _p(x), _p(dw), _p(db), dy.shape[0], dy.shape[1], x.shape[1])
+    tiles = ctypes.c_int64(0)
+    assert _lib.lib().swin_wgrad_pending(ctypes.byref(tiles)) == len(probs) and tiles.value > 0
+    call("swin_wgrad_flush", _s())
+    assert _lib.lib().swin_wgrad_pending(None) == 0
+    torch.cuda.synchronize()
+    for (dy, x, dw, db), (rw, rb) in zip(probs[:len(shapes)], refs):
+        assert float((dw - rw).abs().max()) <= 2e-3 * float(rw.abs().max()) + 1e-4, tuple(dw.shape)
+        if db is not None:
+            assert float((db - rb).abs().max()) <= 2e-3 * float(rb.abs().max()) + 1e-3, tuple(dw.shape)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_roi_align_multilevel_group_equals_separate_calls(ops, dtype):
     """The grouped form (bbox 7x7 + mask 14x14 RoIs of one stage, one shared fp32 backward accumulator) == two separate

@@ -23,9 +23,9 @@ def timeit(fn, n=15, warm=3):
 
 
 def setenv(**kw):
-    for k in ("SWIN_WGRAD_GEN", "SWIN_WGRAD2_NBUF", "SWIN_WGRAD2_WKG", "SWIN_WGRAD2_BLOCKS", "SWIN_WGRAD2_XCD"):
+    for k in ("SWIN_WGRAD_GEN", "SWIN_WGRAD2_NBUF", "SWIN_WGRAD2_WKG", "SWIN_WGRAD2_BLOCKS", "SWIN_WGRAD2_XCD", "SWIN_WGRAD_FORM", "SWIN_WGRAD3_BLOCKS"):
         os.environ.pop(k, None)
-    if kw and kw.get("SWIN_WGRAD_GEN") != 1:
+    if kw and kw.get("SWIN_WGRAD_GEN") != 1 and "SWIN_WGRAD_FORM" not in kw:
         os.environ["SWIN_WGRAD2_FORCE"] = "1"
     else:
         os.environ.pop("SWIN_WGRAD2_FORCE", None)
@@ -45,6 +45,9 @@ for nb, kg in ((2, 1), (3, 1), (4, 1), (2, 2)):
         cfgs.append(dict(SWIN_WGRAD2_NBUF=nb, SWIN_WGRAD2_WKG=kg, SWIN_WGRAD2_BLOCKS=bl, SWIN_WGRAD2_XCD=0))
 cfgs += [dict(SWIN_WGRAD2_NBUF=2, SWIN_WGRAD2_WKG=1, SWIN_WGRAD2_BLOCKS=bl, SWIN_WGRAD2_XCD=1) for bl in (384, 512, 768)]
 cfgs += [dict(SWIN_WGRAD2_NBUF=3, SWIN_WGRAD2_WKG=1, SWIN_WGRAD2_BLOCKS=bl, SWIN_WGRAD2_XCD=1) for bl in (256, 384)]
+if os.environ.get("SWEEP_SHORT") == "1":
+    cfgs = [dict(SWIN_WGRAD_GEN=1), dict(), dict(SWIN_WGRAD_FORM=2, SWIN_WGRAD2_FORCE=1)]
+lin_cfgs = cfgs + [dict(SWIN_WGRAD_FORM=3, SWIN_WGRAD3_BLOCKS=bl) for bl in (192, 256, 320, 512)]
 
 
 def tag(c):
@@ -52,6 +55,10 @@ def tag(c):
         return "gen1"
     if not c:
         return "default"
+    if c.get("SWIN_WGRAD_FORM") == 3:
+        return f"f3b{c['SWIN_WGRAD3_BLOCKS']}"
+    if c.get("SWIN_WGRAD_FORM") == 2:
+        return "f2default"
     return f"nb{c['SWIN_WGRAD2_NBUF']}kg{c['SWIN_WGRAD2_WKG']}b{c['SWIN_WGRAD2_BLOCKS']}x{c['SWIN_WGRAD2_XCD']}"
 
 
@@ -63,7 +70,7 @@ if which in ("all", "lin"):
         ref = dy.float().t() @ x.float()
         refb = dy.float().sum(0)
         res = []
-        for c in cfgs:
+        for c in lin_cfgs:
             setenv(**c)
             dw = torch.zeros(N1, N2, device="cuda"); db = torch.zeros(N1, device="cuda")
             Fn.call("wgrad_linear_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), T, N1, N2, Fn._s())
