@@ -333,17 +333,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # One hipGraph launch per step: the ~570 launches of a step cost the host as much time as the GPU needs to
-    # run them, so the eager rate follows the host's speed.  The graph holds the same launches; learning rates / bias
-    # corrections / sampler seeds are refreshed in device memory before every replay.
-    launch_mode, graph_note = "eager", None
-    if args.graph == "on" or (args.graph == "auto" and world == 1 and dtype != torch.float32):
+    # Launch mode.  Eager: ~520 launches per step issued from Python on two HIP streams (weight gradients overlap
+    # the data-gradient chain) -- the host needs 8-9 ms per step for that on a fast box and 12-13 ms on a slow one, the GPU ~10.9 ms,
+    # so the eager rate follows the HOST on a slow box.  hipGraph: the whole step captured on ONE stream and replayed with a single
+    # hipGraphLaunch (0.3 ms of host time; this runtime replays single-queue graphs from pre-built packets, multi-queue graphs cost
+    # 7-9 ms of host time per launch) -- no overlap between the streams, ~11.4 ms per step on every box.  auto (one GPU): both are
+    # timed for a few steps and the faster one runs the measurement.
+    eager_step = step
+    launch_mode, graph_note, mode_trials = "eager", None, None
+
+    def time_steps(fn, n):
+        fn(); barrier()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        return (time.perf_counter() - t_) / n * 1e3
+
+    want_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and dtype != torch.float32)
+    if want_graph:
         try:
+            for _ in range(3):
+                eager_step()                    # GEMM plans, scratch buffers, optimizer tables
+            t_eager = time_steps(eager_step, 6) if args.graph == "auto" else None
             from swin_transformer_object_detection_amd.graph_step import GraphedTrainStep
-            gstep = GraphedTrainStep(model, reducer, optim, warmup=3, capture_collectives=world > 1)
-            gstep(batch)                        # 3 eager steps, capture, first replay
-            step = lambda: gstep(batch)         # noqa: E731
-            launch_mode = "hipgraph"
+            side_was = mixed.side_enabled()
+            mixed.set_side_enabled(False)       # a single-queue graph: this runtime's fast replay path
+            gstep = GraphedTrainStep(model, reducer, optim, warmup=2, capture_collectives=world > 1)
+            gstep(batch)                        # 2 eager steps on one stream, capture, first replay
+            graph_step = lambda: gstep(batch)   # noqa: E731
+            t_graph = time_steps(graph_step, 6)
+            mode_trials = {"eager_two_streams_ms": None if t_eager is None else round(t_eager, 3), "hipgraph_one_stream_ms": round(t_graph, 3)}
+            if t_eager is None or t_graph <= t_eager:
+                step, launch_mode = graph_step, "hipgraph"
+            else:
+                mixed.set_side_enabled(side_was)
         except Exception as e:                  # noqa: BLE001 -- report and measure the eager step instead
             graph_note = f"capture failed, eager step measured: {type(e).__name__}: {e}"[:400]
             torch.cuda.synchronize()
@@ -393,7 +417,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             # how the step was issued, and the host's share of it: host_enqueue_ms = host time to issue one step (no waiting),
             # ms_per_step = until the GPU has finished it.  host_enqueue_ms ~ ms_per_step means the host, not the GPU, set the rate.
-            "launch_mode": launch_mode, "graph_note": graph_note,
+            "launch_mode": launch_mode, "graph_note": graph_note, "mode_trials": mode_trials,
             "host_enqueue_ms": round(1000 * t_enq / args.steps, 3), "gpu_ms": round(1000 * elapsed / args.steps, 3),
             "config": {"workload": workload_desc,
                        "global_batch": gb, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},

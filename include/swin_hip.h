@@ -310,6 +310,20 @@ int swin_adamw_step_dev(const void* segs, const void* chunks, int n_chunks, cons
 int64_t swin_gemm_workspace_bytes(void);
 int swin_gemm_bf16(const void* a, const void* b, const void* bias, void* c, int64_t M, int N, int K, int b_layout,
                    void* workspace, void* stream);
+/* swin_linear_hip_bf16: the same GEMM on the hand-written MFMA kernel of csrc/conv_gemm.hip (128 x 128 x 64 tiles, LDS-DMA):
+ *   c (M,N) bf16 = a (M,K) bf16 x w (N,K)^T + bias (N) f32 (nullable), ReLU when relu != 0.  K % 64 == 0, N % 4 == 0. */
+int swin_linear_hip_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int relu,
+                         void* stream);
+/* The two GELU-fused GEMMs of Mlp (swin_transformer.py:32-38) for the widths csrc/ts_mlp.hip does not cover (C >= 256 and every Swin-B
+ * width), on the same hand-written kernel, so that no pass over a T x 4C tensor is spent on the activation:
+ *   swin_linear_gelu_hip_bf16 : hpre (M,N) = a (M,K) w (N,K)^T (no bias: the pre-activation the backward reads); h (M,N) = gelu_erf(that + bias)
+ *   swin_linear_dgelu_hip_bf16: dhpre (M,N) = (dy (M,K) wt (N,K)^T) * gelu_erf'(hpre + bias), wt = the TRANSPOSED fc2 weight (4C, C)
+ *   linear_t_layout_multi     : dsts[k] (cols, rows) = srcs[k] (rows, cols)^T, bf16, n matrices per call (HOST arrays) -- those
+ *                               transposed weights, rebuilt once per optimizer step.   K % 64 == 0, N % 4 == 0; bias (N) f32. */
+int swin_linear_gelu_hip_bf16(const void* a, const void* w, const float* bias, void* hpre, void* h, int64_t M, int N, int K, void* stream);
+int swin_linear_dgelu_hip_bf16(const void* dy, const void* wt, const void* hpre, const float* bias, void* dhpre, int64_t M, int N, int K,
+                               void* stream);
+int linear_t_layout_multi(const void* const* srcs, void* const* dsts, const int* rows, const int* cols, int n, void* stream);
 /* A plan's algorithm is chosen by timing the library's candidates on first use, so two data-parallel ranks may choose
  * differently.  swin_gemm_plans_export: records of 6 int64 {M, N, K, b_layout, has_bias, chosen candidate index} of the current
  * device's plans into HOST memory `out` (capacity `cap` records); returns the number of plans.  swin_gemm_plans_import: select the

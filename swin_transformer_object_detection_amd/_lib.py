@@ -70,6 +70,10 @@ SIGNATURES = {
     "swin_adamw_chunk_elems": [],
     "swin_adamw_set_state": [_p, _p, _p, _i, _f, _f, _p],
     "swin_adamw_step_dev": [_p, _p, _i, _p, _f, _f, _f, _p],
+    "swin_linear_hip_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],
+    "swin_linear_gelu_hip_bf16": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
+    "swin_linear_dgelu_hip_bf16": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
+    "linear_t_layout_multi": [_p, _p, _p, _p, _i, _p],
     "swin_gemm_plans_export": [_p, _i],
     "swin_gemm_plans_import": [_p, _i],
     "det_rpn_loss_fwd": [_p, _p, _i, _i64, _i, _p, _p, _p, _f, _p, _i, _p],

@@ -38,8 +38,13 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
     if (iv[6]) {
         CHK(swin_mlp_fwd_bf16(p[24], p[13], (const float*)p[14], p[15], (const float*)p[35], const_cast<void*>(p[29]), T, C, stream));
     } else {
-        CHK(swin_gemm_bf16(p[24], p[13], nullptr, const_cast<void*>(p[27]), T, 4 * C, C, 0, ws, stream));
-        CHK(swin_bias_gelu_fwd(p[27], (const float*)p[14], const_cast<void*>(p[28]), T, 4 * C, SWIN_BF16, stream));
+        // fc1 with the GELU in its epilogue (hand-written GEMM: hpre and h leave the kernel together) when the width allows
+        if (C % 64 == 0) {
+            CHK(swin_linear_gelu_hip_bf16(p[24], p[13], (const float*)p[14], const_cast<void*>(p[27]), const_cast<void*>(p[28]), T, 4 * C, C, stream));
+        } else {
+            CHK(swin_gemm_bf16(p[24], p[13], nullptr, const_cast<void*>(p[27]), T, 4 * C, C, 0, ws, stream));
+            CHK(swin_bias_gelu_fwd(p[27], (const float*)p[14], const_cast<void*>(p[28]), T, 4 * C, SWIN_BF16, stream));
+        }
         CHK(swin_gemm_bf16(p[28], p[15], p[16], const_cast<void*>(p[29]), T, C, 4 * C, 0, ws, stream));
     }
     if (p[17])
@@ -63,6 +68,8 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
 //  fp32 gradient accumulators (null = not wanted): 37 dWqkv 38 dbqkv 39 dbqkv_pad 40 dWproj 41 dbproj 42 dW1 43 db1 44 dW2
 //          45 db2 46 dn2w 47 dn2b 48 dnnw 49 dnnb 50 dtable
 //  workspaces: 51 attention backward  52 LayerNorm backward (norm2)  53 LayerNorm backward (next norm)  54 gemm
+//  56 w2t|null: the TRANSPOSED fc2 weight (4C, C) -- with it (and C % 64 == 0, no fused MLP) the fc2 data gradient and the GELU backward are
+//     ONE launch (swin_linear_dgelu_hip_bf16), dh (30) is never written and db1 (43) comes from the dW1 launch
 //  55 weight-gradient stream (a hipStream_t, or null = `stream`): the four weight-gradient GEMMs are enqueued there, each
 //     after an event recorded on `stream` behind the kernel that produced its dY operand; the caller joins the two
 //     streams before anything reads the accumulators and keeps the operands alive until then.
@@ -92,7 +99,11 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     auto M = [&](int i) { return const_cast<void*>(p[i]); };
     const void* dx1 = p[28];
     const void* dy2 = p[29];
-    if ((p[45] && !p[44]) || (p[43] && iv[6] && !p[42]) || (p[41] && !p[40]) || (p[38] && !p[37])) return SWIN_ERR_UNSUPPORTED;
+    // GELU backward in the epilogue of the fc2 data-gradient GEMM (entry 56 = the transposed fc2 weight): db1 then comes from the dW1
+    // launch, as with the fused MLP
+    const bool gelu_epi = !iv[6] && p[56] && C % 64 == 0;
+    const bool db1_from_wgrad = iv[6] || gelu_epi;
+    if ((p[45] && !p[44]) || (p[43] && db1_from_wgrad && !p[42]) || (p[41] && !p[40]) || (p[38] && !p[37])) return SWIN_ERR_UNSUPPORTED;
     if (p[21]) {                              // second residual + next norm
         if (!p[25] || !p[48] || !p[49]) return SWIN_ERR_BAD_ARG;
         CHK(swin_layernorm_bwd(p[25], p[11], (const float*)p[21], (const float*)p[12], (const float*)p[13], p[24], M(28),
@@ -109,8 +120,12 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
         hbuf = p[30];
     } else {
         // fc2: dh = dy2 w2; GELU; fc1: dn2 = dhpre w1
-        CHK(swin_gemm_bf16(dy2, p[19], nullptr, M(30), T, 4 * C, C, 1, gws, stream));
-        CHK(swin_bias_gelu_bwd(p[30], p[9], (const float*)p[22], M(31), (float*)p[43], T, 4 * C, SWIN_BF16, stream));
+        if (gelu_epi) {
+            CHK(swin_linear_dgelu_hip_bf16(dy2, p[56], p[9], (const float*)p[22], M(31), T, 4 * C, C, stream));
+        } else {
+            CHK(swin_gemm_bf16(dy2, p[19], nullptr, M(30), T, 4 * C, C, 1, gws, stream));
+            CHK(swin_bias_gelu_bwd(p[30], p[9], (const float*)p[22], M(31), (float*)p[43], T, 4 * C, SWIN_BF16, stream));
+        }
         CHK(swin_gemm_bf16(p[31], p[18], nullptr, M(32), T, C, 4 * C, 1, gws, stream));
         hbuf = p[10];
     }
@@ -140,13 +155,13 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     else if (side) CHK(swin_fork_stream(stream, side));
     if (record) {                 // iv[7]: recorded for the caller's next grouped launch (swin_wgrad_flush) instead of four launches here
         if (p[44]) CHK(swin_wgrad_record(dy2, hbuf, (float*)p[44], (float*)p[45], T, C, 4 * C));
-        if (p[42]) CHK(swin_wgrad_record(p[31], p[8], (float*)p[42], iv[6] ? (float*)p[43] : nullptr, T, 4 * C, C));
+        if (p[42]) CHK(swin_wgrad_record(p[31], p[8], (float*)p[42], db1_from_wgrad ? (float*)p[43] : nullptr, T, 4 * C, C));
         if (p[40]) CHK(swin_wgrad_record(dy, p[4], (float*)p[40], (float*)p[41], T, C, C));
         if (p[37]) CHK(swin_wgrad_record(p[35], p[0], (float*)p[37], (float*)p[38], T, 3 * C, C));
         return SWIN_OK;
     }
     if (p[44]) CHK(wgrad_linear_bf16(dy2, hbuf, (float*)p[44], (float*)p[45], T, C, 4 * C, wst));                           // fc2
-    if (p[42]) CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], iv[6] ? (float*)p[43] : nullptr, T, 4 * C, C, wst));       // fc1
+    if (p[42]) CHK(wgrad_linear_bf16(p[31], p[8], (float*)p[42], db1_from_wgrad ? (float*)p[43] : nullptr, T, 4 * C, C, wst));       // fc1
     if (p[40]) CHK(wgrad_linear_bf16(dy, p[4], (float*)p[40], (float*)p[41], T, C, C, wst));                                // proj
     if (p[37]) CHK(wgrad_linear_bf16(p[35], p[0], (float*)p[37], (float*)p[38], T, 3 * C, C, wst));                         // qkv
     return SWIN_OK;

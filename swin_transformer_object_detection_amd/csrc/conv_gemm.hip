@@ -68,6 +68,19 @@ struct ConvA {
     }
 };
 
+// Plain row-major A (M, K): the token-major activations of the Linear layers (swin_transformer.py:33,36,129,151,296) -- the same
+// kernel as a GEMM  C = A Wt^T.  One "tap" that is always inside.
+struct PlainA {
+    const bf16* a; int64_t M; int K;
+    __device__ __forceinline__ void prep(int64_t m, int64_t& base, int& y, int& x) const { y = x = 0; base = m < M ? m * K : -1; }
+    __device__ __forceinline__ unsigned tapmask(int64_t base, int, int) const { return base < 0 ? 0u : 1u; }
+    struct Cur { int tap, c; };
+    __device__ __forceinline__ void seek(int kt, Cur& q) const { q.tap = 0; q.c = kt; }
+    __device__ __forceinline__ int64_t koff(const Cur& q) const { return (int64_t)q.c * BK; }
+    __device__ __forceinline__ int ktile(const Cur& q) const { return q.c; }
+    __device__ __forceinline__ void next(Cur& q) const { ++q.c; }
+};
+
 __device__ __forceinline__ int swz(int row, int piece) { return piece ^ ((row >> 1) & 7); }
 
 __device__ uint4 g_zero16[4];      // zero-initialised: source of padded 16-byte pieces
@@ -86,11 +99,23 @@ __device__ __forceinline__ void glds16(uint64_t gsrc, unsigned lds_addr) {
 // WM = wave rows of the block: tile (64 WM) x 128 x 64 with 2 WM waves.  WM = 2 is the 128x128 tile (two blocks per
 // CU); WM = 4 doubles the pixel rows per weight tile (one 8-wave block per CU): 48 KB instead of 64 KB of operand
 // traffic per 4.2 MFLOP, for the large maps where the L2 -> LDS stream is the limit.
-template <typename ALoader, bool RELU, int WM, int NBUF>
+// EPI (epilogue): 0 = bias (+ ReLU, + gate);  1 = the fc1 of Mlp (swin_transformer.py:33-34): C = the product without bias (the
+// pre-activation the backward reads), C2 = gelu_erf(product + bias);  2 = the data gradient through that GELU: C = product *
+// gelu'(gate + bias), `gate` here being the saved pre-activation (no separate pass over the T x 4C tensors either way).  The
+// product is rounded to bf16 BEFORE the activation, as in the reference under autocast (the Linear's output is a half tensor) and
+// as the three-launch chain GEMM -> bias_gelu does: the two paths give the same bits.
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float v) {
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    return cdf + v * 0.39894228040143267794f * __expf(-0.5f * v * v);
+}
+
+template <typename ALoader, bool RELU, int WM, int NBUF, int EPI = 0>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2 : 1)) : 1) void gemm_bf16_kernel(ALoader A, const bf16* __restrict__ Wt,
                                                                               const float* __restrict__ bias, bf16* __restrict__ C,
                                                                               int64_t M, int Nn, int K, int mtiles, int ntiles,
-                                                                              const bf16* __restrict__ gate, float* __restrict__ part, int ksplit) {
+                                                                              const bf16* __restrict__ gate, float* __restrict__ part, int ksplit,
+                                                                              bf16* __restrict__ C2 = nullptr) {
     constexpr int TM = 64 * WM;                                          // tile rows (pixels)
     extern __shared__ __attribute__((aligned(16))) uint4 lds_raw[];      // [buf][A: TM*8 | W: BN*8]
     auto ldsA = [&](int buf) { return lds_raw + (size_t)buf * (TM + BN) * 8; };
@@ -288,16 +313,27 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
                 int n = n0 + wn * 64 + 16 * nt + 4 * fq;            // C layout: row (= n) = 4 fq + j, column (= m) = fr
                 if (n >= Nn) continue;
                 bf16x4 o;
+                if constexpr (EPI == 1) {
+                    bf16x4 o2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc16[nt][mt][e] + (bias ? bias[n + e] : 0.f);
-                    if (RELU) v = fmaxf(v, 0.f);
-                    o[e] = (bf16)v;
-                }
-                if (gate) {                       // ReLU backward of the layer below: zero where its output was not positive
-                    const bf16x4 gt = *(const bf16x4*)(gate + m * Nn + n);
+                    for (int e = 0; e < 4; ++e) { o[e] = (bf16)acc16[nt][mt][e]; o2[e] = (bf16)gelu_erf((float)o[e] + bias[n + e]); }
+                    *(bf16x4*)(C2 + m * Nn + n) = o2;
+                } else if constexpr (EPI == 2) {
+                    const bf16x4 hp = *(const bf16x4*)(gate + m * Nn + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (!((float)gt[e] > 0.f)) o[e] = (bf16)0.f;
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)((float)(bf16)acc16[nt][mt][e] * gelu_erf_grad((float)hp[e] + bias[n + e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc16[nt][mt][e] + (bias ? bias[n + e] : 0.f);
+                        if (RELU) v = fmaxf(v, 0.f);
+                        o[e] = (bf16)v;
+                    }
+                    if (gate) {                       // ReLU backward of the layer below: zero where its output was not positive
+                        const bf16x4 gt = *(const bf16x4*)(gate + m * Nn + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (!((float)gt[e] > 0.f)) o[e] = (bf16)0.f;
+                    }
                 }
                 *(bf16x4*)(crow + n) = o;
             }
@@ -335,16 +371,30 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
                 int n = n0 + wn * 64 + 32 * nt + 8 * gq + 4 * h;
                 if (n >= Nn) continue;
                 bf16x4 o;
+                if constexpr (EPI == 1) {
+                    bf16x4 o2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[nt][mt][4 * gq + e] + (bias ? bias[n + e] : 0.f);
-                    if (RELU) v = fmaxf(v, 0.f);
-                    o[e] = (bf16)v;
-                }
-                if (gate) {
-                    const bf16x4 gt = *(const bf16x4*)(gate + m * Nn + n);
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (bf16)acc[nt][mt][4 * gq + e];
+                        o2[e] = (bf16)gelu_erf((float)o[e] + bias[n + e]);
+                    }
+                    *(bf16x4*)(C2 + m * Nn + n) = o2;
+                } else if constexpr (EPI == 2) {
+                    const bf16x4 hp = *(const bf16x4*)(gate + m * Nn + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (!((float)gt[e] > 0.f)) o[e] = (bf16)0.f;
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)((float)(bf16)acc[nt][mt][4 * gq + e] * gelu_erf_grad((float)hp[e] + bias[n + e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[nt][mt][4 * gq + e] + (bias ? bias[n + e] : 0.f);
+                        if (RELU) v = fmaxf(v, 0.f);
+                        o[e] = (bf16)v;
+                    }
+                    if (gate) {
+                        const bf16x4 gt = *(const bf16x4*)(gate + m * Nn + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (!((float)gt[e] > 0.f)) o[e] = (bf16)0.f;
+                    }
                 }
                 *(bf16x4*)(crow + n) = o;
             }
@@ -505,3 +555,64 @@ extern "C" int conv3x3_nhwc_bf16_gated(const void* x, const void* w, const float
     return gemm_launch(A, (const bf16*)w, bias, (bf16*)y, M, Cout, 9 * Cin, 0, (hipStream_t)stream, (const bf16*)gate);
 }
 
+// c (M,N) bf16 = a (M,K) bf16 x w (N,K)^T + bias (N) f32 [ReLU] on the same hand-written MFMA kernel (K % 64 == 0, N % 4 == 0):
+// nn.Linear forward, and its data gradient when `w` is the transposed weight.
+extern "C" int swin_linear_hip_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int relu,
+                                    void* stream) {
+    if (M == 0) return SWIN_OK;
+    if (!a || !w || !c || M < 0 || N <= 0 || K <= 0) return SWIN_ERR_BAD_ARG;
+    if (K % BK != 0 || N % 4 != 0) return SWIN_ERR_UNSUPPORTED;
+    PlainA A{(const bf16*)a, M, K};
+    return gemm_launch(A, (const bf16*)w, bias, (bf16*)c, M, N, K, relu, (hipStream_t)stream);
+}
+
+// The two GELU-fused GEMMs of Mlp (EPI 1 / 2) for every width the token-stationary kernel of csrc/ts_mlp.hip does not cover:
+// the same tile choice as gemm_launch, PlainA only.
+template <int EPI, int WM, int NBUF>
+static int gemm_launch_epi_wm(PlainA A, const bf16* Wt, const float* bias, bf16* C, bf16* C2, const bf16* aux, int64_t M, int Nn, int K,
+                              hipStream_t s) {
+    constexpr int TM = 64 * WM;
+    const size_t lds_bytes = NBUF * (size_t)(TM + BN) * 8 * sizeof(uint4);
+    static bool attr_set[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<PlainA, false, WM, NBUF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess)
+            return SWIN_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    const int mtiles = (int)((M + TM - 1) / TM), ntiles = (Nn + BN - 1) / BN;
+    gemm_bf16_kernel<PlainA, false, WM, NBUF, EPI><<<mtiles * ntiles, 128 * WM, lds_bytes, s>>>(A, Wt, bias, C, M, Nn, K, mtiles, ntiles, aux,
+                                                                                          nullptr, 1, C2);
+    return swin_launch_status();
+}
+
+template <int EPI>
+static int gemm_launch_epi(PlainA A, const bf16* Wt, const float* bias, bf16* C, bf16* C2, const bf16* aux, int64_t M, int Nn, int K, hipStream_t s) {
+    const int64_t blocks128 = ((M + 127) / 128) * ((Nn + BN - 1) / BN);
+    if (blocks128 > 512) return gemm_launch_epi_wm<EPI, 2, 1>(A, Wt, bias, C, C2, aux, M, Nn, K, s);
+    if (blocks128 <= 256) return gemm_launch_epi_wm<EPI, 2, 4>(A, Wt, bias, C, C2, aux, M, Nn, K, s);
+    return gemm_launch_epi_wm<EPI, 2, 2>(A, Wt, bias, C, C2, aux, M, Nn, K, s);
+}
+
+// hpre (M,N) = a (M,K) w (N,K)^T (no bias);  h (M,N) = gelu_erf(that + bias).   K % 64 == 0, N % 4 == 0.
+extern "C" int swin_linear_gelu_hip_bf16(const void* a, const void* w, const float* bias, void* hpre, void* h, int64_t M, int N, int K,
+                                         void* stream) {
+    if (M == 0) return SWIN_OK;
+    if (!a || !w || !bias || !hpre || !h || M < 0 || N <= 0 || K <= 0) return SWIN_ERR_BAD_ARG;
+    if (K % BK != 0 || N % 4 != 0) return SWIN_ERR_UNSUPPORTED;
+    PlainA A{(const bf16*)a, M, K};
+    return gemm_launch_epi<1>(A, (const bf16*)w, bias, (bf16*)hpre, (bf16*)h, nullptr, M, N, K, (hipStream_t)stream);
+}
+
+// dhpre (M,N) = (dy (M,K) wt (N,K)^T) * gelu_erf'(hpre + bias): the data gradient through fc2 and the GELU in one launch; wt is the
+// TRANSPOSED fc2 weight ((4C, C): linear_t_layout_multi).  K % 64 == 0, N % 4 == 0.
+extern "C" int swin_linear_dgelu_hip_bf16(const void* dy, const void* wt, const void* hpre, const float* bias, void* dhpre, int64_t M,
+                                          int N, int K, void* stream) {
+    if (M == 0) return SWIN_OK;
+    if (!dy || !wt || !hpre || !bias || !dhpre || M < 0 || N <= 0 || K <= 0) return SWIN_ERR_BAD_ARG;
+    if (K % BK != 0 || N % 4 != 0) return SWIN_ERR_UNSUPPORTED;
+    PlainA A{(const bf16*)dy, M, K};
+    return gemm_launch_epi<2>(A, (const bf16*)wt, bias, (bf16*)dhpre, nullptr, (const bf16*)hpre, M, N, K, (hipStream_t)stream);
+}

@@ -389,7 +389,7 @@ extern "C" int fpn_upsample_add_bwd(const void* dfine, void* dcoarse, int N, int
 struct DgradLayoutTable {
     const bf16* src[DGL_MAX];
     bf16* dst[DGL_MAX];
-    int co[DGL_MAX], ci[DGL_MAX], tile0[DGL_MAX + 1];
+    int co[DGL_MAX], ci[DGL_MAX], taps[DGL_MAX], tile0[DGL_MAX + 1];       // taps: 9 (3x3 conv, rotated) or 1 (a plain transpose)
     int n;
 };
 
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_layout_kernel(DgradLayoutTable
     __shared__ bf16 tile[32][34];
     int k = 0;
     while (k + 1 < t.n && (int)blockIdx.x >= t.tile0[k + 1]) ++k;
-    const int co = t.co[k], ci = t.ci[k];
+    const int co = t.co[k], ci = t.ci[k], taps = t.taps[k];
     const int tci = (ci + 31) / 32, tco = (co + 31) / 32;
     int id = blockIdx.x - t.tile0[k];
     const int tap = id / (tci * tco); id -= tap * (tci * tco);
@@ -408,13 +408,13 @@ __global__ __launch_bounds__(256) void conv_dgrad_layout_kernel(DgradLayoutTable
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const int o = co0 + r, i = ci0 + tx;
-        if (o < co && i < ci) tile[r][tx] = src[((size_t)o * 9 + tap) * ci + i];
+        if (o < co && i < ci) tile[r][tx] = src[((size_t)o * taps + tap) * ci + i];
     }
     __syncthreads();
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const int i = ci0 + r, o = co0 + tx;
-        if (o < co && i < ci) dst[((size_t)i * 9 + (8 - tap)) * co + o] = tile[tx][r];
+        if (o < co && i < ci) dst[((size_t)i * taps + (taps - 1 - tap)) * co + o] = tile[tx][r];
     }
 }
 
@@ -430,9 +430,34 @@ extern "C" int conv_dgrad_layout_multi(const void* const* srcs, void* const* dst
         for (int k = 0; k < t.n; ++k) {
             if (!srcs[base + k] || !dsts[base + k] || couts[base + k] <= 0 || cins[base + k] <= 0) return SWIN_ERR_BAD_ARG;
             t.src[k] = (const bf16*)srcs[base + k]; t.dst[k] = (bf16*)dsts[base + k];
-            t.co[k] = couts[base + k]; t.ci[k] = cins[base + k];
+            t.co[k] = couts[base + k]; t.ci[k] = cins[base + k]; t.taps[k] = 9;
             t.tile0[k] = tiles;
             tiles += 9 * ((t.co[k] + 31) / 32) * ((t.ci[k] + 31) / 32);
+        }
+        t.tile0[t.n] = tiles;
+        conv_dgrad_layout_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(t);
+        int st = swin_launch_status();
+        if (st != SWIN_OK) return st;
+    }
+    return SWIN_OK;
+}
+
+// dsts[k] (cols, rows) = srcs[k] (rows, cols)^T for n bf16 matrices in as few launches as the table allows (16 per launch): the
+// K-contiguous weights of the Linear layers' data-gradient GEMMs on the hand-written kernel (dx = dy W needs W^T as its
+// (N, K) operand), rebuilt once per optimizer step.
+extern "C" int linear_t_layout_multi(const void* const* srcs, void* const* dsts, const int* rows, const int* cols, int n, void* stream) {
+    if (n == 0) return SWIN_OK;
+    if (!srcs || !dsts || !rows || !cols || n < 0) return SWIN_ERR_BAD_ARG;
+    for (int base = 0; base < n; base += DGL_MAX) {
+        DgradLayoutTable t;
+        t.n = n - base < DGL_MAX ? n - base : DGL_MAX;
+        int tiles = 0;
+        for (int k = 0; k < t.n; ++k) {
+            if (!srcs[base + k] || !dsts[base + k] || rows[base + k] <= 0 || cols[base + k] <= 0) return SWIN_ERR_BAD_ARG;
+            t.src[k] = (const bf16*)srcs[base + k]; t.dst[k] = (bf16*)dsts[base + k];
+            t.co[k] = rows[base + k]; t.ci[k] = cols[base + k]; t.taps[k] = 1;
+            t.tile0[k] = tiles;
+            tiles += ((t.co[k] + 31) / 32) * ((t.ci[k] + 31) / 32);
         }
         t.tile0[t.n] = tiles;
         conv_dgrad_layout_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(t);

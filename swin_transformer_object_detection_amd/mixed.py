@@ -495,14 +495,35 @@ def conv_dgrad_weight(master, shadow):
     return _DERIVED[k]
 
 
+def linear_t_weight(master, shadow):
+    """The transposed (in, out) copy of a Linear weight's bf16 shadow -- the K-contiguous operand of its data-gradient GEMM on the
+    hand-written kernel (swin_linear_dgelu_hip_bf16): a persistent buffer that refresh_aux() rewrites for every registered weight
+    in one launch after each optimizer step.  Without a shadow (no ShadowParams): a plain transposed copy."""
+    if master is None or id(master) not in _SHADOW:
+        return shadow.detach().t().contiguous()
+    k = (id(master), 't')
+    v = _DERIVED.get(k)
+    if v is not None:
+        return v
+    ent = _AUX.get(k)
+    if ent is None or ent[0] is not shadow:
+        _AUX[k] = (shadow, torch.empty(shadow.shape[1], shadow.shape[0], device=shadow.device, dtype=shadow.dtype))
+    refresh_aux()
+    return _DERIVED[k]
+
+
 def refresh_aux():
-    """Rebuild every registered auxiliary layout from the current shadows (one multi-tensor launch) and publish them."""
+    """Rebuild every registered auxiliary layout from the current shadows (one multi-tensor launch per kind) and publish them."""
     if not _AUX:
         return
-    from .ops.functional import conv_dgrad_layout_multi
-    items = list(_AUX.items())
-    conv_dgrad_layout_multi([e[0] for _, e in items], [e[1] for _, e in items])
-    for k, e in items:
+    from .ops.functional import conv_dgrad_layout_multi, linear_t_layout_multi
+    conv = [(k, e) for k, e in _AUX.items() if k[1] == 'dgrad']
+    lin = [(k, e) for k, e in _AUX.items() if k[1] == 't']
+    if conv:
+        conv_dgrad_layout_multi([e[0] for _, e in conv], [e[1] for _, e in conv])
+    if lin:
+        linear_t_layout_multi([e[0] for _, e in lin], [e[1] for _, e in lin])
+    for k, e in conv + lin:
         _DERIVED[k] = e[1]
 
 
@@ -566,4 +587,5 @@ class ShadowParams:
             _CONST.pop(id(p), None)
         for p in self.masters:
             _AUX.pop((id(p), 'dgrad'), None)
+            _AUX.pop((id(p), 't'), None)
         _DERIVED.clear()

@@ -426,6 +426,23 @@ def conv_dgrad_layout_multi(srcs, dsts):
     call("conv_dgrad_layout_multi", sp, dp, co, ci, n, _s())
 
 
+def linear_t_layout_multi(srcs, dsts):
+    """dsts[i] (cols, rows) <- srcs[i] (rows, cols)^T for a list of contiguous bf16 matrices, in as few launches as the kernel's
+    table allows (the transposed weights of the data-gradient GEMMs on the hand-written kernel)."""
+    n = len(srcs)
+    if n == 0:
+        return
+    for s_, d_ in zip(srcs, dsts):
+        if not (s_.is_cuda and s_.dtype == torch.bfloat16 and s_.dim() == 2 and s_.is_contiguous() and d_.is_contiguous()
+                and d_.dtype == torch.bfloat16 and tuple(d_.shape) == (s_.shape[1], s_.shape[0])):
+            raise SwinHipError("linear_t_layout_multi: contiguous bf16 (rows, cols) sources and (cols, rows) outputs")
+    sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    dp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
+    rr = (ctypes.c_int * n)(*[t.shape[0] for t in srcs])
+    cc = (ctypes.c_int * n)(*[t.shape[1] for t in srcs])
+    call("linear_t_layout_multi", sp, dp, rr, cc, n, _s())
+
+
 class _Conv3x3(torch.autograd.Function):
     """Inputs: x, weight (compute-dtype leaf: the bf16 shadow or a cast of the master), bias (fp32 master), relu,
     weight_master.  The re-laid-out weights are cached per step (mixed.derived); with a reducer active the weight

@@ -709,8 +709,9 @@ def test_reducer_over_rccl_one_rank():
 @pytest.mark.parametrize("fused_mlp", [False, True])
 def test_fused_swin_block_equals_per_op_blocks(fused_mlp, monkeypatch):
     """ops/swin_block.py (one autograd node per block) against backbone._block built from the individual ops.
-    fused_mlp=False: the same kernels in the same order -> identical outputs and input gradient, parameter gradients
-    bit-exact up to the order of the fp32 atomics in the weight-gradient kernels.
+    fused_mlp=False: the same kernels in the same order (but for the GELU-backward GEMM at C = 192, see below) -> identical
+    outputs, input gradient within a few bf16 ulps, parameter gradients up to the order of the fp32 atomics in the
+    weight-gradient kernels.
     fused_mlp=True (the default of the step at C in {96, 192}): fc1 -> GELU -> fc2 is the token-stationary kernel of
     csrc/ts_mlp.hip, which keeps the hidden activation in fp32 where the three-launch chain rounds it to bf16 twice: the two
     paths then agree to a few bf16 ulps of each tensor's scale (both are checked against the fp32 oracle elsewhere)."""
@@ -752,7 +753,11 @@ def test_fused_swin_block_equals_per_op_blocks(fused_mlp, monkeypatch):
         return
     for a, b in zip(o0, o1):
         assert torch.equal(a, b)
-    assert torch.equal(gx0, gx1)
+    # the input gradient: identical kernels except at C = 192, where the runner takes the fc2 data gradient and the GELU backward as
+    # ONE launch of the hand-written GEMM (round 3) while the per-op path runs the library GEMM + bias_gelu_bwd -- two GEMM kernels
+    # may round a product differently by one bf16 ulp, which then travels through the remaining blocks
+    assert float((gx0 - gx1).norm() / gx0.norm()) <= 0.01
+    assert float((gx0 - gx1).abs().max()) <= 8 * 2.0 ** -8 * float(gx0.abs().max())
     for n in gp0:
         # without a reducer both paths hand the GEMM weight gradients back in bf16 (and the per-op path the Linear bias
         # gradients too): the fp32 atomics of the weight-gradient kernel arrive in a different order, which can flip a

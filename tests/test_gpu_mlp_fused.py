@@ -89,3 +89,43 @@ def test_mlp_fused_backward_vs_oracle(fn, T, C):
     F.linear(F.gelu(F.linear(x.float(), w1f, b1)), w2f, b2).backward(dy.float())
     np.testing.assert_allclose(dw2.numpy(), w2f.grad.numpy(), rtol=0, atol=2e-2 * float(w2f.grad.abs().max()) + 1e-3)
     np.testing.assert_allclose(dw1.numpy(), w1f.grad.numpy(), rtol=0, atol=2e-2 * float(w1f.grad.abs().max()) + 1e-3)
+
+
+# ---- every other width (Swin-T/S stages 3-4: 384, 768; Swin-B: 128 ... 1024): the GELU lives in the epilogues of the hand-written
+# GEMM (csrc/conv_gemm.hip: swin_linear_gelu_hip_bf16 / swin_linear_dgelu_hip_bf16), the transposed fc2 weight comes from
+# linear_t_layout_multi
+@pytest.mark.parametrize("T,C", [(8000, 384), (2000, 768), (1999, 128), (4097, 256), (777, 512), (130, 1024), (1, 384)])
+def test_mlp_gelu_epilogue_gemms_vs_oracle(fn, T, C):
+    x, w1, b1, w2, b2 = _case(T, C, T + C)
+    g = torch.Generator().manual_seed(T)
+    dy = (torch.randn(T, C, generator=g) * 0.5).bfloat16()
+    # oracle: Mlp.forward / backward in fp32 on the same bf16 operands, the fc1 output rounded to bf16 as under autocast
+    hpre_ref = F.linear(x.float(), w1.float()).bfloat16().float()
+    xx = (hpre_ref + b1).requires_grad_(True)
+    h_ref = F.gelu(xx)
+    dh_ref = (dy.float() @ w2.float()).bfloat16().float()                    # data gradient through fc2, a bf16 tensor under autocast
+    (h_ref * dh_ref).sum().backward()
+    dhpre_ref = xx.grad
+    xc, w1c, b1c, w2c, dyc = x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), dy.cuda()
+    hpre = torch.empty(T, 4 * C, device="cuda", dtype=torch.bfloat16)
+    h = torch.empty_like(hpre)
+    fn.call("swin_linear_gelu_hip_bf16", fn._p(xc), fn._p(w1c), fn._p(b1c), fn._p(hpre), fn._p(h), T, 4 * C, C, fn._s())
+    w2t = torch.empty(4 * C, C, device="cuda", dtype=torch.bfloat16)
+    fn.linear_t_layout_multi([w2c], [w2t])
+    assert torch.equal(w2t, w2c.t().contiguous())
+    dhpre = torch.empty_like(hpre)
+    fn.call("swin_linear_dgelu_hip_bf16", fn._p(dyc), fn._p(w2t), fn._p(hpre), fn._p(b1c), fn._p(dhpre), T, 4 * C, C, fn._s())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(hpre.float().cpu().numpy(), hpre_ref.numpy(), rtol=0, atol=_tol(hpre_ref, 1.01))
+    np.testing.assert_allclose(h.float().cpu().numpy(), h_ref.detach().numpy(), rtol=0, atol=_tol(h_ref.detach(), 2))
+    np.testing.assert_allclose(dhpre.float().cpu().numpy(), dhpre_ref.numpy(), rtol=0, atol=_tol(dhpre_ref, 2.5))
+    # and against the three-launch chain it replaces: the same bits (the product is rounded to bf16 before the activation in both)
+    ws = torch.empty(fn._lib.lib().swin_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    hp2 = torch.empty_like(hpre)
+    fn.call("swin_gemm_bf16", fn._p(xc), fn._p(w1c), None, fn._p(hp2), T, 4 * C, C, 0, fn._p(ws), fn._s())
+    h2 = torch.empty_like(hpre)
+    fn.call("swin_bias_gelu_fwd", fn._p(hp2), fn._p(b1c), fn._p(h2), T, 4 * C, fn.SWIN_BF16, fn._s())
+    torch.cuda.synchronize()
+    assert float((hp2.float() - hpre.float()).abs().max()) <= _tol(hpre_ref, 1.01)       # two GEMM kernels: at most an ulp apart
+    same = hp2 == hpre
+    assert bool((h2[same] == h[same]).all())                                               # same pre-activation -> same GELU bits
