@@ -28,6 +28,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 IMG_H, IMG_W, PER_GPU_BATCH = 800, 1280, 2
+
+
+def _HD():
+    """torch dtype of the loaded library's 16-bit type"""
+    from swin_transformer_object_detection_amd import _lib
+    return _lib.half_dtype()
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
@@ -38,7 +44,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="bf16: the headline metric.  fp16: the reference's own mixed precision (apex O1, BASELINE configs[4]) -- the "
+                         "libswin_hip_f16.so build of the same kernels plus dynamic loss scaling on the device")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the whole step as ONE hipGraph launch (graph_step.GraphedTrainStep).  auto: on one GPU (the "
                          "multi-rank step, whose all-reduces overlap backward, is issued eagerly)")
@@ -67,7 +75,7 @@ def attention_roofline(device, steps=30):
     from swin_transformer_object_detection_amd import ops
     B, H, W, C, nH = PER_GPU_BATCH, IMG_H // 4, IMG_W // 4, 96, 3
     g = torch.Generator().manual_seed(0)
-    qkv = torch.randn(B, H * W, 3 * C, generator=g).to(device=device, dtype=torch.bfloat16)
+    qkv = torch.randn(B, H * W, 3 * C, generator=g).to(device=device, dtype=_HD())
     qb = (torch.randn(3 * C, generator=g) * 0.1).to(device)
     table = (torch.randn(169, nH, generator=g) * 0.02).to(device)
     for _ in range(5):
@@ -76,7 +84,7 @@ def attention_roofline(device, steps=30):
     # the op wrapper also launches the (tiny) bias-expand kernel; time the attention launch alone through the ABI
     from swin_transformer_object_detection_amd.ops import functional as Fn
     bias_exp = ops.rel_bias_expand(table)
-    out = torch.empty(B, H * W, C, device=device, dtype=torch.bfloat16)
+    out = torch.empty(B, H * W, C, device=device, dtype=_HD())
     lse = torch.empty(B * ((H + 6) // 7) * ((W + 6) // 7) * nH, 64, device=device, dtype=torch.float32)
     scale = 32 ** -0.5
     # cache-cold: the launches rotate over four input / output sets (4 x 98 MB > the 256 MB Infinity Cache), so every launch
@@ -145,26 +153,26 @@ def gemm_rooflines(device, steps=20):
     from swin_transformer_object_detection_amd.ops import functional as Fn
     B, H, W, C = PER_GPU_BATCH, IMG_H // 4, IMG_W // 4, 256
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(B, H, W, C, generator=g).to(device=device, dtype=torch.bfloat16)
-    dy = torch.randn(B, H, W, C, generator=g).to(device=device, dtype=torch.bfloat16)
-    w = (torch.randn(C, 3, 3, C, generator=g) * 0.02).to(device=device, dtype=torch.bfloat16)
+    x = torch.randn(B, H, W, C, generator=g).to(device=device, dtype=_HD())
+    dy = torch.randn(B, H, W, C, generator=g).to(device=device, dtype=_HD())
+    w = (torch.randn(C, 3, 3, C, generator=g) * 0.02).to(device=device, dtype=_HD())
     b = torch.zeros(C, device=device)
     y = torch.empty_like(x)
     dw = torch.zeros(C, 3, 3, C, device=device)
     db = torch.zeros(C, device=device)
     T, N1, N2 = PER_GPU_BATCH * (IMG_H // 16) * (IMG_W // 16), 1536, 384
-    ldy = torch.randn(T, N1, generator=g).to(device=device, dtype=torch.bfloat16)
-    lx = torch.randn(T, N2, generator=g).to(device=device, dtype=torch.bfloat16)
+    ldy = torch.randn(T, N1, generator=g).to(device=device, dtype=_HD())
+    lx = torch.randn(T, N2, generator=g).to(device=device, dtype=_HD())
     ldw = torch.zeros(N1, N2, device=device)
     ldb = torch.zeros(N1, device=device)
     Tm, Cm = PER_GPU_BATCH * (IMG_H // 4) * (IMG_W // 4), 96
-    mx = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=torch.bfloat16)
-    mdy = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=torch.bfloat16)
-    mw1 = (torch.randn(4 * Cm, Cm, generator=g) * 0.05).to(device=device, dtype=torch.bfloat16)
-    mw2 = (torch.randn(Cm, 4 * Cm, generator=g) * 0.05).to(device=device, dtype=torch.bfloat16)
+    mx = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=_HD())
+    mdy = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=_HD())
+    mw1 = (torch.randn(4 * Cm, Cm, generator=g) * 0.05).to(device=device, dtype=_HD())
+    mw2 = (torch.randn(Cm, 4 * Cm, generator=g) * 0.05).to(device=device, dtype=_HD())
     mb1, mb2 = torch.zeros(4 * Cm, device=device), torch.zeros(Cm, device=device)
     my = torch.empty_like(mx)
-    mh = torch.empty(Tm, 4 * Cm, device=device, dtype=torch.bfloat16)
+    mh = torch.empty(Tm, 4 * Cm, device=device, dtype=_HD())
     mdh = torch.empty_like(mh)
     cases = [
         (f"ts_mlp_fwd_kernel (fused fc1+GELU+fc2, stage 1: T={Tm}, C={Cm})", 16.0 * Tm * Cm * Cm,
@@ -278,14 +286,16 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from swin_transformer_object_detection_amd import data, ddp, detector, presets
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    from swin_transformer_object_detection_amd import data, ddp, detector, mixed, presets
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    if dtype != torch.float32:
+        from swin_transformer_object_detection_amd import _lib as _swinlib
+        _swinlib.set_half_dtype(dtype)
     torch.manual_seed(0)                       # identical weights on every rank
     builder, variant, img_h, img_w, workload_desc = WORKLOADS[args.workload]
-    headline = args.workload == "mask_rcnn_swin_t"
+    headline = args.workload == "mask_rcnn_swin_t" and args.dtype == "bf16"
     model = detector.build_detector(getattr(presets, builder)(variant), compute_dtype=dtype).to(device)
     model.train()
-    from swin_transformer_object_detection_amd import mixed
     shadows = mixed.ShadowParams(model, dtype) if dtype != torch.float32 else None
     # buckets in reverse first-use order (= the order gradients arrive): with plain registration order the backbone's output norms
     # sit in the first backbone bucket and hold it back until the end of backward
@@ -297,6 +307,7 @@ def main():
     opt_cfg = presets.OPTIMIZER
     from swin_transformer_object_detection_amd.optim import FusedAdamW
     optim = FusedAdamW(build_param_groups(model, opt_cfg), lr=opt_cfg["lr"], betas=opt_cfg["betas"])      # one launch, refreshes the bf16 shadows
+    scaler = mixed.LossScaler(optim, reducer) if dtype == torch.float16 else None      # apex O1's dynamic loss scaling, on the device
     if world == 1 and os.environ.get("SWIN_EARLY_OPT", "0") == "1":
         # one process: a bucket's gradients are final as soon as its parameters have arrived -- the optimizer can run for it right
         # then, on the second stream, instead of for everything after the join at the end of backward.  Measured: no gain
@@ -317,6 +328,8 @@ def main():
         reducer.zero_grad()
         losses = model.forward_train(**batch)
         loss, log_vars = model.parse_losses(losses)
+        if scaler is not None:
+            loss = scaler.scale(loss)
         reducer.mark_backward_start()
         with torch.autograd.set_multithreading_enabled(False):    # engine on this thread: 9.4 vs 9.4-10.2 ms of host time per step (tools/host_time.py engine)
             loss.backward()
@@ -325,7 +338,11 @@ def main():
         comm["finish_ms"] = round(reducer._now() * 1e3, 3)
         comm["buckets"] = [dict(bucket=b, bytes=n, issued_ms=round(t0_ * 1e3, 3), done_ms=None if t1_ is None else round(t1_ * 1e3, 3))
                            for b, t0_, t1_, n in reducer.timeline]
+        if scaler is not None:
+            scaler.check()
         optim.step()                            # AdamW + bf16 shadow refresh, one HIP launch
+        if scaler is not None:
+            scaler.update()
         return log_vars
 
     def barrier():
@@ -359,7 +376,7 @@ def main():
             from swin_transformer_object_detection_amd.graph_step import GraphedTrainStep
             side_was = mixed.side_enabled()
             mixed.set_side_enabled(False)       # a single-queue graph: this runtime's fast replay path
-            gstep = GraphedTrainStep(model, reducer, optim, warmup=2, capture_collectives=world > 1)
+            gstep = GraphedTrainStep(model, reducer, optim, warmup=2, capture_collectives=world > 1, loss_scale=scaler)
             gstep(batch)                        # 2 eager steps on one stream, capture, first replay
             graph_step = lambda: gstep(batch)   # noqa: E731
             t_graph = time_steps(graph_step, 6)

@@ -12,8 +12,11 @@
  *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call
  *     returns immediately;
  *   - `dtype` selects the activation element type: SWIN_F32 (parity path, fp32 math)
- *     or SWIN_BF16 (bf16 storage, MFMA bf16 products, fp32 accumulation/softmax/LN
- *     statistics).  Parameters (weights, biases, LN affine, bias table) are fp32;
+ *     or SWIN_BF16 (16-bit storage, 16-bit MFMA products, fp32 accumulation/softmax/LN
+ *     statistics).  Parameters (weights, biases, LN affine, bias table) are fp32.
+ *     The library is built twice from the same sources: libswin_hip.so, in which "bf16" is
+ *     bfloat16, and libswin_hip_f16.so (-DSWIN_HALF), in which it is IEEE half (the
+ *     reference's apex O1 fp16, mmdet/apis/train.py:82-89); swin_hip_half_type() tells which;
  *   - activations are token-major: (B, H, W, C) row-major == (B*H*W, C);
  *   - return value: SWIN_OK or a SWIN_ERR_* code (nothing was launched on error).
  */
@@ -32,7 +35,7 @@ extern "C" {
 #define SWIN_ERR_LAUNCH 3       /* hipGetLastError() after launch != hipSuccess */
 
 #define SWIN_F32 0
-#define SWIN_BF16 1
+#define SWIN_BF16 1             /* the library's 16-bit type: bfloat16 in libswin_hip.so, IEEE half in libswin_hip_f16.so (-DSWIN_HALF) */
 
 #define SWIN_WINDOW 7           /* window_size of every config under configs/swin/ */
 #define SWIN_HEAD_DIM 32        /* C / num_heads in Swin-T/S/B */
@@ -40,6 +43,8 @@ extern "C" {
 
 /* ABI version, bumped on any signature change (2: det_random_sample gained seed_dev; swin_set_scratch removed). */
 int swin_hip_abi_version(void);
+/* 0: this build's 16-bit type is bfloat16; 1: IEEE half */
+int swin_hip_half_type(void);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channel dim.   Replaces nn.LayerNorm at
@@ -302,6 +307,14 @@ int swin_adamw_set_state(void* state, const float* lr, const float* weight_decay
                          float bias_correction2, void* stream);
 int swin_adamw_step_dev(const void* segs, const void* chunks, int n_chunks, const void* state, float beta1, float beta2,
                         float eps, void* stream);
+/* fp16 dynamic loss scaling on the device, in the same state block (apex O1's dynamic LossScaler, mmdet/apis/train.py:82-89: 2^16,
+ * halved on an inf / nan gradient -- that step is skipped --, doubled after 2000 clean steps).  Per step: swin_loss_scale_begin
+ * (skip = 0, grad_scale = 1 / loss scale), swin_grad_check_finite per gradient bucket (g: 16-byte aligned; skip = 1 on a non-finite
+ * value), the optimizer launch, swin_loss_scale_update.  The loss is multiplied by state[20] on the device. */
+int swin_loss_scale_begin(void* state, void* stream);
+int swin_grad_check_finite(const float* g, int64_t n, void* state, void* stream);
+int swin_loss_scale_update(void* state, float growth, float backoff, int growth_interval, float min_scale, float max_scale,
+                           void* stream);
 
 /* swin_gemm_bf16: the plain GEMMs of the path (nn.Linear forward / data gradient, swin_transformer.py:33-36,129,151,296;
  * 1x1 convs; head FCs) on hipBLASLt with cached plans -- one library launch per call, no framework dispatch.

@@ -2,9 +2,42 @@
 import ctypes
 import os
 
+import torch
+
 HERE = os.path.dirname(os.path.abspath(__file__))
-# SWIN_HIP_LIB selects an alternative build of the SAME ABI (A/B experiments); default: the in-tree library
-LIB_PATH = os.environ.get("SWIN_HIP_LIB") or os.path.join(HERE, "lib", "libswin_hip.so")
+# The library exists in two builds of the same sources and ABI (csrc/common.h): libswin_hip.so, whose 16-bit type is bfloat16, and
+# libswin_hip_f16.so (-DSWIN_HALF), whose 16-bit type is IEEE half -- the reference's mixed precision is fp16 (apex O1,
+# mmdet/apis/train.py:82-89).  A process works with ONE of them: chosen by SWIN_HALF_DTYPE=fp16 in the environment or by
+# set_half_dtype() before the library is first used (build_detector(compute_dtype=torch.float16) does that).
+_HALF = torch.float16 if os.environ.get("SWIN_HALF_DTYPE", "bf16").lower() in ("fp16", "f16", "float16", "half") else torch.bfloat16
+
+
+def _default_path():
+    return os.path.join(HERE, "lib", "libswin_hip_f16.so" if _HALF == torch.float16 else "libswin_hip.so")
+
+
+# SWIN_HIP_LIB selects an alternative build of the SAME ABI (A/B experiments, the -DSWIN_DEV build); default: the in-tree library
+LIB_PATH = os.environ.get("SWIN_HIP_LIB") or _default_path()
+
+
+def half_dtype():
+    """torch dtype of the loaded library's 16-bit type (what SWIN_BF16 means in this process)"""
+    return _HALF
+
+
+def set_half_dtype(dtype):
+    """Choose the 16-bit type of this process (torch.bfloat16 or torch.float16).  Only before the library is first used."""
+    global _HALF, LIB_PATH
+    if dtype == _HALF:
+        return
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise SwinHipError(f"the 16-bit compute type is torch.bfloat16 or torch.float16, not {dtype}")
+    if _lib is not None:
+        raise SwinHipError(f"the library is already loaded with {_HALF} as its 16-bit type; choose {dtype} before first use "
+                           "(SWIN_HALF_DTYPE=fp16, or build the model first)")
+    _HALF = dtype
+    if not os.environ.get("SWIN_HIP_LIB"):
+        LIB_PATH = _default_path()
 
 SWIN_F32, SWIN_BF16 = 0, 1
 _ERR = {1: "SWIN_ERR_BAD_ARG", 2: "SWIN_ERR_UNSUPPORTED", 3: "SWIN_ERR_LAUNCH"}
@@ -14,6 +47,7 @@ _p, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 # name -> argtypes, mirrors include/swin_hip.h one to one
 SIGNATURES = {
     "swin_hip_abi_version": [],
+    "swin_hip_half_type": [],
     "swin_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _i, _p],
     "swin_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i, _i, _p, _p],
     "swin_layernorm_bwd_workspace_bytes": [_i64, _i, _i],
@@ -70,6 +104,9 @@ SIGNATURES = {
     "swin_adamw_chunk_elems": [],
     "swin_adamw_set_state": [_p, _p, _p, _i, _f, _f, _p],
     "swin_adamw_step_dev": [_p, _p, _i, _p, _f, _f, _f, _p],
+    "swin_loss_scale_begin": [_p, _p],
+    "swin_grad_check_finite": [_p, _i64, _p, _p],
+    "swin_loss_scale_update": [_p, _f, _f, _i, _f, _f, _p],
     "swin_linear_hip_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],
     "swin_linear_gelu_hip_bf16": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
     "swin_linear_dgelu_hip_bf16": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
@@ -126,6 +163,8 @@ def lib():
             fn = getattr(l, name)          # AttributeError here == header/library mismatch
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, _i)
+        if l.swin_hip_half_type() != (1 if _HALF == torch.float16 else 0):
+            raise SwinHipError(f"{LIB_PATH} was built for the other 16-bit type than {_HALF}")
         _lib = l
     return _lib
 

@@ -20,6 +20,8 @@ The module itself is glue: submodules only hold parameters under the reference's
 import math
 
 import torch
+
+from ._lib import half_dtype as _H
 import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
@@ -148,6 +150,9 @@ class SwinTransformer(nn.Module):
         self.num_layers = len(depths)
         self.embed_dim, self.ape, self.patch_norm = embed_dim, ape, patch_norm
         self.out_indices, self.frozen_stages = out_indices, frozen_stages
+        if compute_dtype in (torch.bfloat16, torch.float16):
+            from . import _lib
+            _lib.set_half_dtype(compute_dtype)    # the process's 16-bit type (and library build)
         self.compute_dtype = compute_dtype
         self.fused_blocks = True       # one autograd node per block on the bf16 GPU path (ops/swin_block.py)
         self._dp_replay = None
@@ -272,7 +277,7 @@ class SwinTransformer(nn.Module):
         dt = self.compute_dtype
         a = blk.attn
         L = H * W
-        if (self.fused_blocks and dt == torch.bfloat16 and x.is_cuda and a.qkv.bias is not None and blk.mlp.fc1.bias is not None
+        if (self.fused_blocks and dt == _H() and x.is_cuda and a.qkv.bias is not None and blk.mlp.fc1.bias is not None
                 and B * L >= ops.functional._MIN_T and blk.dim % 8 == 0):
             # the same kernels in the same order inside ONE autograd node (ops/swin_block.py): host overhead only
             from .ops.swin_block import swin_block

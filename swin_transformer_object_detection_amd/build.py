@@ -35,15 +35,21 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False, dev=False):
+def build_all(force=False, verbose=False):
+    """both shipped builds: libswin_hip.so (16-bit type = bfloat16) and libswin_hip_f16.so (-DSWIN_HALF: IEEE half)"""
+    return build_library(force, verbose), build_library(force, verbose, half=True)
+
+
+def build_library(force=False, verbose=False, dev=False, half=False):
     """dev=True (or SWIN_DEV_BUILD=1 in the environment): a -DSWIN_DEV build in lib/libswin_hip_dev.so -- the only build in which
     the kernels' launchers read SWIN_* environment variables (geometry sweeps, A/B switches, ablation instantiations).  Select it
     with SWIN_HIP_LIB=<path>; the shipped lib/libswin_hip.so never reads the environment."""
     dev = dev or os.environ.get("SWIN_DEV_BUILD") == "1"
     hipcc = _hipcc()
-    objdir = os.path.join(LIBDIR, "obj_dev" if dev else "obj")
-    lib_path = os.path.join(LIBDIR, "libswin_hip_dev.so") if dev else LIB
-    flags = FLAGS + (["-DSWIN_DEV"] if dev else [])
+    tag = ("_f16" if half else "") + ("_dev" if dev else "")
+    objdir = os.path.join(LIBDIR, "obj" + tag)
+    lib_path = os.path.join(LIBDIR, f"libswin_hip{tag}.so") if tag else LIB
+    flags = FLAGS + (["-DSWIN_DEV"] if dev else []) + (["-DSWIN_HALF"] if half else [])
     os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
@@ -74,4 +80,7 @@ def build_library(force=False, verbose=False, dev=False):
 
 if __name__ == "__main__":
     import sys
-    print(build_library(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))
+    if "--dev" in sys.argv or "--half" in sys.argv:
+        print(build_library(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv, half="--half" in sys.argv))
+    else:
+        print(build_all(force="--force" in sys.argv, verbose=True))

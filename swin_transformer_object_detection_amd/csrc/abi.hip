@@ -4,6 +4,13 @@
 #include "common.h"
 #include <cstdlib>
 extern "C" int swin_hip_abi_version(void) { return 2; }
+extern "C" int swin_hip_half_type(void) {
+#ifdef SWIN_HALF
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 // ---- second stream for work that nothing on the main stream waits for ------------------------------------------------------
 // Per device: while an auxiliary stream is set, the entry points that end in a small REDUCTION nobody on the main stream

@@ -5,10 +5,39 @@
 
 #include "../../include/swin_hip.h"
 
+// The 16-bit storage / MFMA-operand type.  The library is built TWICE from these sources: libswin_hip.so with bfloat16 and
+// libswin_hip_f16.so (-DSWIN_HALF) with IEEE half -- the reference's mixed precision is fp16 (apex O1, mmdet/apis/train.py:82-89;
+// configs/swin/mask_rcnn_swin_small_*: use_fp16=True).  The two 16-bit MFMA forms have the same shape, rate and operand maps on
+// gfx950, so nothing but the element type, the MFMA / transposed-read builtins and the library GEMM's type enum differs; the type
+// keeps the name `bf16` in the sources ("the 16-bit type"), and SWIN_BF16 as a dtype code means "the library's 16-bit type".
+#ifdef SWIN_HALF
+typedef _Float16 bf16;
+#define SWIN_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define SWIN_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define SWIN_HIP_R_16 HIP_R_16F
+#else
 typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#define SWIN_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define SWIN_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define SWIN_HIP_R_16 HIP_R_16BF
+#endif
+typedef __attribute__((ext_vector_type(8))) bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) bf16 bf16x2;
+
+// ds_read_b64_tr_b16 (guide T10) for the library's 16-bit type: p = this lane's 8-byte-aligned LDS address
+typedef __attribute__((address_space(3))) bf16x4 swin_lds_h4;
+__device__ __forceinline__ bf16x4 swin_ds_read_tr16(swin_lds_h4* p) {
+#ifdef SWIN_HALF
+    typedef __fp16 swin_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    typedef __attribute__((address_space(3))) swin_fp16x4 swin_lds_fp16x4;
+    const swin_fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((swin_lds_fp16x4*)p);
+    return __builtin_bit_cast(bf16x4, v);
+#else
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p);
+#endif
+}
+#define SWIN_DS_READ_TR16(p) swin_ds_read_tr16((swin_lds_h4*)(p))
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        acc16[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc16[nt][mt], 0, 0, 0);
+                        acc16[nt][mt] = SWIN_MFMA_16x16x32(wf[nt], af[mt], acc16[nt][mt], 0, 0, 0);
             }
         } else {
             // two fragment sets: the reads of k-step s+1 are in flight under the MFMAs of step s (these variants run one or two
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? (NBUF == 1 ? 4 : (NBUF == 2 ? 2
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][nt], af[s & 1][mt], acc[nt][mt], 0, 0, 0);
+                        acc[nt][mt] = SWIN_MFMA_32x32x16(wf[s & 1][nt], af[s & 1][mt], acc[nt][mt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -90,17 +90,17 @@ Plan* get_plan(int64_t M, int N, int K, int layout, int bias, const void* a = nu
     hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
     if (bias) {
         const uint32_t ep = HIPBLASLT_EPILOGUE_BIAS;
-        const int32_t bt = HIP_R_16BF;
+        const int32_t bt = SWIN_HIP_R_16;
         hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep));
         hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
     }
     bool good = true;
     if (layout == 0)   // B given as (N,K) row-major = (K,N) column-major, transposed by the op
-        good &= hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, (uint64_t)K, (uint64_t)N, K) == HIPBLAS_STATUS_SUCCESS;
+        good &= hipblasLtMatrixLayoutCreate(&p.a, SWIN_HIP_R_16, (uint64_t)K, (uint64_t)N, K) == HIPBLAS_STATUS_SUCCESS;
     else               // B given as (K,N) row-major = (N,K) column-major
-        good &= hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, (uint64_t)N, (uint64_t)K, N) == HIPBLAS_STATUS_SUCCESS;
-    good &= hipblasLtMatrixLayoutCreate(&p.b, HIP_R_16BF, (uint64_t)K, (uint64_t)M, K) == HIPBLAS_STATUS_SUCCESS;
-    good &= hipblasLtMatrixLayoutCreate(&p.c, HIP_R_16BF, (uint64_t)N, (uint64_t)M, N) == HIPBLAS_STATUS_SUCCESS;
+        good &= hipblasLtMatrixLayoutCreate(&p.a, SWIN_HIP_R_16, (uint64_t)N, (uint64_t)K, N) == HIPBLAS_STATUS_SUCCESS;
+    good &= hipblasLtMatrixLayoutCreate(&p.b, SWIN_HIP_R_16, (uint64_t)K, (uint64_t)M, K) == HIPBLAS_STATUS_SUCCESS;
+    good &= hipblasLtMatrixLayoutCreate(&p.c, SWIN_HIP_R_16, (uint64_t)N, (uint64_t)M, N) == HIPBLAS_STATUS_SUCCESS;
     if (!good) return nullptr;
     hipblasLtMatmulPreference_t pref;
     if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return nullptr;

@@ -106,3 +106,61 @@ extern "C" int swin_set_u64(void* dst, uint64_t value, void* stream) {
 }
 
 extern "C" int swin_adamw_chunk_elems(void) { return ADAM_CHUNK; }
+
+// ---- fp16 dynamic loss scaling on the device (the reference trains with apex O1: mmdet/apis/train.py:82-89 -> apex.amp's
+// LossScaler("dynamic"): scale 2^16, halved when a step's gradients hold an inf / nan -- that step is skipped --, doubled after 2000
+// clean steps).  Everything lives in the optimizer's device-resident state (layout above), so no step waits for the host:
+//   swin_loss_scale_begin : skip = 0, grad_scale = 1 / loss_scale          (before the gradients are checked)
+//   swin_grad_check_finite: skip = 1 if any of g[0..n) is not finite       (one call per gradient bucket)
+//   swin_loss_scale_update: after the optimizer launch -- skipped step: scale *= backoff, counter = 0; clean step: counter += 1 and
+//                           scale *= growth once it reaches growth_interval; the scale stays within [min_scale, max_scale].
+__global__ void loss_scale_begin_kernel(AdamState* st) {
+    st->skip = 0.f;
+    st->grad_scale = 1.f / st->loss_scale;
+}
+
+__global__ __launch_bounds__(256) void grad_check_kernel(const float4* __restrict__ g, int64_t n4, const float* __restrict__ tail, int ntail,
+                                                         AdamState* st) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = g[i];
+        // x - x is 0 for finite x and nan for inf / nan
+        const float z = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+        bad |= !(z == 0.f);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) { const float t = tail[threadIdx.x]; bad |= !((t - t) == 0.f); }
+    if (__any(bad) && (threadIdx.x & 63) == 0) st->skip = 1.f;      // a plain store of the same value from every wave that saw one
+}
+
+__global__ void loss_scale_update_kernel(AdamState* st, float growth, float backoff, float interval, float lo, float hi) {
+    float s = st->loss_scale, good = st->good_steps;
+    if (st->skip != 0.f) { s *= backoff; good = 0.f; }
+    else { good += 1.f; if (good >= interval) { s *= growth; good = 0.f; } }
+    st->loss_scale = fminf(fmaxf(s, lo), hi);
+    st->good_steps = good;
+}
+
+extern "C" int swin_loss_scale_begin(void* state, void* stream) {
+    if (!state) return SWIN_ERR_BAD_ARG;
+    loss_scale_begin_kernel<<<1, 1, 0, (hipStream_t)stream>>>((AdamState*)state);
+    return swin_launch_status();
+}
+
+extern "C" int swin_grad_check_finite(const float* g, int64_t n, void* state, void* stream) {
+    if (n == 0) return SWIN_OK;
+    if (!g || n < 0 || !state || ((uintptr_t)g & 15)) return SWIN_ERR_BAD_ARG;
+    const int64_t n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    grad_check_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4*)g, n4, g + n4 * 4, (int)(n - n4 * 4), (AdamState*)state);
+    return swin_launch_status();
+}
+
+extern "C" int swin_loss_scale_update(void* state, float growth, float backoff, int growth_interval, float min_scale, float max_scale,
+                                      void* stream) {
+    if (!state || growth < 1.f || backoff <= 0.f || backoff > 1.f || growth_interval < 1 || !(min_scale > 0.f) || max_scale < min_scale)
+        return SWIN_ERR_BAD_ARG;
+    loss_scale_update_kernel<<<1, 1, 0, (hipStream_t)stream>>>((AdamState*)state, growth, backoff, (float)growth_interval, min_scale, max_scale);
+    return swin_launch_status();
+}

@@ -28,7 +28,7 @@ namespace {
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    return SWIN_MFMA_32x32x16(a, b, c, 0, 0, 0);
 }
 
 // swap bits 2 and 3 of a row index (an involution on 0..15, applied inside each 16-row group)
@@ -75,8 +75,8 @@ __device__ __forceinline__ bf16x8 tr_frag_pi(const bf16* img, int stride, int k0
     const int h = g >> 1, dh = g & 1;
     const int pp = ((p & 1) << 1) | (p >> 1);
     const bf16* a0 = img + (k0 + 8 * h + q) * stride + n0 + 16 * dh + 4 * pp;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * stride));
+    bf16x4 lo = SWIN_DS_READ_TR16((lds_bf16x4*)a0);
+    bf16x4 hi = SWIN_DS_READ_TR16((lds_bf16x4*)(a0 + 4 * stride));
     bf16x8 f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }

@@ -98,8 +98,8 @@ struct ConvSrc {
 // transposed fragment of the 32x32x16 operand from the swizzled image: k = rows 16 s + 8 h + j (j = 0..7), column col0 + (lane & 31).
 // `base` = the lane's byte address for k-step 0, first / second 4-row half (the XOR term does not depend on s).
 __device__ __forceinline__ bf16x8 tr_frag2(const char* lo_base, const char* hi_base, int s) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_d*)(lo_base + s * (16 * ROWB)));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_d*)(hi_base + s * (16 * ROWB)));
+    const bf16x4 lo = SWIN_DS_READ_TR16((lds_bf16x4_d*)(lo_base + s * (16 * ROWB)));
+    const bf16x4 hi = SWIN_DS_READ_TR16((lds_bf16x4_d*)(hi_base + s * (16 * ROWB)));
     bf16x8 f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
@@ -228,10 +228,10 @@ __device__ __forceinline__ void wgrad2_body(char* lds2, const int block_id, cons
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bfr[s & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SWIN_MFMA_32x32x16(af[s & 1][i], bfr[s & 1][j], acc[i][j], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], ones, accb[i], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) accb[i] = SWIN_MFMA_32x32x16(af[s & 1][i], ones, accb[i], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -542,10 +542,10 @@ __global__ __launch_bounds__(64 * W3, 2) void wgrad3_kernel(const bf16* __restri
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SWIN_MFMA_32x32x16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) accb[i] = SWIN_MFMA_32x32x16(af[i], ones, accb[i], 0, 0, 0);
             }
         }
         // every ds_read of this buffer has returned (the MFMAs consumed them): it may be overwritten

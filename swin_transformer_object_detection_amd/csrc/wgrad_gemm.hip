@@ -62,8 +62,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int t0, int col0, in
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int h = g >> 1, dh = g & 1;
     const bf16* a0 = tile + (t0 + 8 * h + q) * WROW + col0 + 16 * dh + 4 * p;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_w*)a0);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_w*)(a0 + 4 * WROW));
+    bf16x4 lo = SWIN_DS_READ_TR16((lds_bf16x4_w*)a0);
+    bf16x4 hi = SWIN_DS_READ_TR16((lds_bf16x4_w*)(a0 + 4 * WROW));
     bf16x8 f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256 * WKG, WKG == 1 ? 2 : 1) void wgrad_kernel(cons
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SWIN_MFMA_32x32x16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
             __syncthreads();                                  // everyone is done reading this stage
             if (more) { gmask(); if (do_bias) bias_acc(); lstore(); }

@@ -144,8 +144,8 @@ __device__ __forceinline__ bf16x8 lds_tr_frag_perm(const bf16 (*tile)[LROW], int
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int h = g >> 1, dh = g & 1;
     const bf16* a0 = &tile[row0 + 4 * h + q][16 * dh + 4 * p];
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 8 * LROW));
+    bf16x4 lo = SWIN_DS_READ_TR16((lds_bf16x4*)a0);
+    bf16x4 hi = SWIN_DS_READ_TR16((lds_bf16x4*)(a0 + 8 * LROW));
     bf16x8 f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
             f32x16 sacc[2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][0], qf[0], biasr[kt][qt], 0, 0, 0);   // + bias / scale
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][1], qf[1], a, 0, 0, 0);
+                f32x16 a = SWIN_MFMA_32x32x16(kf[kt][0], qf[0], biasr[kt][qt], 0, 0, 0);   // + bias / scale
+                sacc[kt] = SWIN_MFMA_32x32x16(kf[kt][1], qf[1], a, 0, 0, 0);
             }
             // ---- raw logits (q.k + bias / scale); softmax over keys with the scale folded into the exponent ------
             if (edge) {                                       // wave-uniform: only last-row / last-column windows
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_bf16_kernel(
                     bf16x8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s + j];
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o, 0, 0, 0);
+                    o = SWIN_MFMA_32x32x16(vf, pf, o, 0, 0, 0);
                 }
                 oacc2[kt] = o;
             }
@@ -512,8 +512,8 @@ __device__ __forceinline__ bf16x8 lds_tr_frag_lin(const bf16* tile, int row0, in
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int h = g >> 1, dh = g & 1;
     const bf16* a0 = tile + (row0 + 8 * h + q) * STRIDE + col0 + 16 * dh + 4 * p;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * STRIDE));
+    bf16x4 lo = SWIN_DS_READ_TR16((lds_bf16x4*)a0);
+    bf16x4 hi = SWIN_DS_READ_TR16((lds_bf16x4*)(a0 + 4 * STRIDE));
     bf16x8 f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
@@ -699,8 +699,8 @@ __global__ __launch_bounds__(512) void win_attn_bwd2_bf16_kernel(
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 kf = *(const bf16x8*)&Ks[32 * kt + c][16 * s + 8 * h];
                     const bf16x8 vf = *(const bf16x8*)&Vs[32 * kt + c][16 * s + 8 * h];
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], a, 0, 0, 0);   // S^T
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[s], d, 0, 0, 0);   // dP^T
+                    a = SWIN_MFMA_32x32x16(kf, qf[s], a, 0, 0, 0);   // S^T
+                    d = SWIN_MFMA_32x32x16(vf, df[s], d, 0, 0, 0);   // dP^T
                 }
                 pacc[kt] = a;
                 dpacc[kt] = d;
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(512) void win_attn_bwd2_bf16_kernel(
                     bf16x8 sf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) sf[j] = (bf16)dpacc[kt][8 * s + j];
-                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, sf, dq, 0, 0, 0);
+                    dq = SWIN_MFMA_32x32x16(kc, sf, dq, 0, 0, 0);
                 }
         }
         __syncthreads();                              // (2) P / dS rows of both query tiles are in LDS
@@ -762,8 +762,8 @@ __global__ __launch_bounds__(512) void win_attn_bwd2_bf16_kernel(
                 bf16x8 qc = lds_tr_frag_lin<LROW>(&Qs[0][0], 16 * ks, 0, lane);
                 bf16x8 pb = lds_tr_frag_lin<PROW>(&Lm->p[0][0], 16 * ks, 32 * w, lane);
                 bf16x8 sb = lds_tr_frag_lin<PROW>(&Lm->ds[0][0], 16 * ks, 32 * w, lane);
-                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doc, pb, dv, 0, 0, 0);
-                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qc, sb, dk, 0, 0, 0);
+                dv = SWIN_MFMA_32x32x16(doc, pb, dv, 0, 0, 0);
+                dk = SWIN_MFMA_32x32x16(qc, sb, dk, 0, 0, 0);
             }
             // ---------------- dq | dk | dv of token 32 w + c ----------------------------------------
             bool pad = false;

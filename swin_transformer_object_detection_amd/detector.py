@@ -25,6 +25,8 @@ import math
 
 import numpy as np
 import torch
+
+from ._lib import half_dtype as _H
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -271,7 +273,7 @@ def _conv(x, conv, dtype, padding=0, relu=False, x_is_relu=False):
         tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
         y = ops.linear(tok, conv.weight, conv.bias, dtype)           # weight/bias gradients on the split-T kernel
         y = y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
-    elif dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and padding == 1 and C % 64 == 0 and conv.out_channels % 64 == 0:
+    elif dtype == _H() and conv.kernel_size == (3, 3) and padding == 1 and C % 64 == 0 and conv.out_channels % 64 == 0:
         return ops.conv3x3(x, conv.weight, conv.bias, relu, x_is_relu=x_is_relu)  # HIP implicit-GEMM kernel (ReLU fused)
     else:
         x = x.contiguous(memory_format=torch.channels_last)
@@ -497,8 +499,8 @@ class RPNHead(nn.Module):
         dt = self.compute_dtype
         cls, reg = [], []
         A = self.num_anchors
-        fused = dt == torch.bfloat16 and feats[0].is_cuda
-        if dt == torch.bfloat16:
+        fused = dt == _H() and feats[0].is_cuda
+        if dt == _H():
             # rpn_cls (A) and rpn_reg (4A) as ONE GEMM over the tokens, rows padded to a multiple of 8 for the kernels; the
             # concatenated bf16 weight / bias are built once per step (mixed.derived: constant until the next shadow refresh)
             C = self.rpn_cls.in_channels
@@ -520,9 +522,9 @@ class RPNHead(nn.Module):
         ys = []
         for x in feats:
             # a small level's conv + heads (P4-P6: 10-126 tiles, 40 us each) run on the second stream next to the big levels
-            with (mixed.small_branch(x) if (fused and dt == torch.bfloat16) else contextlib.nullcontext()) as sd:
+            with (mixed.small_branch(x) if (fused and dt == _H()) else contextlib.nullcontext()) as sd:
                 x = _conv(x, self.rpn_conv, dt, padding=1, relu=True)
-                if dt == torch.bfloat16:
+                if dt == _H():
                     N, C, H, W = x.shape
                     tok = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
                     if fused:
@@ -708,7 +710,7 @@ class SingleRoIExtractor(nn.Module):
     def _fast_ok(self, feats, rois):
         f0 = feats[0]
         return (1 < len(feats) <= 4 and f0.is_cuda and f0.shape[1] % 4 == 0 and rois.size(0) > 0
-                and f0.dtype in (torch.float32, torch.bfloat16))
+                and f0.dtype in (torch.float32, _H()))
 
     def forward_with(self, other, feats, rois, valid, other_rois, other_valid):
         """This extractor's and ``other``'s RoI features from the same pyramid (the bbox and mask extractors of one
@@ -732,7 +734,7 @@ class SingleRoIExtractor(nn.Module):
         num_levels = len(feats)
         f0 = feats[0]
         if (num_levels > 1 and num_levels <= 4 and f0.is_cuda and f0.shape[1] % 4 == 0 and rois.size(0) > 0
-                and f0.dtype in (torch.float32, torch.bfloat16)):
+                and f0.dtype in (torch.float32, _H())):
             # one launch over the pyramid, level chosen per RoI on the device: no per-level nonzero / gather /
             # scatter and no host sync; every level receives a gradient tensor, so the reference's dummy-gradient
             # trick (:98-107) is not needed.  `valid` marks the used slots of a fixed-size sample.
@@ -828,7 +830,7 @@ class ConvFCBBoxHead(nn.Module):
                 if cm.with_norm:
                     x = _bn_act(x, cm, self.training, relu=True)
         x = _cast(x.flatten(1), dt)                 # (K, C*7*7) in the reference's (C,7,7) order
-        fast = dt == torch.bfloat16 and x.is_cuda
+        fast = dt == _H() and x.is_cuda
         for fc in self.shared_fcs:
             y = ops.linear(x, fc.weight, fc.bias, dt) if fast else F.linear(x, _cast(fc.weight, dt), _cast(fc.bias, dt))
             x = F.relu(y, inplace=True)
@@ -1058,7 +1060,7 @@ def mask_target(pos_proposals_list, pos_assigned_gt_inds_list, gt_masks_list, ma
     same = (nimg > 0 and all(g_.size(0) > 0 for g_ in gt_masks) and all(r_.size(0) > 0 for r_ in m_roi)
             and all(g_.shape[1:] == gt_masks[0].shape[1:] for g_ in gt_masks) and m_roi[0].is_cuda)
     if same:
-        m = torch.cat(list(gt_masks), 0).to(torch.bfloat16)[:, None]      # 0/1 exact in bf16
+        m = torch.cat(list(gt_masks), 0).to(_H())[:, None]      # 0/1 exact in bf16
         offs, o_ = [], 0
         for g_ in gt_masks:
             offs.append(o_); o_ += g_.size(0)
@@ -1070,7 +1072,7 @@ def mask_target(pos_proposals_list, pos_assigned_gt_inds_list, gt_masks_list, ma
         if m_roi[i].size(0) == 0 or gt_masks[i].size(0) == 0:
             tg.append(m_roi[i].new_zeros((m_roi[i].size(0),) + size))
             continue
-        m = gt_masks[i].to(torch.bfloat16)[:, None].contiguous()
+        m = gt_masks[i].to(_H())[:, None].contiguous()
         t = ops.roi_align(m, rois_of(i, 0), size, 1.0, 0, 'avg', True)
         tg.append((t[:, 0] >= 0.5).float())
     return torch.cat(tg) if tg else tg
@@ -1198,11 +1200,11 @@ def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cf
         mask_pred = mask_head.forward_rows(mask_feats) if rows_path else mask_head(mask_feats)
         with mixed.on_side(dev, buf.mask_rois, *gt_masks) as sd:
             if stacked:
-                m = (gt_masks[0] if nimg == 1 else torch.cat(list(gt_masks), 0)).to(torch.bfloat16)[:, None]     # 0/1 exact in bf16
+                m = (gt_masks[0] if nimg == 1 else torch.cat(list(gt_masks), 0)).to(_H())[:, None]     # 0/1 exact in bf16
                 tg = (ops.roi_align(m, buf.mask_rois, size, 1.0, 0, 'avg', True)[:, 0] >= 0.5).float()
             else:
                 mr = buf.mask_rois.view(nimg, km, 5)
-                tg = torch.cat([(ops.roi_align(gt_masks[i].to(torch.bfloat16)[:, None].contiguous(), mr[i], size, 1.0, 0, 'avg',
+                tg = torch.cat([(ops.roi_align(gt_masks[i].to(_H())[:, None].contiguous(), mr[i], size, 1.0, 0, 'avg',
                                                True)[:, 0] >= 0.5).float() for i in range(nimg)])
         if sd is not None:
             mixed.side_outputs(tg)            # produced on the second stream, read (and kept for backward) on this one
@@ -1500,11 +1502,14 @@ class CascadeRCNN(MaskRCNN):
 def build_detector(cfg, train_cfg=None, test_cfg=None, compute_dtype=torch.float32):
     """mmdet/models/builder.py:67-77."""
     cfg = dict(cfg)
+    if compute_dtype in (torch.bfloat16, torch.float16):
+        from . import _lib
+        _lib.set_half_dtype(compute_dtype)        # the process's 16-bit type (and library build): before anything uses the library
     if train_cfg is not None:
         cfg['train_cfg'] = train_cfg
     if test_cfg is not None:
         cfg['test_cfg'] = test_cfg
     model = build_from_cfg(cfg, DETECTORS, dict(compute_dtype=compute_dtype))
-    if compute_dtype == torch.bfloat16:
+    if compute_dtype == _H():
         mixed.khwc_resident_(model)          # 3x3 conv weights live in the HIP conv kernels' (Cout,ky,kx,Cin) memory layout
     return model

@@ -11,6 +11,8 @@ channels-last; the extra pyramid level ``max_pool2d(k=1, s=2)`` is a strided vie
 import contextlib
 
 import torch
+
+from ._lib import half_dtype as _H
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -103,7 +105,7 @@ class FPN(nn.Module):
         for i in range(len(laterals) - 1, 0, -1):               # fpn.py:182-191
             laterals[i - 1] = ops.upsample_add(laterals[i - 1], laterals[i])
         branched = False
-        if dt == torch.bfloat16 and self.out_channels % 64 == 0:
+        if dt == _H() and self.out_channels % 64 == 0:
             outs = []
             for i, fc in enumerate(self.fpn_convs):
                 # the small levels' convs (P4, P5: one block per CU on half the chip) go to the second stream

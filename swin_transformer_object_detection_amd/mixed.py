@@ -12,6 +12,8 @@ import os
 
 import torch
 
+from ._lib import half_dtype as _H
+
 _SHADOW = {}          # id(master parameter) -> bf16 leaf tensor (a view of the flat shadow buffer)
 _CONST = {}           # id(master parameter) -> bf16 constant copy (no gradient; biases of shadowed layers)
 _SINK = {}            # id(master parameter) -> (fp32 gradient view in a flat bucket, notify())  -- set by ddp.py
@@ -528,11 +530,12 @@ def refresh_aux():
 
 
 class ShadowParams:
-    def __init__(self, module, dtype=torch.bfloat16, min_numel=1024):
+    def __init__(self, module, dtype=None, min_numel=1024):
         """Shadows are created for the ``weight`` (>= min_numel elements) and ``bias`` of Linear / Conv2d /
         ConvTranspose2d layers (the GEMM / conv operands).  Everything else (LayerNorm affine, relative-position
         bias tables, position embeddings) is consumed in fp32 by the kernels and keeps its direct gradient."""
         import torch.nn as nn
+        dtype = _H() if dtype is None else dtype
         self.dtype = dtype
         seen, self.masters, self.const_masters = set(), [], []
         for m in module.modules():
@@ -589,3 +592,54 @@ class ShadowParams:
             _AUX.pop((id(p), 'dgrad'), None)
             _AUX.pop((id(p), 't'), None)
         _DERIVED.clear()
+
+
+class LossScaler:
+    """Dynamic loss scaling for the fp16 build, entirely on the device (apex O1's dynamic LossScaler, which the reference
+    trains with: mmdet/apis/train.py:82-89): the scale, the skip flag and the clean-step counter live in the optimizer's
+    device-resident state, so a step never waits for the host and the whole step can sit inside a captured hipGraph.
+
+        scaler = LossScaler(optim, reducer)
+        loss = scaler.scale(loss); loss.backward(); reducer.finish()
+        scaler.check(optim); optim.step(); scaler.update(optim)
+
+    check(): non-finite gradient anywhere -> the optimizer launch leaves parameters and moments untouched; every gradient is
+    multiplied by 1 / scale inside the optimizer kernel.  update(): halve on a skipped step, double after ``growth_interval``
+    clean ones."""
+
+    def __init__(self, optim, reducer, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                 min_scale=1.0, max_scale=2.0 ** 24):
+        self.optim, self.reducer = optim, reducer
+        self.growth, self.backoff, self.interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.min_scale, self.max_scale = float(min_scale), float(max_scale)
+        dev = reducer.buckets[0]['flat'].device
+        self.state = optim.state_tensor(dev)
+        self.state[20] = float(init_scale)
+        self.state[21] = 0.0
+        self._scale_view = self.state[20]                 # 0-dim view: the loss is multiplied by it on the device
+
+    def scale(self, loss):
+        return loss * self._scale_view
+
+    def _sp(self):
+        return ctypes.c_void_p(self.state.data_ptr())
+
+    def check(self, optim=None):
+        from ._lib import call
+        st = ctypes.c_void_p(_raw_current(_dev_index(self.state.device)))
+        call("swin_loss_scale_begin", self._sp(), st)
+        for b in self.reducer.buckets:
+            f = b['flat']
+            call("swin_grad_check_finite", ctypes.c_void_p(f.data_ptr()), f.numel(), self._sp(), st)
+
+    def update(self, optim=None):
+        from ._lib import call
+        st = ctypes.c_void_p(_raw_current(_dev_index(self.state.device)))
+        call("swin_loss_scale_update", self._sp(), self.growth, self.backoff, self.interval, self.min_scale, self.max_scale, st)
+
+    def get_scale(self):
+        """host copy of the current scale (synchronises: logging / tests only)"""
+        return float(self.state[20])
+
+    def skipped_last_step(self):
+        return float(self.state[19]) != 0.0

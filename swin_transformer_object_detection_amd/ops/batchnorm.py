@@ -6,6 +6,8 @@ Statistics are exchanged the way SyncBatchNorm does -- one small collective forw
 backward (per-channel gradient sums) -- on ``torch.distributed``'s default group when it is initialised with more than
 one rank; a single process degenerates to plain BatchNorm, as torch.nn.SyncBatchNorm does."""
 import torch
+
+from .._lib import half_dtype as _H
 import torch.distributed as dist
 
 from .._lib import SWIN_BF16, SWIN_F32, SwinHipError, call, lib
@@ -25,7 +27,7 @@ def _ws(dev, C):
 def _dt(t):
     if t.dtype == torch.float32:
         return SWIN_F32
-    if t.dtype == torch.bfloat16:
+    if t.dtype == _H():
         return SWIN_BF16
     raise SwinHipError(f"batch_norm: float32 / bfloat16 activations only, got {t.dtype}")
 

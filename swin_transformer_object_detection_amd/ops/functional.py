@@ -11,6 +11,8 @@ import os
 
 import torch
 
+from .._lib import half_dtype as _H
+
 from .. import _lib
 from .._lib import SWIN_BF16, SWIN_F32, SwinHipError, call
 
@@ -18,7 +20,7 @@ LN_EPS = 1e-5
 
 
 def _dt(t):
-    if t.dtype == torch.bfloat16:
+    if t.dtype == _H():
         return SWIN_BF16
     if t.dtype == torch.float32:
         return SWIN_F32
@@ -386,7 +388,7 @@ def _conv3x3_raw(x_cl, w_khwc, bias, relu, gate=None):
     Few-tile maps (coarse pyramid levels) go through the split-K entry with a workspace from the caching allocator."""
     N, Cin, H, W = x_cl.shape
     Cout = w_khwc.shape[0]
-    y = torch.empty((N, Cout, H, W), device=x_cl.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    y = torch.empty((N, Cout, H, W), device=x_cl.device, dtype=_H(), memory_format=torch.channels_last)
     key = (N, H, W, Cin, Cout)
     nb = _SPLITK_BYTES.get(key)
     if nb is None:
@@ -416,8 +418,8 @@ def conv_dgrad_layout_multi(srcs, dsts):
     if n == 0:
         return
     for s_, d_ in zip(srcs, dsts):
-        if not (s_.is_cuda and s_.dtype == torch.bfloat16 and s_.dim() == 4 and s_.permute(0, 2, 3, 1).is_contiguous()
-                and d_.is_contiguous() and d_.dtype == torch.bfloat16 and d_.numel() == s_.numel()):
+        if not (s_.is_cuda and s_.dtype == _H() and s_.dim() == 4 and s_.permute(0, 2, 3, 1).is_contiguous()
+                and d_.is_contiguous() and d_.dtype == _H() and d_.numel() == s_.numel()):
             raise SwinHipError("conv_dgrad_layout_multi: (Cout,Cin,3,3) bf16 sources in channels-last memory, contiguous bf16 outputs")
     sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
     dp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
@@ -433,8 +435,8 @@ def linear_t_layout_multi(srcs, dsts):
     if n == 0:
         return
     for s_, d_ in zip(srcs, dsts):
-        if not (s_.is_cuda and s_.dtype == torch.bfloat16 and s_.dim() == 2 and s_.is_contiguous() and d_.is_contiguous()
-                and d_.dtype == torch.bfloat16 and tuple(d_.shape) == (s_.shape[1], s_.shape[0])):
+        if not (s_.is_cuda and s_.dtype == _H() and s_.dim() == 2 and s_.is_contiguous() and d_.is_contiguous()
+                and d_.dtype == _H() and tuple(d_.shape) == (s_.shape[1], s_.shape[0])):
             raise SwinHipError("linear_t_layout_multi: contiguous bf16 (rows, cols) sources and (cols, rows) outputs")
     sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
     dp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
@@ -453,14 +455,14 @@ class _Conv3x3(torch.autograd.Function):
     def forward(ctx, x, weight, bias, relu, weight_master, x_is_relu=False):
         from .. import mixed
         ctx.x_is_relu = bool(x_is_relu)
-        if x.dtype != torch.bfloat16 or not x.is_cuda:
+        if x.dtype != _H() or not x.is_cuda:
             raise SwinHipError("conv3x3: bf16 GPU activations only (fp32 parity runs use the library conv)")
         x = x.contiguous(memory_format=torch.channels_last)
-        if weight.dtype == torch.bfloat16 and mixed.is_khwc(weight):
+        if weight.dtype == _H() and mixed.is_khwc(weight):
             w = weight.detach().permute(0, 2, 3, 1)          # resident in the kernel's layout (mixed.khwc_resident_): a view
         else:
             w = mixed.derived(weight_master, 'khwc',
-                              lambda: weight.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())   # (Cout,3,3,Cin)
+                              lambda: weight.detach().to(_H()).permute(0, 2, 3, 1).contiguous())   # (Cout,3,3,Cin)
         b = None if bias is None else _f32(bias.detach().float()).contiguous()
         y = _conv3x3_raw(x, w, b, relu)
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -486,11 +488,11 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dx = conv(dy, rot180(w) with in/out swapped): (Cin, 3, 3, Cout)
             sh = mixed.shadow_of(w_master)
-            if sh is not None and sh.data_ptr() == weight.data_ptr() and sh.dtype == torch.bfloat16 and mixed.is_khwc(sh):
+            if sh is not None and sh.data_ptr() == weight.data_ptr() and sh.dtype == _H() and mixed.is_khwc(sh):
                 wt = mixed.conv_dgrad_weight(w_master, sh)          # persistent, rebuilt for all convs by one launch per step
             else:
                 wt = mixed.derived(w_master, 'dgrad',
-                                   lambda: weight.detach().to(torch.bfloat16).flip(2, 3).permute(1, 2, 3, 0).contiguous())
+                                   lambda: weight.detach().to(_H()).flip(2, 3).permute(1, 2, 3, 0).contiguous())
             if ctx.x_is_relu:
                 # x is the ReLU output of the layer below: its ReLU backward rides in this kernel's epilogue
                 dx = _conv3x3_raw(dy, wt, None, False, gate=x)
@@ -557,12 +559,13 @@ class _Conv3x3(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
-def conv3x3(x, weight, bias=None, relu=False, dtype=torch.bfloat16, x_is_relu=False):
+def conv3x3(x, weight, bias=None, relu=False, dtype=None, x_is_relu=False):
     """3x3, padding 1, stride 1 conv of a logically-NCHW bf16 tensor (channels-last memory).  ``weight`` / ``bias``
     are the fp32 master parameters (the compute-dtype weight is resolved through mixed.weight; gradients may be
     accumulated straight into the reducer's buckets).  ``x_is_relu``: the caller guarantees that ``x`` is the output of a
     ReLU (x == 0 wherever the ReLU was inactive); the data gradient is then produced already multiplied by [x > 0], i.e.
     as the gradient at that ReLU's input, and a conv3x3(relu=True) below recognises it and skips its own masking pass."""
+    dtype = _H() if dtype is None else dtype
     from .. import mixed
     return _Conv3x3.apply(x, mixed.weight(weight, dtype), bias, relu, weight, x_is_relu)
 
@@ -584,7 +587,7 @@ def gemm_bf16(a, b, bias=None, b_is_kn=False, out_shape=None):
     ws = _GEMM_WS.get(dev)
     if ws is None:
         ws = _GEMM_WS[dev] = torch.empty(_lib.lib().swin_gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
-    c = torch.empty((M, N) if out_shape is None else out_shape, dtype=torch.bfloat16, device=dev)   # not a view
+    c = torch.empty((M, N) if out_shape is None else out_shape, dtype=_H(), device=dev)   # not a view
     call("swin_gemm_bf16", _p(a), _p(b), _p(bias), _p(c), M, N, K, 1 if b_is_kn else 0, _p(ws), _s())
     return c
 
@@ -608,7 +611,7 @@ class _LinearBf16(torch.autograd.Function):
             mixed.use_begin(w_master)
             ctx.counted = True
         x2 = x.reshape(-1, w.shape[1])
-        if _DIRECT_GEMM and x2.is_contiguous() and w.is_contiguous() and (b is None or (b.dtype == torch.bfloat16 and b.is_contiguous())):
+        if _DIRECT_GEMM and x2.is_contiguous() and w.is_contiguous() and (b is None or (b.dtype == _H() and b.is_contiguous())):
             return gemm_bf16(x2, w, b, out_shape=tuple(x.shape[:-1]) + (w.shape[0],))
         return torch.nn.functional.linear(x, w, b)
 
@@ -674,7 +677,7 @@ def linear(x, weight, bias=None, dtype=None):
     w = mixed.weight(weight, dtype)
     if w.dim() == 4 and w.is_contiguous():       # a conv weight used as a GEMM over (Cin, ky, kx)-ordered rows: 1x1 convs, patch embedding
         w = w.view(w.shape[0], -1)
-    if (x.dtype == torch.bfloat16 and x.is_cuda and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[0] % 8 == 0
+    if (x.dtype == _H() and x.is_cuda and w.dtype == _H() and w.dim() == 2 and w.shape[0] % 8 == 0
             and w.shape[1] % 8 == 0 and x.numel() // w.shape[1] >= _MIN_T):
         b = mixed.const(bias, dtype)                                # bf16 constant; gradient delivered to the master
         if b is None:
@@ -690,7 +693,7 @@ MLP_FUSED_C = (96, 192)
 
 
 def mlp_fused_ok(x, C):
-    return x.is_cuda and x.dtype == torch.bfloat16 and C in MLP_FUSED_C
+    return x.is_cuda and x.dtype == _H() and C in MLP_FUSED_C
 
 
 def mlp_fwd_raw(x2, w1, b1, w2, b2):
@@ -706,7 +709,7 @@ def mlp_bwd_raw(x2, dy2, w1, b1, w2):
     GEMMs need (dW2 = dy^T h, dW1 = dhpre^T x, db1 = colsum dhpre)."""
     T, C = x2.shape
     dx = torch.empty_like(x2)
-    h = torch.empty((T, 4 * C), device=x2.device, dtype=torch.bfloat16)
+    h = torch.empty((T, 4 * C), device=x2.device, dtype=_H())
     dhpre = torch.empty_like(h)
     call("swin_mlp_bwd_bf16", _p(x2), _p(dy2), _p(w1), _p(_f32(b1)), _p(w2), _p(dx), _p(h), _p(dhpre), T, C, _s())
     return dx, h, dhpre

@@ -7,6 +7,8 @@ import ctypes
 
 import torch
 
+from .._lib import half_dtype as _H
+
 from .._lib import SWIN_BF16, SWIN_F32, SwinHipError, call
 from .functional import _p, _s
 
@@ -14,7 +16,7 @@ from .functional import _p, _s
 def _dt(t):
     if t.dtype == torch.float32:
         return SWIN_F32
-    if t.dtype == torch.bfloat16:
+    if t.dtype == _H():
         return SWIN_BF16
     raise SwinHipError(f"loss kernels: float32 / bfloat16 logits only, got {t.dtype}")
 

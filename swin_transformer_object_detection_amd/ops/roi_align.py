@@ -8,6 +8,8 @@ by name with ``getattr``; ``structures.py:353-354`` calls
 import os
 
 import torch
+
+from .._lib import half_dtype as _H
 import torch.nn as nn
 
 from .._lib import SWIN_BF16, SWIN_F32, SwinHipError, call
@@ -33,7 +35,7 @@ class _RoIAlignFn(torch.autograd.Function):
             cl = 0
         if inp.dtype == torch.float32:
             dt = SWIN_F32
-        elif inp.dtype == torch.bfloat16:
+        elif inp.dtype == _H():
             dt = SWIN_BF16
         else:
             raise SwinHipError(f"roi_align: unsupported feature dtype {inp.dtype}")
@@ -135,7 +137,7 @@ class _RoIAlignMultiLevelFn(torch.autograd.Function):
         flat = torch.zeros(sum(sizes), device=gout.device, dtype=torch.float32)
         offs = [sum(sizes[:i]) for i in range(n)]
         if K > 0:
-            if gout.dtype not in (torch.float32, torch.bfloat16):
+            if gout.dtype not in (torch.float32, _H()):
                 gout = gout.float()
             gout = gout.contiguous(memory_format=torch.channels_last)
             ptrs = (ctypes.c_void_p * n)(*[flat.data_ptr() + 4 * o for o in offs])
@@ -227,7 +229,7 @@ class _RoIAlignMultiLevelGroupFn(torch.autograd.Function):
             K = rois.shape[0]
             if gout is None or K == 0:
                 continue
-            if gout.dtype not in (torch.float32, torch.bfloat16):
+            if gout.dtype not in (torch.float32, _H()):
                 gout = gout.float()
             gout = gout.contiguous(memory_format=torch.channels_last)
             call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, n, _p(gout), _p(rois), _p(lvls), C, K, ph, pw, sr, aligned,

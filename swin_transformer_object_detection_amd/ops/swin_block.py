@@ -11,6 +11,8 @@ import os
 
 import torch
 
+from .._lib import half_dtype as _H
+
 from .. import _lib, mixed
 from .._lib import SWIN_BF16, call
 from .functional import LN_EPS, _f32, _ln_ws, _p, _s, gemm_bf16, rel_bias_expand
@@ -57,8 +59,8 @@ def _bias16(b):
     """bf16 copy of a bias for the GEMM epilogue (the per-step constant when there is one)."""
     if b is None:
         return None
-    c = mixed.const(b, torch.bfloat16)
-    return c if c is not None else b.detach().to(torch.bfloat16)
+    c = mixed.const(b, _H())
+    return c if c is not None else b.detach().to(_H())
 
 
 # ---- native runner (csrc/block_runner.hip): one C call per block and direction ------------------------------------
@@ -131,7 +133,7 @@ class _SwinBlockFn(torch.autograd.Function):
         # ---- attention branch (:211-247, :129-151) ----
         qkv = gemm_bf16(n1.view(T, C), wqkv, _bias16(bqkv), out_shape=(B, L, 3 * C))
         bias_exp = rel_bias_expand(table.detach())
-        o = torch.empty(B, L, C, device=dev, dtype=torch.bfloat16)
+        o = torch.empty(B, L, C, device=dev, dtype=_H())
         nW = ((H + 6) // 7) * ((W + 6) // 7)
         lse = torch.empty(B * nW * nH, 64, device=dev, dtype=torch.float32)
         scale = float((C // nH) ** -0.5)
@@ -276,11 +278,11 @@ class _SwinBlockFn(torch.autograd.Function):
         TC = T * C
         fused = _FUSED_MLP and C in _FUSED_MLP_C       # fc1 -> GELU -> fc2 in one launch; hpre / h are recomputed in backward
         if fused:
-            flat = torch.empty(8 * TC, device=dev, dtype=torch.bfloat16)
+            flat = torch.empty(8 * TC, device=dev, dtype=_H())
             qkv, o, y, x1, n2, y2 = _carve(flat, [3 * TC, TC, TC, TC, TC, TC])
             hpre = h = None
         else:
-            flat = torch.empty(16 * TC, device=dev, dtype=torch.bfloat16)
+            flat = torch.empty(16 * TC, device=dev, dtype=_H())
             qkv, o, y, x1, n2, hpre, h, y2 = _carve(flat, [3 * TC, TC, TC, TC, TC, 4 * TC, 4 * TC, TC])
         nW = ((H + 6) // 7) * ((W + 6) // 7)
         nl = B * nW * nH * 64
@@ -328,7 +330,7 @@ class _SwinBlockFn(torch.autograd.Function):
         dev = x1.device
         nig = ctx.needs_input_grad
         has_next = ctx.has_next
-        flat = torch.empty(16 * TC, device=dev, dtype=torch.bfloat16)
+        flat = torch.empty(16 * TC, device=dev, dtype=_H())
         dx1, dy2, dh, dhpre, dn2, dy, do, dqkv = _carve(flat, [TC, TC, 4 * TC, 4 * TC, TC, TC, TC, 3 * TC])
         if has_next:
             dnn = torch.zeros_like(x2) if dnn is None else dnn.contiguous()

@@ -6,6 +6,8 @@ import ctypes
 
 import torch
 
+from .._lib import half_dtype as _H
+
 from .. import _lib
 from .._lib import SwinHipError, call
 from .functional import _p, _s
@@ -221,7 +223,7 @@ def rpn_topk_decode(cls_all, reg_all, anchors, level_sizes, nms_pre, means, stds
         raise SwinHipError("rpn_topk_decode: GPU tensors only")
     from .._lib import SWIN_BF16, SWIN_F32, lib
     c, r = cls_all.detach().contiguous(), reg_all.detach().contiguous()
-    if c.dtype != r.dtype or c.dtype not in (torch.float32, torch.bfloat16):
+    if c.dtype != r.dtype or c.dtype not in (torch.float32, _H()):
         c, r = c.float(), r.float()
     B, total = c.shape
     if sum(level_sizes) != total or r.shape != (B, total, 4) or anchors.shape != (total, 4):
@@ -248,7 +250,7 @@ def regress_by_class(rois, labels, cls_score, bbox_pred, num_classes, class_agno
         raise SwinHipError("regress_by_class: GPU tensors only")
     from .._lib import SWIN_BF16, SWIN_F32
     c, b = cls_score.detach().contiguous(), bbox_pred.detach().contiguous()
-    if c.dtype != b.dtype or c.dtype not in (torch.float32, torch.bfloat16):
+    if c.dtype != b.dtype or c.dtype not in (torch.float32, _H()):
         c, b = c.float(), b.float()
     r = rois.detach().float().contiguous()
     n = r.size(0)
@@ -269,7 +271,7 @@ def paste_masks(mask_logits, labels, boxes, img_h, img_w, thr, is_prob=False):
     already holds probabilities (stage-averaged masks of CascadeRoIHead)."""
     if not mask_logits.is_cuda:
         raise SwinHipError("paste_masks: GPU tensors only")
-    if mask_logits.dtype not in (torch.float32, torch.bfloat16):
+    if mask_logits.dtype not in (torch.float32, _H()):
         mask_logits = mask_logits.float()
     m = mask_logits.detach().contiguous()
     N, nc, mh, mw = m.shape

@@ -9,6 +9,8 @@ import struct
 
 import torch
 
+from ._lib import half_dtype as _H
+
 from . import _lib, mixed
 from ._lib import SwinHipError, call
 
@@ -69,7 +71,7 @@ class FusedAdamW:
                 if st['exp_avg'].stride() != p.stride() or st['exp_avg_sq'].stride() != p.stride():
                     raise SwinHipError("FusedAdamW: optimizer state laid out differently from its parameter")
                 sh = mixed.shadow_of(p)
-                if sh is not None and not (sh.dtype == torch.bfloat16 and sh.stride() == p.stride() and sh.numel() == p.numel()):
+                if sh is not None and not (sh.dtype == _H() and sh.stride() == p.stride() and sh.numel() == p.numel()):
                     raise SwinHipError("FusedAdamW: shadows must be bf16 copies with the parameter's memory layout")
                 n = p.numel()
                 si = len(segs)
