@@ -105,7 +105,8 @@ hpre_ref = F.linear(xx.float(), w1_.float()).half().float()
 h_ref = F.gelu(hpre_ref + bb1)
 hpre = torch.empty(T, 4 * C, device="cuda", dtype=H16)
 h = torch.empty_like(hpre)
-Fn.call("swin_linear_gelu_hip_bf16", Fn._p(xx.cuda()), Fn._p(w1_.cuda()), Fn._p(bb1.cuda()), Fn._p(hpre), Fn._p(h), T, 4 * C, C, Fn._s())
+xg, wg, bg = xx.cuda(), w1_.cuda(), bb1.cuda()          # (held: the call takes raw pointers)
+Fn.call("swin_linear_gelu_hip_bf16", Fn._p(xg), Fn._p(wg), Fn._p(bg), Fn._p(hpre), Fn._p(h), T, 4 * C, C, Fn._s())
 close(hpre, hpre_ref, 1.01, "gelu-epilogue GEMM: pre-activation")
 close(h, h_ref, 2, "gelu-epilogue GEMM: activation")
 
