@@ -389,6 +389,10 @@ def main():
             graph_note = f"capture failed, eager step measured: {type(e).__name__}: {e}"[:400]
             torch.cuda.synchronize()
 
+    plans_synced = None
+    if world > 1:
+        step()                                  # every shape's library GEMM plan exists
+        plans_synced = ddp.sync_gemm_plans()    # ... and every rank runs rank 0's algorithm choices from here on
     for _ in range(args.warmup):
         log_vars = step()
     barrier()
@@ -442,7 +446,7 @@ def main():
             "roofline": roof, "roofline_mfma_kernels": roof_gemm, "cpu_baseline": cpu, "sync_check": sync_check,
             # host-side timeline of the last step's gradient exchange, relative to the start of backward (N > 1 only has
             # entries): a bucket issued before backward_issued_ms overlapped the rest of backward
-            "comm_timeline": comm if world > 1 else None,
+            "comm_timeline": comm if world > 1 else None, "gemm_plans_changed_to_rank0": plans_synced,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

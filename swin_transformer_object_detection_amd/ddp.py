@@ -295,6 +295,37 @@ class BucketedGradReducer:
                 dist.broadcast(d if d.is_contiguous() else d.permute(0, 2, 3, 1), src, group=self.group)
 
 
+def sync_gemm_plans(group=None, src=0):
+    """Every rank runs the library GEMMs with the algorithms rank ``src`` chose.  swin_gemm_bf16 picks a plan's algorithm by timing
+    hipBLASLt's candidates on first use, so ranks can choose differently for the same shape (harmless for the replicas' parameters --
+    the gradients are all-reduced -- but it makes per-rank step times and local gradients differ).  Call once after the warm-up
+    steps: plans exported on ``src`` (csrc/gemm_lt.hip: swin_gemm_plans_export), broadcast, imported everywhere.
+    Returns the number of plans changed on this rank."""
+    import ctypes
+    from . import _lib
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    lib = _lib.lib()
+    n = max(lib.swin_gemm_plans_export(None, 0), 0)
+    buf = (ctypes.c_int64 * (6 * max(n, 1)))()
+    if n:
+        lib.swin_gemm_plans_export(buf, n)
+    if world == 1:
+        return 0
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    dist.broadcast(cnt, src, group=group)
+    m = int(cnt.item())
+    rec = torch.tensor(list(buf)[:6 * n] if dist.get_rank(group) == src else [0] * (6 * m), dtype=torch.int64, device=dev).reshape(-1)
+    if rec.numel() != 6 * m:
+        rec = torch.zeros(6 * m, dtype=torch.int64, device=dev)
+    dist.broadcast(rec, src, group=group)
+    if m == 0:
+        return 0
+    host = rec.cpu().tolist()
+    arr = (ctypes.c_int64 * (6 * m))(*host)
+    return max(lib.swin_gemm_plans_import(arr, m), 0)
+
+
 def reduce_log_vars(log_vars, group=None):
     """One packed all-reduce(mean) for all logged scalars (vs one per scalar in base.py:211-216)."""
     keys = sorted(log_vars)

@@ -215,15 +215,21 @@ def gen_window_attention(ref, seed=7):
     print("window_attention ok")
 
 
-def gen_fpn(reffpn, seed=11):
-    in_ch, oc = (8, 16, 32, 64), 16
-    shapes = [(20, 28), (10, 14), (5, 7), (3, 4)]
+def gen_fpn(reffpn, seed=11, name="fpn_small", in_ch=(8, 16, 32, 64), oc=16, shapes=((20, 28), (10, 14), (5, 7), (3, 4)),
+            bf16_operands=False):
+    """bf16_operands: parameters and inputs are rounded to bf16-representable values first (the reference still computes in fp32):
+    the fixture for the bf16 HIP path, whose MFMA conv then sees exactly these operand values."""
     p = fpn_oracle.make_params(in_ch, oc, seed=seed)
+    if bf16_operands:
+        p = {k: v.bfloat16().float() for k, v in p.items()}
     m = reffpn.FPN(list(in_ch), oc, 5)
     m.init_weights()
     m.load_state_dict(p, strict=True)
     g = torch.Generator().manual_seed(seed + 1)
-    xs = [torch.randn(2, c, h, w, generator=g, requires_grad=True) for c, (h, w) in zip(in_ch, shapes)]
+    xs = [torch.randn(2, c, h, w, generator=g) for c, (h, w) in zip(in_ch, shapes)]
+    if bf16_operands:
+        xs = [x.bfloat16().float() for x in xs]
+    xs = [x.requires_grad_(True) for x in xs]
     outs = m(tuple(xs))
     ws = [torch.randn(o.shape, generator=g) for o in outs]
     loss = sum((o * w).sum() for o, w in zip(outs, ws))
@@ -239,8 +245,8 @@ def gen_fpn(reffpn, seed=11):
         data[f"w{i}"] = _np(w)
     for n, gg in zip(pn, gs[len(xs):]):
         data["grad__" + n] = _np(gg)
-    np.savez_compressed(os.path.join(HERE, "fpn_small.npz"), **data)
-    print("fpn ok", [tuple(o.shape) for o in outs])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+    print(name, "ok", [tuple(o.shape) for o in outs])
 
 
 def main():
@@ -259,7 +265,19 @@ def main():
     gen_swin(ref, "swin_tiny_224", tiny, (1, 3, 224, 224), seed=3, grads=False, store_inputs=False)
     gen_window_attention(ref)
     gen_fpn(reffpn)
+    gen_fpn_c64(reffpn)
+
+
+def gen_fpn_c64(reffpn):
+    # (round 3) FPN wide enough for the hand-written MFMA 3x3 conv (Cin % 64 == 0), operands bf16-representable
+    gen_fpn(reffpn, seed=12, name="fpn_c64", in_ch=(64, 128, 192, 256), oc=64, shapes=((16, 24), (8, 12), (4, 6), (2, 3)),
+            bf16_operands=True)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "fpn_c64":      # only the fixture added in round 3 (the others are unchanged)
+        torch.set_num_threads(8)
+        _install_shims()
+        gen_fpn_c64(_load(os.path.join(REF, "mmdet/models/necks/fpn.py"), "mmdet.models.necks.fpn", "mmdet.models.necks"))
+    else:
+        main()

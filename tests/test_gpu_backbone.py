@@ -156,6 +156,39 @@ def test_fpn_vs_reference_golden(pkg, golden_dir):
         _cmp(params[k[6:]].grad, g[k], 1e-3, 1e-4, k)
 
 
+def test_fpn_bf16_hip_conv_vs_reference_golden(pkg, golden_dir):
+    """The REFERENCE's FPN (fpn.py:169-221, run by tests/golden/make_golden.py on bf16-representable parameters and inputs) against
+    the bf16 path: 1x1 laterals as GEMMs, the upsample + add kernel and the HAND-WRITTEN MFMA 3x3 conv (in_channels 64..256 -> 64:
+    wide enough for it; the fp32 fixture `fpn_small` is too narrow and runs torch's conv).  Operands are identical, accumulation is
+    fp32, every stored tensor is one bf16 rounding: outputs within 4 bf16 ulps of the fixture's scale, input gradients within 6."""
+    g = _load(golden_dir, "fpn_c64")
+    in_ch = (64, 128, 192, 256)
+    p = {k: v.bfloat16().float() for k, v in fpn_oracle.make_params(in_ch, 64, seed=int(g["seed"])).items()}
+    m = pkg.fpn.FPN(list(in_ch), 64, 5, compute_dtype=torch.bfloat16)
+    m.init_weights()
+    m.load_state_dict(p, strict=True)
+    m.cuda()
+    xs = [torch.from_numpy(g[f"in{i}"]).cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+          for i in range(4)]
+    for i in range(4):
+        assert torch.equal(xs[i].detach().float().cpu(), torch.from_numpy(g[f"in{i}"]))          # bf16-representable inputs
+    outs = m(tuple(xs))
+    assert len(outs) == 5 and all(o.dtype == torch.bfloat16 for o in outs)
+    ulp = 2.0 ** -8
+    for i, o in enumerate(outs):
+        ref = g[f"out{i}"]
+        _cmp(o, ref, 4 * ulp * float(np.abs(ref).max()), msg=f"out{i}")
+    loss = sum((o.float() * torch.from_numpy(g[f"w{i}"]).cuda()).sum() for i, o in enumerate(outs))
+    loss.backward()
+    for i in range(4):
+        ref = g[f"gin{i}"]
+        _cmp(xs[i].grad, ref, 6 * ulp * float(np.abs(ref).max()), msg=f"gin{i}")
+    params = dict(m.named_parameters())
+    for k in [k for k in g.files if k.startswith("grad__")]:
+        ref = g[k]
+        _cmp(params[k[6:]].grad, ref, 0.02 * float(np.abs(ref).max()), msg=k)
+
+
 def test_full_size_attention_sampled_windows(pkg):
     """BASELINE configs[1] stage-1 geometry (B=2, 200x320 tokens, C=96, 3 heads, shifted): the bf16 MFMA
     kernel at full size, checked by the oracle on a sample of windows (windows are independent) and

@@ -1004,3 +1004,32 @@ def test_rpn_flatten_kernel(ops, dtype):
     ((cls * wc).sum() + (reg * wr).sum()).backward()
     for a, b in zip(ys, ys2):
         assert torch.equal(a.grad, b.grad)
+
+
+def test_gemm_plan_export_import_roundtrip(ops):
+    """swin_gemm_plans_export / _import (the records data-parallel ranks exchange so that all of them run rank 0's hipBLASLt
+    algorithm choices -- ddp.sync_gemm_plans): a plan exists after a call, re-importing the exported choices changes nothing,
+    importing another candidate index changes exactly that plan and the GEMM still computes the same product."""
+    import ctypes
+    from swin_transformer_object_detection_amd import _lib, ddp
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    a = torch.randn(3000, 192, device="cuda").bfloat16()
+    w = (torch.randn(576, 192, device="cuda") * 0.05).bfloat16()
+    c0 = Fn.gemm_bf16(a, w)
+    lib = _lib.lib()
+    n = lib.swin_gemm_plans_export(None, 0)
+    assert n >= 1
+    buf = (ctypes.c_int64 * (6 * n))()
+    assert lib.swin_gemm_plans_export(buf, n) == n
+    recs = [list(buf[6 * i:6 * i + 6]) for i in range(n)]
+    mine = [r for r in recs if r[:5] == [3000, 576, 192, 0, 0]]
+    assert len(mine) == 1
+    assert lib.swin_gemm_plans_import(buf, n) == 0                      # the same choices: nothing changes
+    assert ddp.sync_gemm_plans() == 0                                    # one process: a no-op
+    other = (ctypes.c_int64 * 6)(3000, 576, 192, 0, 0, 1 if mine[0][5] == 0 else 0)
+    changed = lib.swin_gemm_plans_import(other, 1)
+    assert changed in (0, 1)                                             # 0 only if the heuristic offered a single candidate
+    c1 = Fn.gemm_bf16(a, w)
+    torch.cuda.synchronize()
+    assert float((c0.float() - c1.float()).abs().max()) <= 2.0 ** -7 * float(c0.float().abs().max())
+    lib.swin_gemm_plans_import(buf, n)                                   # back to the tuned choice
