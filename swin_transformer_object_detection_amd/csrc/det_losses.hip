@@ -159,13 +159,23 @@ __global__ __launch_bounds__(1024) void bbox_loss_fwd_kernel(const T* __restrict
     __shared__ float red[16];
     float ce = 0.f, hit = 0.f, l1 = 0.f, cnt = 0.f;
     const int C = nc + 1;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    // one WAVE per row (the 16 waves walk the rows): the lanes read the row's logits coalesced and reduce max / arg-max / sum with
+    // shuffles.  (One thread per row -- 81 strided scalar loads and expf's in a serial loop -- made this single-block kernel 84 us.)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int i = wv; i < n; i += nwv) {
         const T* row = cls + (int64_t)i * C;
-        float m = -3.0e38f; int am = 0;
-        for (int c = 0; c < C; ++c) { const float v = Elt<T>::ld(row + c); if (v > m) { m = v; am = c; } }
+        float m = -3.0e38f; int am = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) { const float v = Elt<T>::ld(row + c); if (v > m) { m = v; am = c; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {                       // max with the LOWEST index among equal maxima (as the serial scan)
+            const float m2 = __shfl_xor(m, o); const int a2 = __shfl_xor(am, o);
+            if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+        }
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(Elt<T>::ld(row + c) - m);
+        for (int c = lane; c < C; c += 64) s += expf(Elt<T>::ld(row + c) - m);
+        s = wave_sum(s);
         const float l = m + logf(s);
+        if (lane != 0) continue;
         lse[i] = l;
         const uint8_t f = flags[i];
         if (!(f & 1)) continue;

@@ -34,10 +34,33 @@ def test_header_symbols_exported(built_lib):
         assert hasattr(lib, s), f"{s} declared in include/swin_hip.h but not exported"
 
 
+def test_fp16_build_exports_the_same_abi():
+    """libswin_hip_f16.so (-DSWIN_HALF: the 16-bit type is IEEE half, the reference's apex O1 precision) is the same ABI: every
+    declared symbol, and it says which build it is (pure host calls)."""
+    from swin_transformer_object_detection_amd.build import build_library
+    lib = ctypes.CDLL(build_library(half=True))
+    for s in _declared_symbols():
+        assert hasattr(lib, s), f"{s} missing from the fp16 build"
+    assert lib.swin_hip_half_type() == 1 and lib.swin_hip_abi_version() == 2
+
+
+def test_half_dtype_choice_is_per_process():
+    """SWIN_HALF_DTYPE=fp16 selects the fp16 library; the bf16 process refuses to switch once its library is loaded"""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from swin_transformer_object_detection_amd import _lib\n"
+            "assert _lib.half_dtype() == torch.float16 and _lib.LIB_PATH.endswith('libswin_hip_f16.so')\n"
+            "assert _lib.lib().swin_hip_half_type() == 1\n"
+            "try:\n    _lib.set_half_dtype(torch.bfloat16)\nexcept _lib.SwinHipError:\n    print('REFUSED')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SWIN_HALF_DTYPE="fp16"))
+    assert r.returncode == 0 and "REFUSED" in r.stdout, r.stdout + r.stderr
+
+
 def test_ctypes_table_matches_header(built_lib):
     from swin_transformer_object_detection_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
     assert _lib.lib().swin_hip_abi_version() == 2          # pure host call
+    assert _lib.lib().swin_hip_half_type() == 0 and _lib.half_dtype() == torch.bfloat16
 
 
 def test_header_cites_reference_for_every_entry_point():
