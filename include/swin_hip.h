@@ -110,8 +110,20 @@ int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bi
  * -30000 for key >= 49 (folds the 49->64 padding mask into the bias).  Index rule of
  * swin_transformer.py:101-110.  */
 int swin_rel_bias_expand(const float* table, float* bias_exp, int nH, void* stream);
+/* the same for n tables (nH[i] heads each) in one launch: the expansions are a function of the parameters alone, so a training
+ * loop rebuilds all of them once per optimizer step instead of once per block forward */
+int swin_rel_bias_expand_multi(const float* const* tables, float* const* outs, const int* nH, int n, void* stream);
 /* dbias_exp (nH,64,64) -> dtable (169,nH), ACCUMULATED. */
 int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int nH, void* stream);
+/* The small reductions behind a block backward as ONE launch (csrc/tail_reduce.hip); problem i of n, parallel arrays:
+ *   kind 0 (column sums): src (rows, cols) f32; columns [0, a0) are ADDED into dst0, columns [a0, cols) into dst1 -- the
+ *           [dgamma | dbeta] partial rows swin_layernorm_bwd leaves in its workspace (rows = workspace bytes / (8 C), a0 = C);
+ *   kind 1 (relative position bias): src = the attention backward's workspace (rows slabs of `cols` floats, slab s belongs to
+ *           head s % a0); ADDS the [key][query] tiles into dst0 = dtable (169, a0) by the index rule of swin_transformer.py:105-110
+ *           and the pad-token sums into dst1 = dqkv_bias_pad (3, a1) (NULL: skipped).
+ * swin_block_bwd uses this internally for norm2 / the next norm / the bias table (no (nH,64,64) intermediate, no memset). */
+int swin_tail_reduce(const int* kind, const float* const* src, float* const* dst0, float* const* dst1, const int* rows,
+                     const int* cols, const int* a0, const int* a1, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Elementwise pieces of the block.

@@ -56,7 +56,9 @@ SIGNATURES = {
     "swin_window_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "swin_window_attn_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "swin_rel_bias_expand": [_p, _p, _i, _p],
+    "swin_rel_bias_expand_multi": [_p, _p, _p, _i, _p],
     "swin_rel_bias_reduce": [_p, _p, _i, _p],
+    "swin_tail_reduce": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "swin_bias_gelu_fwd": [_p, _p, _p, _i64, _i, _i, _p],
     "swin_bias_gelu_bwd": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
     "swin_patch_merge_ln_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],

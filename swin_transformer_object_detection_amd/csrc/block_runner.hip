@@ -14,7 +14,7 @@
 
 // Forward pointer table (all device pointers; bf16 activations / weights unless noted):
 //  0 x            1 n1           2 dp0 (B f32|null)   3 dp1 (B f32|null)
-//  4 wqkv (3C,C)  5 bqkv16|null  6 bqkv32 (3C f32)    7 table (169,nH f32)   8 bias_exp (nH,64,64 f32, out)
+//  4 wqkv (3C,C)  5 bqkv16|null  6 bqkv32 (3C f32)    7 table (169,nH f32)|null   8 bias_exp (nH,64,64 f32; out, or in when 7 is null)
 //  9 wproj (C,C)  10 bproj16|null 11 n2w f32 12 n2b f32 13 w1 (4C,C) 14 b1 (4C f32) 15 w2 (C,4C) 16 b216|null
 //  17 nnw f32|null 18 nnb f32|null
 //  outputs / saved: 19 qkv (T,3C) 20 lse (f32) 21 o 22 y (tmp) 23 x1 24 n2 25 mean2 26 rstd2 27 hpre (T,4C) 28 h (T,4C)
@@ -29,7 +29,7 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
     const int64_t L = (int64_t)H * W, T = (int64_t)B * L;
     void* ws = const_cast<void*>(p[34]);
     CHK(swin_gemm_bf16(p[1], p[4], p[5], const_cast<void*>(p[19]), T, 3 * C, C, 0, ws, stream));
-    CHK(swin_rel_bias_expand((const float*)p[7], (float*)p[8], nH, stream));
+    if (p[7]) CHK(swin_rel_bias_expand((const float*)p[7], (float*)p[8], nH, stream));     // null: 8 already holds this step's expansion
     CHK(swin_window_attn_fwd(p[19], (const float*)p[6], (const float*)p[8], const_cast<void*>(p[21]), (float*)p[20], B, H, W, C, nH,
                              shift, scale, SWIN_BF16, stream));
     CHK(swin_gemm_bf16(p[21], p[9], p[10], const_cast<void*>(p[22]), T, C, C, 0, ws, stream));
@@ -64,7 +64,7 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
 //          required with a next norm)
 //  out:    26 dx   27 dn1
 //  temporaries: 28 dx1  29 dy2 (INPUT when there is no next norm: dx2 scaled by DropPath, or dx2 itself)  30 dh (T,4C)
-//          31 dhpre (T,4C)  32 dn2  33 dy  34 do  35 dqkv (T,3C)  36 dbexp (nH,64,64 f32; zeroed here)
+//          31 dhpre (T,4C)  32 dn2  33 dy  34 do  35 dqkv (T,3C)  36 unused (was dbexp)
 //  fp32 gradient accumulators (null = not wanted): 37 dWqkv 38 dbqkv 39 dbqkv_pad 40 dWproj 41 dbproj 42 dW1 43 db1 44 dW2
 //          45 db2 46 dn2w 47 dn2b 48 dnnw 49 dnnb 50 dtable
 //  workspaces: 51 attention backward  52 LayerNorm backward (norm2)  53 LayerNorm backward (next norm)  54 gemm
@@ -81,6 +81,10 @@ struct AuxScope {                 // the auxiliary stream is set (and its launch
     ~AuxScope() { if (on) swin_aux_defer(false); swin_set_aux_stream(nullptr); }
     bool on;
 };
+struct TailScope {                // the block's small reductions are collected and flushed as one launch (csrc/tail_reduce.hip)
+    TailScope() { swin_tail_collect(true); }
+    ~TailScope() { swin_tail_collect(false); }
+};
 
 extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const float* fv, void* stream) {
     if (!p || !iv || !fv) return SWIN_ERR_BAD_ARG;
@@ -92,6 +96,7 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     void* const wst = side ? side : stream;
     static const bool aux_on = swin_dev_int("SWIN_AUX_REDUCE", 1) != 0;      // development A/B (-DSWIN_DEV builds only)
     AuxScope aux(side && aux_on ? side : nullptr);
+    TailScope tail;
     const int B = (int)iv[0], H = (int)iv[1], W = (int)iv[2], C = (int)iv[3], nH = (int)iv[4], shift = (int)iv[5];
     const float scale = fv[0];
     const int64_t L = (int64_t)H * W, T = (int64_t)B * L;
@@ -143,16 +148,20 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     // proj
     CHK(swin_gemm_bf16(dy, p[17], nullptr, M(34), T, C, C, 1, gws, stream));
     // window attention
-    if (hipMemsetAsync(M(36), 0, (size_t)nH * 64 * 64 * sizeof(float), (hipStream_t)stream) != hipSuccess) return SWIN_ERR_LAUNCH;
-    CHK(swin_window_attn_bwd(p[1], (const float*)p[23], (const float*)p[2], (const float*)p[3], p[34], M(35), (float*)p[36],
-                             (float*)p[39], M(51), B, H, W, C, nH, shift, scale, SWIN_BF16, stream));
-    if (p[50]) CHK(swin_rel_bias_reduce((const float*)p[36], (float*)p[50], nH, stream));
+    {   // the per-wave bias-gradient slabs go straight into the (169, nH) table in the block's tail launch
+        int n_slabs = 0, slab_stride = 0;
+        CHK(swin_window_attn_bwd_slabs(p[1], (const float*)p[23], (const float*)p[2], (const float*)p[3], p[34], M(35), (float*)p[39],
+                                       M(51), B, H, W, C, nH, shift, scale, stream, &n_slabs, &slab_stride));
+        if (p[50]) swin_tail_push(SwinTailProb{(const float*)p[51], (float*)p[50], (float*)p[39], SWIN_TAIL_RELBIAS, n_slabs, slab_stride,
+                                               nH, C, 0});
+    }
     // qkv
     CHK(swin_gemm_bf16(p[35], p[16], nullptr, M(27), T, C, 3 * C, 1, gws, stream));
 
     // ---- off the chain: one fork, then the collected reductions and the weight gradients (dW += dY^T X, db += colsum dY)
     if (aux.on) CHK(swin_aux_flush(stream, side));
     else if (side) CHK(swin_fork_stream(stream, side));
+    CHK(swin_tail_flush(wst));
     if (record) {                 // iv[7]: recorded for the caller's next grouped launch (swin_wgrad_flush) instead of four launches here
         if (p[44]) CHK(swin_wgrad_record(dy2, hbuf, (float*)p[44], (float*)p[45], T, C, 4 * C));
         if (p[42]) CHK(swin_wgrad_record(p[31], p[8], (float*)p[42], db1_from_wgrad ? (float*)p[43] : nullptr, T, 4 * C, C));

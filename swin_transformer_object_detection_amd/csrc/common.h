@@ -63,6 +63,25 @@ void* swin_aux_stream(void);
 void swin_aux_defer(bool on);                                 // block runner: collect the reductions, flush once
 int swin_aux_flush(void* main, void* side);
 
+// csrc/tail_reduce.hip: the small parameter-gradient reductions of a block backward collected into one table-driven launch
+enum { SWIN_TAIL_COLSUM = 0, SWIN_TAIL_RELBIAS = 1 };
+struct SwinTailProb {
+    const float* src;      // COLSUM: partial rows [rows][cols];  RELBIAS: attention-backward slabs [rows][cols] (cols = slab stride)
+    float* dst0;           // COLSUM: columns [0, a0) are added here;  RELBIAS: dtable (169, nH)
+    float* dst1;           // COLSUM: columns [a0, cols) are added here;  RELBIAS: dbias_pad (3, C) or null
+    int kind, rows, cols;
+    int a0, a1;            // COLSUM: a0 = split column;  RELBIAS: a0 = nH, a1 = C
+    int blk0;              // first thread block of this problem (filled in by the launcher)
+};
+void swin_tail_collect(bool on);                              // open / close (and drop) a collection on the current device
+bool swin_tail_push(const SwinTailProb& p);                   // true: queued for swin_tail_flush; false: no collection open
+int swin_tail_flush(void* stream);
+int swin_tail_launch(const SwinTailProb* probs, int n, void* stream);
+// swin_window_attn_bwd without its bias-gradient reduce: the slabs stay in `workspace` (n_slabs of slab_stride floats)
+int swin_window_attn_bwd_slabs(const void* qkv, const float* qkv_bias, const float* bias_exp, const float* lse, const void* dout,
+                               void* dqkv, float* dqkv_bias_pad, void* workspace, int B, int H, int W, int C, int nH, int shift,
+                               float scale, void* stream, int* n_slabs, int* slab_stride);
+
 template <typename T> struct Elt;
 template <> struct Elt<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }

@@ -341,6 +341,8 @@ static int ln_bwd_launch(Src src, const T* dy, const float* gamma, const float* 
                                                                               scale, rps, dgamma, dbeta, rows, C, use_slab,
                                                                               partials)))
     if (partials) {
+        // a block backward is collecting its small reductions into one launch (csrc/tail_reduce.hip)
+        if (swin_tail_push(SwinTailProb{partials, dgamma, dbeta, SWIN_TAIL_COLSUM, blocks, 2 * C, C, 0, 0})) return swin_launch_status();
         // nobody on this stream consumes the parameter gradients: with an auxiliary stream set, reduce them there
         auto launch = [=](void* st) {
             ln_param_reduce_kernel<<<(2 * C + 63) / 64, 1024, 0, (hipStream_t)st>>>(partials, blocks, C, dgamma, dbeta);

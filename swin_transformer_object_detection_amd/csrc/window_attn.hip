@@ -1000,6 +1000,45 @@ extern "C" int swin_rel_bias_expand(const float* table, float* bias_exp, int nH,
     return swin_launch_status();
 }
 
+// every block's table in one launch (the expanded tables are a function of the parameters alone: the caller rebuilds them once per
+// optimizer step, not once per block forward)
+struct ExpTab { int n; const float* t[48]; float* o[48]; int nH[48]; };
+__global__ void rel_bias_expand_multi_kernel(ExpTab tab) {
+    const int j = blockIdx.y;
+    const int nH = tab.nH[j];
+    const float* __restrict__ table = tab.t[j];
+    float* __restrict__ out = tab.o[j];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nH * TILE * TILE; i += gridDim.x * blockDim.x) {
+        int q = i & 63, k = (i >> 6) & 63, h = i >> 12;
+        float v = NEG_BIG;
+        if (k < NTOK) {
+            v = 0.f;
+            if (q < NTOK) {
+                int qh = q / 7, qw = q % 7, kh = k / 7, kw = k % 7;
+                v = table[((qh - kh + 6) * 13 + (qw - kw + 6)) * nH + h];   // swin_transformer.py:105-110
+            }
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int swin_rel_bias_expand_multi(const float* const* tables, float* const* outs, const int* nH, int n, void* stream) {
+    if (!tables || !outs || !nH || n <= 0) return SWIN_ERR_BAD_ARG;
+    for (int i0 = 0; i0 < n; i0 += 48) {
+        ExpTab tab;
+        tab.n = n - i0 < 48 ? n - i0 : 48;
+        int mx = 0;
+        for (int i = 0; i < tab.n; ++i) {
+            if (!tables[i0 + i] || !outs[i0 + i] || nH[i0 + i] <= 0) return SWIN_ERR_BAD_ARG;
+            tab.t[i] = tables[i0 + i]; tab.o[i] = outs[i0 + i]; tab.nH[i] = nH[i0 + i];
+            mx = nH[i0 + i] > mx ? nH[i0 + i] : mx;
+        }
+        const int bx = mx * 16 < 64 ? mx * 16 : 64;
+        rel_bias_expand_multi_kernel<<<dim3(bx, tab.n), 256, 0, (hipStream_t)stream>>>(tab);
+    }
+    return swin_launch_status();
+}
+
 extern "C" int swin_rel_bias_reduce(const float* dbias_exp, float* dtable, int nH, void* stream) {
     if (!dbias_exp || !dtable || nH <= 0) return SWIN_ERR_BAD_ARG;
     auto launch = [=](void* st) {
@@ -1043,6 +1082,37 @@ extern "C" int64_t swin_window_attn_bwd_workspace_bytes(int B, int H, int W, int
     return (int64_t)attn_bwd_blocks(B * g.nW * nH, nH) * 4 * SLAB * sizeof(float);
 }
 
+static_assert(TILE == 64 && NTOK == 49 && HD == 32, "csrc/tail_reduce.hip restates these");
+
+// the bf16 backward launch alone: dqkv written, the per-wave bias-gradient slabs left in `workspace`
+int swin_window_attn_bwd_slabs(const void* qkv, const float* qkv_bias, const float* bias_exp, const float* lse, const void* dout,
+                               void* dqkv, float* dqkv_bias_pad, void* workspace, int B, int H, int W, int C, int nH, int shift,
+                               float scale, void* stream, int* n_slabs, int* slab_stride) {
+    int st = check_attn_args(qkv, qkv_bias, bias_exp, dqkv, B, H, W, C, nH, shift, SWIN_BF16);
+    if (st != SWIN_OK) return st;
+    if (!lse || !dout || !workspace) return SWIN_ERR_BAD_ARG;
+    if ((H % 7 != 0 || W % 7 != 0) && !dqkv_bias_pad) return SWIN_ERR_BAD_ARG;
+    WinGeom g = make_geom(B, H, W, C, nH, shift);
+    const int n_tasks = B * g.nW * nH;
+    const int blocks = attn_bwd_blocks(n_tasks, nH);
+    static bool attr_set[16] = {};                       // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)win_attn_bwd2_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(4 * sizeof(BwdLds2))) != hipSuccess) return SWIN_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    const int ppb = attn_bwd_ppb(nH);
+    const int iters = (n_tasks + blocks * ppb - 1) / (blocks * ppb);
+    win_attn_bwd2_bf16_kernel<<<blocks, 128 * ppb, ppb * sizeof(BwdLds2), (hipStream_t)stream>>>(
+        (const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout, (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks,
+        iters, ppb);
+    if (n_slabs) *n_slabs = blocks * ppb;
+    if (slab_stride) *slab_stride = SLAB;
+    return swin_launch_status();
+}
+
 extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_exp, const float* lse,
                                     const void* dout, void* dqkv, float* dbias_exp, float* dqkv_bias_pad,
                                     void* workspace, int B, int H, int W, int C, int nH, int shift, float scale,
@@ -1051,29 +1121,17 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
     if (st != SWIN_OK) return st;
     if (!lse || !dout || !dbias_exp) return SWIN_ERR_BAD_ARG;
     if ((H % 7 != 0 || W % 7 != 0) && !dqkv_bias_pad) return SWIN_ERR_BAD_ARG;
-    WinGeom g = make_geom(B, H, W, C, nH, shift);
-    int n_tasks = B * g.nW * nH;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SWIN_BF16) {
-        if (!workspace) return SWIN_ERR_BAD_ARG;
-        int blocks = attn_bwd_blocks(n_tasks, nH);
-        static bool attr_set[16] = {};                       // per device: the attribute belongs to the device's code object
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SWIN_ERR_UNSUPPORTED;
-        if (!attr_set[dev]) {
-            if (hipFuncSetAttribute((const void*)win_attn_bwd2_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(4 * sizeof(BwdLds2))) != hipSuccess) return SWIN_ERR_LAUNCH;
-            attr_set[dev] = true;
-        }
-        const int ppb = attn_bwd_ppb(nH);
-        const int iters = (n_tasks + blocks * ppb - 1) / (blocks * ppb);
-        win_attn_bwd2_bf16_kernel<<<blocks, 128 * ppb, ppb * sizeof(BwdLds2), s>>>((const bf16*)qkv, qkv_bias, bias_exp, lse, (const bf16*)dout,
-                                                           (bf16*)dqkv, (float*)workspace, dqkv_bias_pad, g, scale, n_tasks, iters, ppb);
+        int n_slabs = 0;
+        st = swin_window_attn_bwd_slabs(qkv, qkv_bias, bias_exp, lse, dout, dqkv, dqkv_bias_pad, workspace, B, H, W, C, nH, shift, scale,
+                                        stream, &n_slabs, nullptr);
+        if (st != SWIN_OK) return st;
         int n = nH * (TILE * TILE + 3 * HD);
         dim3 rgrid((n + 255) / 256, 16);
         // bias-gradient reduce: off the data-gradient chain (see csrc/abi.hip)
         auto launch = [=](void* st) {
-            dbias_slab_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)st>>>((const float*)workspace, dbias_exp, dqkv_bias_pad, blocks * ppb, nH, C);
+            dbias_slab_reduce_kernel<<<rgrid, 256, 0, (hipStream_t)st>>>((const float*)workspace, dbias_exp, dqkv_bias_pad, n_slabs, nH, C);
             return swin_launch_status();
         };
         if (!swin_aux_push(launch)) {
@@ -1086,7 +1144,8 @@ extern "C" int swin_window_attn_bwd(const void* qkv, const float* qkv_bias, cons
             return launch(rs);
         }
     } else {
-        win_attn_bwd_f32_kernel<<<n_tasks, 64, 0, s>>>((const float*)qkv, qkv_bias, bias_exp, lse, (const float*)dout,
+        WinGeom g = make_geom(B, H, W, C, nH, shift);
+        win_attn_bwd_f32_kernel<<<B * g.nW * nH, 64, 0, s>>>((const float*)qkv, qkv_bias, bias_exp, lse, (const float*)dout,
                                                        (float*)dqkv, dbias_exp, dqkv_bias_pad, g, scale);
     }
     return swin_launch_status();

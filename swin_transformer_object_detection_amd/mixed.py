@@ -514,18 +514,39 @@ def linear_t_weight(master, shadow):
     return _DERIVED[k]
 
 
+def rel_bias_expanded(table, gate_master):
+    """The (nH, 64, 64) expansion of a relative-position-bias table (swin_transformer.py:105-110 with the 49 -> 64 padding mask
+    folded in) as a persistent buffer that refresh_aux() rebuilds for every registered table in one launch after each optimizer
+    step.  Only while ``gate_master`` (a weight of the same block) has a shadow -- the table then changes exactly when the shadows
+    are refreshed; returns None otherwise (the caller expands the table itself)."""
+    if gate_master is None or id(gate_master) not in _SHADOW or not table.is_cuda or table.dtype != torch.float32:
+        return None
+    k = (id(table), 'relbias')
+    v = _DERIVED.get(k)
+    if v is not None:
+        return v
+    ent = _AUX.get(k)
+    if ent is None or ent[0] is not table:
+        _AUX[k] = (table, torch.empty(table.shape[1], 64, 64, device=table.device, dtype=torch.float32))
+    refresh_aux()
+    return _DERIVED[k]
+
+
 def refresh_aux():
     """Rebuild every registered auxiliary layout from the current shadows (one multi-tensor launch per kind) and publish them."""
     if not _AUX:
         return
-    from .ops.functional import conv_dgrad_layout_multi, linear_t_layout_multi
+    from .ops.functional import conv_dgrad_layout_multi, linear_t_layout_multi, rel_bias_expand_multi
     conv = [(k, e) for k, e in _AUX.items() if k[1] == 'dgrad']
     lin = [(k, e) for k, e in _AUX.items() if k[1] == 't']
+    rel = [(k, e) for k, e in _AUX.items() if k[1] == 'relbias']
     if conv:
         conv_dgrad_layout_multi([e[0] for _, e in conv], [e[1] for _, e in conv])
     if lin:
         linear_t_layout_multi([e[0] for _, e in lin], [e[1] for _, e in lin])
-    for k, e in conv + lin:
+    if rel:
+        rel_bias_expand_multi([e[0].detach() for _, e in rel], [e[1] for _, e in rel])
+    for k, e in conv + lin + rel:
         _DERIVED[k] = e[1]
 
 
@@ -591,6 +612,8 @@ class ShadowParams:
         for p in self.masters:
             _AUX.pop((id(p), 'dgrad'), None)
             _AUX.pop((id(p), 't'), None)
+        for k in [k for k in _AUX if k[1] == 'relbias']:      # gated on a shadowed weight of their block: none survives the shadows
+            _AUX.pop(k, None)
         _DERIVED.clear()
 
 

@@ -195,6 +195,21 @@ def rel_bias_expand(table):
     return out
 
 
+def rel_bias_expand_multi(tables, outs):
+    """outs[i] (nH_i, 64, 64) f32 <- the expansion of tables[i] (169, nH_i) f32, all in one launch"""
+    n = len(tables)
+    if n == 0:
+        return
+    for t, o in zip(tables, outs):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[0] == 169 and t.is_contiguous()
+                and o.dtype == torch.float32 and o.is_contiguous() and o.numel() == t.shape[1] * 4096):
+            raise SwinHipError("rel_bias_expand_multi: contiguous f32 (169, nH) tables and (nH, 64, 64) outputs")
+    tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tables])
+    op = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
+    hh = (ctypes.c_int * n)(*[t.shape[1] for t in tables])
+    call("swin_rel_bias_expand_multi", tp, op, hh, n, _s())
+
+
 class _WindowAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, qkv_bias, table, B, H, W, nH, shift):

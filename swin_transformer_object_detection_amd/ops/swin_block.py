@@ -286,13 +286,21 @@ class _SwinBlockFn(torch.autograd.Function):
             qkv, o, y, x1, n2, hpre, h, y2 = _carve(flat, [3 * TC, TC, TC, TC, TC, 4 * TC, 4 * TC, TC])
         nW = ((H + 6) // 7) * ((W + 6) // 7)
         nl = B * nW * nH * 64
-        f32 = torch.empty(nl + 4 * T + nH * 4096, device=dev, dtype=torch.float32)
-        lse, mean2, rstd2, mean3, rstd3, bias_exp = _carve(f32, [nl, T, T, T, T, nH * 4096])
+        # the expanded bias table: this step's persistent copy (rebuilt for all blocks in one launch after the optimizer step) when
+        # the block's weights are shadowed, else expanded here by the runner
+        bias_exp = mixed.rel_bias_expanded(table, masters[0])
+        step_exp = bias_exp is not None
+        f32 = torch.empty(nl + 4 * T + (0 if step_exp else nH * 4096), device=dev, dtype=torch.float32)
+        if step_exp:
+            lse, mean2, rstd2, mean3, rstd3 = _carve(f32, [nl, T, T, T, T])
+            bias_exp = bias_exp.view(-1)
+        else:
+            lse, mean2, rstd2, mean3, rstd3, bias_exp = _carve(f32, [nl, T, T, T, T, nH * 4096])
         x2 = torch.empty_like(x)
         nn_ = torch.empty_like(x) if has_next else None
         qkv_bias = bqkv.detach() if bqkv is not None else torch.zeros(3 * C, device=dev)
         gws = _scratch(dev, 'gemm', _lib.lib().swin_gemm_workspace_bytes())
-        tab = _f32(table.detach())
+        tab = None if step_exp else _f32(table.detach())
         f_n2w, f_n2b = _f32(n2w), _f32(n2b)
         f_nnw, f_nnb = (_f32(nnw), _f32(nnb)) if has_next else (None, None)
         bq16, bp16, b216 = _bias16(bqkv), _bias16(bproj), _bias16(b2)
@@ -340,7 +348,7 @@ class _SwinBlockFn(torch.autograd.Function):
             dy2 = dx2 if dp1 is None else (dx2.view(B, -1) * dp1.to(dx2.dtype).view(B, 1)).view_as(dx2)
         dx = torch.empty_like(x1)
         dn1 = torch.empty_like(x1)
-        dbexp = torch.empty(nH * 4096, device=dev, dtype=torch.float32)
+        dbexp = None          # entry 36: no longer used by the runner (the bias slabs go straight into the table, csrc/tail_reduce.hip)
         padded = (H % 7 != 0) or (W % 7 != 0)
         a_wqkv, f_wqkv = _acc_weight(wqkv, m_wqkv, nig[6])
         a_wproj, f_wproj = _acc_weight(wproj, m_wproj, nig[9])

@@ -1033,3 +1033,67 @@ def test_gemm_plan_export_import_roundtrip(ops):
     torch.cuda.synchronize()
     assert float((c0.float() - c1.float()).abs().max()) <= 2.0 ** -7 * float(c0.float().abs().max())
     lib.swin_gemm_plans_import(buf, n)                                   # back to the tuned choice
+
+
+def test_tail_reduce_equals_separate_reductions(ops):
+    """csrc/tail_reduce.hip: LayerNorm parameter-gradient partial rows and the attention backward's bias-gradient slabs reduced in
+    ONE launch, against torch column sums and against the two-kernel path (slab reduce into (nH,64,64), then the index-rule
+    reduce of swin_transformer.py:105-110)."""
+    import ctypes
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    B, H, W, nH, shift = 2, 30, 45, 3, 3                       # padded grid: the pad-token part of the qkv bias gradient is exercised
+    C = 32 * nH
+    g = torch.Generator().manual_seed(11)
+    qkv = dev(torch.randn(B, H * W, 3 * C, generator=g) * 0.7, torch.bfloat16)
+    qb = dev(torch.randn(3 * C, generator=g) * 0.3)
+    table = dev(torch.randn(169, nH, generator=g) * 0.5)
+    dout = dev(torch.randn(B, H * W, C, generator=g), torch.bfloat16)
+    bias_exp = ops.rel_bias_expand(table)
+    out = torch.empty(B, H * W, C, device=qkv.device, dtype=qkv.dtype)
+    nW = ((H + 6) // 7) * ((W + 6) // 7)
+    lse = torch.empty(B * nW * nH, 64, device=qkv.device, dtype=torch.float32)
+    scale = 32 ** -0.5
+    Fn.call("swin_window_attn_fwd", Fn._p(qkv), Fn._p(qb), Fn._p(bias_exp), Fn._p(out), Fn._p(lse), B, H, W, C, nH, shift, scale,
+            Fn.SWIN_BF16, Fn._s())
+    ws_bytes = _lib.lib().swin_window_attn_bwd_workspace_bytes(B, H, W, nH, Fn.SWIN_BF16)
+    ws = torch.zeros(ws_bytes // 4, device=qkv.device, dtype=torch.float32)
+    dqkv = torch.empty_like(qkv)
+    dbexp = torch.zeros_like(bias_exp)
+    dpad_ref = torch.zeros(3 * C, device=qkv.device)
+    Fn.call("swin_window_attn_bwd", Fn._p(qkv), Fn._p(qb), Fn._p(bias_exp), Fn._p(lse), Fn._p(dout), Fn._p(dqkv), Fn._p(dbexp),
+            Fn._p(dpad_ref), Fn._p(ws), B, H, W, C, nH, shift, scale, Fn.SWIN_BF16, Fn._s())
+    dtable_ref = torch.zeros(169, nH, device=qkv.device)
+    Fn.call("swin_rel_bias_reduce", Fn._p(dbexp), Fn._p(dtable_ref), nH, Fn._s())
+    torch.cuda.synchronize()
+    slab = 64 * 64 + 3 * 32 + 32
+    blocks = ws.numel() // (4 * slab)                          # the workspace is sized for 4 waves-pairs per block; 3 heads use 3
+    assert blocks * 4 * slab == ws.numel()
+    n_slabs = blocks * 3
+    # two LayerNorm-style problems of different widths next to the bias problem
+    parts = [dev(torch.randn(rows, 2 * c, generator=g)) for rows, c in ((768, 96), (37, 192))]
+    dg = [torch.full((p.shape[1] // 2,), 0.5, device=qkv.device) for p in parts]      # accumulated INTO (+=)
+    db = [torch.full((p.shape[1] // 2,), -0.25, device=qkv.device) for p in parts]
+    dtable = torch.ones(169, nH, device=qkv.device)
+    dpad = torch.ones(3 * C, device=qkv.device)
+    srcs = parts + [ws]
+    d0 = dg + [dtable]
+    d1 = db + [dpad]
+    kinds = [0, 0, 1]
+    rows = [p.shape[0] for p in parts] + [n_slabs]
+    cols = [p.shape[1] for p in parts] + [slab]
+    a0 = [p.shape[1] // 2 for p in parts] + [nH]
+    a1 = [0, 0, C]
+    n = len(kinds)
+    ia = lambda v: (ctypes.c_int * n)(*v)
+    pa = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    Fn.call("swin_tail_reduce", ia(kinds), pa(srcs), pa(d0), pa(d1), ia(rows), ia(cols), ia(a0), ia(a1), n, Fn._s())
+    torch.cuda.synchronize()
+    for p, a, b in zip(parts, dg, db):
+        c = p.shape[1] // 2
+        s = p.double().sum(0)
+        close(a, (s[:c] + 0.5).float(), 1e-3, 1e-5, msg="dgamma")
+        close(b, (s[c:] - 0.25).float(), 1e-3, 1e-5, msg="dbeta")
+    assert float(dtable_ref.abs().max()) > 0 and float(dpad_ref.abs().max()) > 0
+    close(dtable - 1.0, dtable_ref, 1e-4 * float(dtable_ref.abs().max()) + 1e-5, 1e-5, msg="dtable")
+    close(dpad - 1.0, dpad_ref, 1e-4 * float(dpad_ref.abs().max()) + 1e-5, 1e-5, msg="dbias_pad")
