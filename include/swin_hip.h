@@ -412,6 +412,12 @@ int swin_stream_create_low_priority(void** out);
  *   heads (rpn_head.py:41-47) fused with the ReLU backward of rpn_conv. */
 int conv3x3_nhwc_bf16_gated(const void* x, const void* w, const float* bias, const void* gate, void* y, int N, int H, int W,
                             int Cin, int Cout, void* stream);
+/* The same convolution (gate may be NULL; with a gate relu is ignored by the callers above) in its halo-staged form (csrc/conv_halo.hip):
+ * a tile of 256 consecutive pixels stages its three input row segments ONCE per 32-channel block and streams only weight tiles.
+ * conv3x3_nhwc_bf16 / _ws / _gated route the many-pixel maps here themselves; this entry always uses it (parity tests, tools).
+ * nt: 2 (tile 256 x 128) or 4 (256 x 256, Cout % 256 == 0), 0 = choose.  Cin % 32 == 0, Cout % 8 == 0; else SWIN_ERR_UNSUPPORTED. */
+int conv3x3_halo_nhwc_bf16(const void* x, const void* w, const float* bias, const void* gate, void* y, int N, int H, int W, int Cin,
+                           int Cout, int relu, int nt, void* stream);
 int narrow_dgrad_gated_bf16(const void* dy, const void* w, const void* gate, void* dx, int64_t T, int K, int C, void* stream);
 
 /* conv3x3_splitk_workspace_bytes / conv3x3_nhwc_bf16_ws: the same convolutions for maps with so few 128 x 128 output tiles that one

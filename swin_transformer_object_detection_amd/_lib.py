@@ -97,6 +97,7 @@ SIGNATURES = {
     "swin_fork_stream": [_p, _p],
     "swin_stream_create_low_priority": [_p],
     "conv3x3_nhwc_bf16_gated": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "conv3x3_halo_nhwc_bf16": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "narrow_dgrad_gated_bf16": [_p, _p, _p, _p, _i64, _i, _i, _p],
     "conv3x3_splitk_workspace_bytes": [_i, _i, _i, _i, _i],
     "conv3x3_nhwc_bf16_ws": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i64, _p],

@@ -63,6 +63,10 @@ void* swin_aux_stream(void);
 void swin_aux_defer(bool on);                                 // block runner: collect the reductions, flush once
 int swin_aux_flush(void* main, void* side);
 
+// csrc/conv_halo.hip: the halo-staged 3x3 convolution (nt = 0: choose the tile width); SWIN_ERR_UNSUPPORTED when the shape does not fit
+int swin_conv_halo(const bf16* x, const bf16* Wt, const float* bias, const bf16* gate, bf16* y, int N, int H, int W, int Cin, int Cout, int relu,
+                   int nt, hipStream_t s);
+
 // csrc/tail_reduce.hip: the small parameter-gradient reductions of a block backward collected into one table-driven launch
 enum { SWIN_TAIL_COLSUM = 0, SWIN_TAIL_RELBIAS = 1 };
 struct SwinTailProb {

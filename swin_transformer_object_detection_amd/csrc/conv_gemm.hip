@@ -512,11 +512,24 @@ static int gemm_launch(ALoader A, const bf16* Wt, const float* bias, bf16* C, in
     return gemm_launch_wm<ALoader, false, 2, 2>(A, Wt, bias, C, M, Nn, K, s, gate);
 }
 
+// The halo-staged form (csrc/conv_halo.hip) for the many-pixel maps; SWIN_ERR_UNSUPPORTED = not this shape, use the implicit GEMM.
+static int conv_try_halo(const void* x, const void* w, const float* bias, const void* gate, void* y, int N, int H, int W, int Cin, int Cout,
+                         int relu, hipStream_t s) {
+    // from 400 tiles of 128 x 128 (P3 of the bench batch: 500; P4: 128 stays on the split-K implicit GEMM, where the two forms tie); 0 = never
+    static const int min128 = swin_dev_int("SWIN_CONV_HALO_MIN", 400);
+    const int64_t M = (int64_t)N * H * W;
+    const int64_t blocks128 = ((M + 127) / 128) * ((Cout + BN - 1) / BN);
+    if (min128 <= 0 || blocks128 < min128 || Cout % 128 != 0) return SWIN_ERR_UNSUPPORTED;
+    static const int nt = swin_dev_int("SWIN_CONV_HALO_NT", 0);
+    return swin_conv_halo((const bf16*)x, (const bf16*)w, bias, (const bf16*)gate, (bf16*)y, N, H, W, Cin, Cout, relu, nt, s);
+}
+
 // x (N,H,W,Cin) bf16 channels-last; w (Cout,3,3,Cin) bf16; bias (Cout) f32 or NULL; y (N,H,W,Cout) bf16.
 extern "C" int conv3x3_nhwc_bf16(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin,
                                  int Cout, int relu, void* stream) {
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SWIN_ERR_BAD_ARG;
     if (Cin % BK != 0 || Cout % 4 != 0) return SWIN_ERR_UNSUPPORTED;
+    if (int st = conv_try_halo(x, w, bias, nullptr, y, N, H, W, Cin, Cout, relu, (hipStream_t)stream); st != SWIN_ERR_UNSUPPORTED) return st;
     int64_t M = (int64_t)N * H * W;
     ConvA A{(const bf16*)x, M, ConvGeom{N, H, W, Cin}, Cin / BK};
     return gemm_launch(A, (const bf16*)w, bias, (bf16*)y, M, Cout, 9 * Cin, relu, (hipStream_t)stream);
@@ -537,6 +550,7 @@ extern "C" int conv3x3_nhwc_bf16_ws(const void* x, const void* w, const float* b
                                     int Cin, int Cout, int relu, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (workspace && workspace_bytes <= 0)) return SWIN_ERR_BAD_ARG;
     if (Cin % BK != 0 || Cout % 4 != 0) return SWIN_ERR_UNSUPPORTED;
+    if (int st = conv_try_halo(x, w, bias, gate, y, N, H, W, Cin, Cout, gate ? 0 : relu, (hipStream_t)stream); st != SWIN_ERR_UNSUPPORTED) return st;
     int64_t M = (int64_t)N * H * W;
     ConvA A{(const bf16*)x, M, ConvGeom{N, H, W, Cin}, Cin / BK};
     return gemm_launch(A, (const bf16*)w, bias, (bf16*)y, M, Cout, 9 * Cin, gate ? 0 : relu, (hipStream_t)stream, (const bf16*)gate,
@@ -550,6 +564,7 @@ extern "C" int conv3x3_nhwc_bf16_gated(const void* x, const void* w, const float
                                        int W, int Cin, int Cout, void* stream) {
     if (!x || !w || !y || !gate || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SWIN_ERR_BAD_ARG;
     if (Cin % BK != 0 || Cout % 4 != 0) return SWIN_ERR_UNSUPPORTED;
+    if (int st = conv_try_halo(x, w, bias, gate, y, N, H, W, Cin, Cout, 0, (hipStream_t)stream); st != SWIN_ERR_UNSUPPORTED) return st;
     int64_t M = (int64_t)N * H * W;
     ConvA A{(const bf16*)x, M, ConvGeom{N, H, W, Cin}, Cin / BK};
     return gemm_launch(A, (const bf16*)w, bias, (bf16*)y, M, Cout, 9 * Cin, 0, (hipStream_t)stream, (const bf16*)gate);

