@@ -8,10 +8,11 @@
 A step = forward_train + backward + gradient all-reduce (RCCL, overlapped) + AdamW step on a fixed
 synthetic batch of 2 images per GPU (BASELINE.json configs[1]; weak scaling).  Rank 0 prints ONE JSON
 line.  Besides the contract keys it carries
-  roofline     : the WindowAttention forward kernel (stage-1 geometry of this workload) timed live with
-                 HIP events on the launch stream, against the HBM roofline (DESIGN.md section 5);
-  roofline_mfma_kernels : the same measurement for the MFMA-bound kernels with the largest share of the step
-                 (3x3 conv forward/data-gradient, conv weight gradient, linear weight gradient);
+  roofline     : the step's dominant kernel -- the 3x3-conv weight gradient at the P2 geometry of this workload -- timed live
+                 with HIP events on the launch stream, cache-cold, against the MFMA roofline; `traffic` = HBM
+                 bytes per launch from the committed rocprofv3 --pmc passes in the same regime;
+  roofline_kernels : the same measurement for the WindowAttention core (HBM-bound; with the BASELINE metric's "MFMA util%") and for
+                 the other MFMA-bound kernels with large shares of the step (halo-staged 3x3 conv, linear weight gradient, fused MLP);
   cpu_baseline : the CPU oracle (torch-CPU fp32 restatement + C RoIAlign/NMS) timed on the host cores
                  on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -119,19 +120,21 @@ def attention_roofline(device, steps=30):
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(avg_ms, 5), "median_launch_ms": round(ms[len(ms) // 2], 5),
             "algorithmic_bytes_per_launch": alg_bytes, "cache": "cold (launches rotate over 4 x 98 MB of inputs/outputs)",
-            "step_share_profiled": step_shares({"a": "win_attn_fwd"}).get("a"),
+            "step_share": step_shares({"a": "win_attn_fwd"}).get("a"), "step_share_source": PROFILE_NOTE,
             "mfma_util": {"useful_tflops": round(useful_tflops, 1), "issued_tflops": round(issued_tflops, 1),
                           "issued_frac_of_dense_bf16_peak": round(issued_tflops / MFMA_PEAK_TFLOPS, 4)},
             "shape": {"B": B, "H": H, "W": W, "C": C, "heads": nH, "shift": 3, "windows": B * 29 * 46}}
 
 
-PROFILE_STATS = os.path.join(ROOT, "profiles", "r02_step_kernel_stats.csv")     # rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3`
-PROFILE_STEPS = 13
+# rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3 --graph off` (two-stream eager step), committed under profiles/
+PROFILE_STATS = os.path.join(ROOT, "profiles", "r03_step_kernel_stats.csv")
+PROFILE_NOTE = "share of the kernel time of profiles/r03_step_kernel_stats.csv (committed rocprofv3 summary of this bench command), not measured in this run"
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_roofline.json")      # FETCH_SIZE / WRITE_SIZE passes of tools/microbench.py rooflinep
 
 
 def step_shares(patterns):
     """share of the profiled step's kernel time taken by the kernels whose name contains each pattern (committed rocprofv3
-    summary; the roofline launches bench.py itself makes inside that trace are subtracted: 23 per MFMA case, 35 attention)."""
+    summary; bench.py's own roofline launches are in that trace too -- a few dozen launches against 13 steps)."""
     import csv
     try:
         rows = list(csv.DictReader(open(PROFILE_STATS)))
@@ -145,19 +148,41 @@ def step_shares(patterns):
     return out
 
 
-def gemm_rooflines(device, steps=20):
-    """The MFMA-bound kernels that take the largest share of the step, timed the same way (HIP events around the
-    C-ABI launch on the launch stream) at the workload's geometry: 3x3 conv on the P2 map (2x200x320, 256 -> 256,
-    forward = data-gradient kernel), its weight gradient, and the weight gradient of a stage-3 MLP linear.
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed counter passes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE, separate
+    rocprofv3 --pmc runs in the same cold-cache regime as the timing below); None if not collected"""
+    try:
+        with open(PMC_FILE) as f:
+            return round(json.load(f)["kernels"][key]["hbm_bytes_per_launch_corrected"])
+    except Exception:
+        return None
+
+
+def _time_launches(fn, steps):
+    for _ in range(3):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for s_, e_ in ev:
+        s_.record(); fn(); e_.record()
+    torch.cuda.synchronize()
+    ms = sorted(s_.elapsed_time(e_) for s_, e_ in ev)
+    return sum(ms) / len(ms), ms[len(ms) // 2]
+
+
+def gemm_rooflines(device, steps=18):
+    """The MFMA-bound kernels with the largest shares of the step, each timed live (HIP events around the C-ABI launch on the launch
+    stream) at the workload's geometry and CACHE-COLD: the launches rotate over three operand sets (3 x 131 MB of P2 maps > the
+    256 MB Infinity Cache), the regime of the step itself and of the counter passes behind `traffic`.  First entry = the step's
+    dominant kernel (the 3x3-conv weight gradient, csrc/wgrad_dma.hip), reported as `roofline`.
     Algorithmic flops per launch: SURVEY 8(d) formulas (2*B*H*W*256*256*9; 2*T*N1*N2)."""
     from swin_transformer_object_detection_amd.ops import functional as Fn
     B, H, W, C = PER_GPU_BATCH, IMG_H // 4, IMG_W // 4, 256
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(B, H, W, C, generator=g).to(device=device, dtype=_HD())
-    dy = torch.randn(B, H, W, C, generator=g).to(device=device, dtype=_HD())
+    sets = [(torch.randn(B, H, W, C, generator=g).to(device=device, dtype=_HD()), torch.randn(B, H, W, C, generator=g).to(device=device, dtype=_HD()))
+            for _ in range(3)]
     w = (torch.randn(C, 3, 3, C, generator=g) * 0.02).to(device=device, dtype=_HD())
     b = torch.zeros(C, device=device)
-    y = torch.empty_like(x)
+    y = torch.empty_like(sets[0][0])
     dw = torch.zeros(C, 3, 3, C, device=device)
     db = torch.zeros(C, device=device)
     T, N1, N2 = PER_GPU_BATCH * (IMG_H // 16) * (IMG_W // 16), 1536, 384
@@ -174,38 +199,44 @@ def gemm_rooflines(device, steps=20):
     my = torch.empty_like(mx)
     mh = torch.empty(Tm, 4 * Cm, device=device, dtype=_HD())
     mdh = torch.empty_like(mh)
+    k = [0]
+
+    def rot():
+        k[0] += 1
+        return sets[k[0] % 3]
+
+    def conv_wgrad():
+        dy_, x_ = rot()
+        Fn.call("wgrad_conv3x3_nhwc_bf16", Fn._p(dy_), Fn._p(x_), Fn._p(dw), Fn._p(db), B, H, W, C, C, Fn._s())
+
+    def conv_fwd():
+        x_, _ = rot()
+        Fn.call("conv3x3_nhwc_bf16", Fn._p(x_), Fn._p(w), Fn._p(b), Fn._p(y), B, H, W, C, C, 0, Fn._s())
+    conv_flops = 2.0 * B * H * W * C * C * 9
+    # (name, kernel-name pattern in the profile, PMC key, flops per launch, launcher, cache regime)
     cases = [
-        (f"ts_mlp_fwd_kernel (fused fc1+GELU+fc2, stage 1: T={Tm}, C={Cm})", 16.0 * Tm * Cm * Cm,
-         lambda: Fn.call("swin_mlp_fwd_bf16", Fn._p(mx), Fn._p(mw1), Fn._p(mb1), Fn._p(mw2), Fn._p(mb2), Fn._p(my), Tm, Cm, Fn._s())),
-        (f"ts_mlp_bwd_kernel (fused MLP data gradient with fc1 recompute, stage 1: T={Tm}, C={Cm})", 24.0 * Tm * Cm * Cm,
+        ("wgrad2_kernel<ConvSrc> (3x3 conv weight gradient, P2 2x200x320x256: LDS-DMA ring, split over t, fp32 atomics)", "wgrad2_kernelINS_7ConvSrc",
+         "wgrad2_conv@P2", conv_flops, conv_wgrad, "cold"),
+        ("conv_halo_kernel<4> (3x3 conv forward / data gradient, P2 2x200x320x256, halo-staged)", "conv_halo_kernel", "conv_halo@P2", conv_flops,
+         conv_fwd, "cold"),
+        (f"wgrad3_kernel (fc1 weight gradient alone, stage 3: T={T}, {N1}x{N2}; inside the step these run grouped: wgrad2_group_kernel)",
+         "wgrad2_group_kernel", None, 2.0 * T * N1 * N2,
+         lambda: Fn.call("wgrad_linear_bf16", Fn._p(ldy), Fn._p(lx), Fn._p(ldw), Fn._p(ldb), T, N1, N2, Fn._s()), "warm (18 MB of operands)"),
+        (f"ts_mlp_bwd_kernel (fused MLP data gradient with fc1 recompute, stage 1: T={Tm}, C={Cm})", "ts_mlp_bwd_kernel", None, 24.0 * Tm * Cm * Cm,
          lambda: Fn.call("swin_mlp_bwd_bf16", Fn._p(mx), Fn._p(mdy), Fn._p(mw1), Fn._p(mb1), Fn._p(mw2), Fn._p(my), Fn._p(mh),
-                         Fn._p(mdh), Tm, Cm, Fn._s())),
-        ("gemm_bf16_kernel<ConvA> (3x3 conv fwd/dgrad, P2 2x200x320x256)", 2.0 * B * H * W * C * C * 9,
-         lambda: Fn.call("conv3x3_nhwc_bf16", Fn._p(x), Fn._p(w), Fn._p(b), Fn._p(y), B, H, W, C, C, 0, Fn._s())),
-        ("wgrad_kernel<ConvX> (3x3 conv weight gradient, P2)", 2.0 * B * H * W * C * C * 9,
-         lambda: Fn.call("wgrad_conv3x3_nhwc_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), B, H, W, C, C, Fn._s())),
-        (f"wgrad_kernel<PlainX> (fc1 weight gradient, stage 3: T={T}, {N1}x{N2})", 2.0 * T * N1 * N2,
-         lambda: Fn.call("wgrad_linear_bf16", Fn._p(ldy), Fn._p(lx), Fn._p(ldw), Fn._p(ldb), T, N1, N2, Fn._s())),
+                         Fn._p(mdh), Tm, Cm, Fn._s()), "warm"),
+        (f"ts_mlp_fwd_kernel (fused fc1+GELU+fc2, stage 1: T={Tm}, C={Cm})", "ts_mlp_fwd_kernel", None, 16.0 * Tm * Cm * Cm,
+         lambda: Fn.call("swin_mlp_fwd_bf16", Fn._p(mx), Fn._p(mw1), Fn._p(mb1), Fn._p(mw2), Fn._p(mb2), Fn._p(my), Tm, Cm, Fn._s()), "warm"),
     ]
+    shares = step_shares({i: c[1] for i, c in enumerate(cases)})
     out = []
-    for name, flops, fn in cases:
-        for _ in range(3):
-            fn()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        for s_, e_ in ev:
-            s_.record(); fn(); e_.record()
-        torch.cuda.synchronize()
-        ms = sorted(s_.elapsed_time(e_) for s_, e_ in ev)
-        avg = sum(ms) / len(ms)
+    for i, (name, _pat, pmc_key, flops, fn, cache) in enumerate(cases):
+        avg, med = _time_launches(fn, steps)
         tf = flops / (avg * 1e-3) / 1e12
         out.append({"kernel": name, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg, 5),
-                    "algorithmic_flops_per_launch": flops})
-    shares = step_shares({0: "ts_mlp_fwd_kernel", 1: "ts_mlp_bwd_kernel", 2: "gemm_bf16_kernel<ConvA", 3: "wgrad_kernelI5ConvX",
-                          4: "wgrad_kernelI6PlainX"})
-    for i, o in enumerate(out):
-        o["step_share_profiled"] = shares.get(i)          # all launches of this kernel family in the profiled step
-    out.sort(key=lambda o: -(o["step_share_profiled"] or 0.0))
+                    "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(pmc_key) if pmc_key else None,
+                    "avg_launch_ms": round(avg, 5), "median_launch_ms": round(med, 5), "algorithmic_flops_per_launch": flops, "cache": cache,
+                    "step_share": shares.get(i), "step_share_source": PROFILE_NOTE})
     return out
 
 
@@ -423,8 +454,12 @@ def main():
             raise SystemExit(f"replicas diverged: max parameter-checksum difference {worst}")
         sync_check = "replicas bit-identical after %d steps" % (args.warmup + args.steps)
 
-    roof = attention_roofline(device) if rank == 0 else None
+    # `roofline` = the step's dominant kernel (largest share of the profiled step's kernel time: the 3x3-conv weight gradient);
+    # `roofline_kernels` = the other priced kernels, the WindowAttention core (the north_star's "WindowAttn MFMA util%") first
     roof_gemm = gemm_rooflines(device) if rank == 0 else None
+    roof_attn = attention_roofline(device) if rank == 0 else None
+    roof = roof_gemm[0] if roof_gemm else None
+    roof_others = ([roof_attn] + roof_gemm[1:]) if roof_gemm else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and headline:
         cpu = cpu_baseline()
@@ -443,7 +478,7 @@ def main():
             "config": {"workload": workload_desc,
                        "global_batch": gb, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
             "losses": {k: round(v, 4) for k, v in logs.items()},
-            "roofline": roof, "roofline_mfma_kernels": roof_gemm, "cpu_baseline": cpu, "sync_check": sync_check,
+            "roofline": roof, "roofline_kernels": roof_others, "cpu_baseline": cpu, "sync_check": sync_check,
             # host-side timeline of the last step's gradient exchange, relative to the start of backward (N > 1 only has
             # entries): a bucket issued before backward_issued_ms overlapped the rest of backward
             "comm_timeline": comm if world > 1 else None, "gemm_plans_changed_to_rank0": plans_synced,

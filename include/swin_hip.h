@@ -372,7 +372,8 @@ int swin_gemm_plans_import(const int64_t* in, int n);
  *   pred in the row order of the ConvTranspose2d(k=2,s=2)-as-GEMM output, (roi, h, w, ky, kx, class) -- the logits
  *   before the 2x2 pixel shuffle of fcn_mask_head.py:122-126, so training skips the shuffle and layout copies.
  * Backward entries take grad_out aligned with the forward's out array; dcls/dreg (rpn) and dpred (mask) must be zeroed
- * by the caller, dcls/dbbox (bbox) are fully written. */
+ * by the caller, dcls/dbbox (bbox) are fully written.  det_bbox_loss_fwd's lse holds n + 4 * ceil(n / 16) floats: the rows'
+ * log-sum-exp (kept for the backward) followed by the call's scratch. */
 int det_rpn_loss_fwd(const void* cls, const void* reg, int B, int64_t A, int S, const int64_t* inds, const uint8_t* flags,
                      const float* targets, float beta, float* out3, int dtype, void* stream);
 int det_rpn_loss_bwd(const void* cls, const void* reg, int B, int64_t A, int S, const int64_t* inds, const uint8_t* flags,

@@ -151,23 +151,26 @@ __global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(const T* __restrict__
 // cls (n, nc+1) logits, bbox (n, 4 nc) class-specific or (n, 4) class-agnostic deltas, labels (n) in [0, nc] (nc =
 // background), tgt (n,4) (encoded deltas, or gt boxes in GIoU mode), rois (n,4) (GIoU mode only), flags (n) (bit 0 used,
 // bit 1 positive).  out[0] = CE sum / nv, out[1] = accuracy (%), out[2] = regression sum / nv, out[3] = nv.
+// One WAVE per row, 16 rows per block: the lanes read the row's logits coalesced and reduce max / arg-max / sum with shuffles; a
+// block leaves the sums of its 16 rows in part[block][4] and bbox_loss_final_kernel adds the blocks.  (History: one thread per row in
+// ONE block -- 81 strided scalar loads and expf's in a serial loop -- 84 us; one wave per row in one block, 64 rows per wave each a
+// chain of dependent global loads -- 140 us.  The work is 83 K logits.)
 template <typename T>
-__global__ __launch_bounds__(1024) void bbox_loss_fwd_kernel(const T* __restrict__ cls, const T* __restrict__ bbox, int n, int nc,
-                                                             const int64_t* __restrict__ labels, const float* __restrict__ tgt,
-                                                             const uint8_t* __restrict__ flags, const float* __restrict__ rois,
-                                                             RegCfg rc, float* __restrict__ out, float* __restrict__ lse) {
+__global__ __launch_bounds__(1024) void bbox_loss_rows_kernel(const T* __restrict__ cls, const T* __restrict__ bbox, int n, int nc,
+                                                              const int64_t* __restrict__ labels, const float* __restrict__ tgt,
+                                                              const uint8_t* __restrict__ flags, const float* __restrict__ rois,
+                                                              RegCfg rc, float* __restrict__ part, float* __restrict__ lse) {
     __shared__ float red[16];
     float ce = 0.f, hit = 0.f, l1 = 0.f, cnt = 0.f;
     const int C = nc + 1;
-    // one WAVE per row (the 16 waves walk the rows): the lanes read the row's logits coalesced and reduce max / arg-max / sum with
-    // shuffles.  (One thread per row -- 81 strided scalar loads and expf's in a serial loop -- made this single-block kernel 84 us.)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    for (int i = wv; i < n; i += nwv) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 16 + wv;
+    if (i < n) {
         const T* row = cls + (int64_t)i * C;
         float m = -3.0e38f; int am = 0x7fffffff;
         for (int c = lane; c < C; c += 64) { const float v = Elt<T>::ld(row + c); if (v > m) { m = v; am = c; } }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {                       // max with the LOWEST index among equal maxima (as the serial scan)
+        for (int o = 32; o > 0; o >>= 1) {                       // max with the LOWEST index among equal maxima (as a serial scan)
             const float m2 = __shfl_xor(m, o); const int a2 = __shfl_xor(am, o);
             if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
         }
@@ -175,35 +178,53 @@ __global__ __launch_bounds__(1024) void bbox_loss_fwd_kernel(const T* __restrict
         for (int c = lane; c < C; c += 64) s += expf(Elt<T>::ld(row + c) - m);
         s = wave_sum(s);
         const float l = m + logf(s);
-        if (lane != 0) continue;
-        lse[i] = l;
         const uint8_t f = flags[i];
-        if (!(f & 1)) continue;
-        const int lab = (int)labels[i];
-        ce += l - Elt<T>::ld(row + lab);
-        hit += (am == lab) ? 1.f : 0.f;
-        cnt += 1.f;
-        if ((f & 2) && lab < nc) {
-            const T* p = rc.agnostic ? bbox + (int64_t)i * 4 : bbox + ((int64_t)i * nc + lab) * 4;
-            float dl[4], t4[4];
+        if (lane == 0) {
+            lse[i] = l;
+            if (f & 1) {
+                const int lab = (int)labels[i];
+                ce = l - Elt<T>::ld(row + lab);
+                hit = (am == lab) ? 1.f : 0.f;
+                cnt = 1.f;
+                if ((f & 2) && lab < nc) {
+                    const T* p = rc.agnostic ? bbox + (int64_t)i * 4 : bbox + ((int64_t)i * nc + lab) * 4;
+                    float dl[4], t4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { dl[k] = Elt<T>::ld(p + k); t4[k] = tgt[(int64_t)i * 4 + k]; }
-            if (rc.mode == 2) {
-                float r4[4], o[4];
+                    for (int k = 0; k < 4; ++k) { dl[k] = Elt<T>::ld(p + k); t4[k] = tgt[(int64_t)i * 4 + k]; }
+                    if (rc.mode == 2) {
+                        float r4[4], o[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) r4[k] = rois[(int64_t)i * 4 + k];
-                decode_box(r4, dl, rc, o, nullptr);
-                l1 += giou_loss(o, t4, rc.eps, nullptr);
-            } else {
+                        for (int k = 0; k < 4; ++k) r4[k] = rois[(int64_t)i * 4 + k];
+                        decode_box(r4, dl, rc, o, nullptr);
+                        l1 = giou_loss(o, t4, rc.eps, nullptr);
+                    } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) l1 += reg_elem_loss(dl[k] - t4[k], rc.beta);
+                        for (int k = 0; k < 4; ++k) l1 += reg_elem_loss(dl[k] - t4[k], rc.beta);
+                    }
+                }
             }
         }
     }
     ce = block_sum(ce, red); hit = block_sum(hit, red); l1 = block_sum(l1, red); cnt = block_sum(cnt, red);
     if (threadIdx.x == 0) {
-        const float nv = fmaxf(cnt, 1.f);
-        out[0] = ce / nv; out[1] = hit / nv * 100.f; out[2] = l1 / nv; out[3] = nv;
+        float* o = part + (int64_t)blockIdx.x * 4;
+        o[0] = ce; o[1] = hit; o[2] = l1; o[3] = cnt;
+    }
+}
+
+// out[0] = CE sum / nv, out[1] = accuracy (%), out[2] = regression sum / nv, out[3] = nv from the blocks' partial sums (fixed order:
+// the result does not depend on the launch's scheduling)
+__global__ __launch_bounds__(256) void bbox_loss_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    __shared__ float red[16];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += part[(int64_t)b * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = block_sum(a[k], red);
+    if (threadIdx.x == 0) {
+        const float nv = fmaxf(a[3], 1.f);
+        out[0] = a[0] / nv; out[1] = a[1] / nv * 100.f; out[2] = a[2] / nv; out[3] = nv;
     }
 }
 
@@ -382,7 +403,8 @@ static int reg_cfg(RegCfg& rc, int reg_mode, int class_agnostic, float beta, flo
     return SWIN_OK;
 }
 
-// out4: loss_cls, accuracy (%), loss_bbox, n_valid; lse (n) f32 scratch kept for the backward.
+// out4: loss_cls, accuracy (%), loss_bbox, n_valid; lse: n + 4 * ceil(n / 16) floats -- the first n (the rows' log-sum-exp) are kept
+// for the backward, the rest is this call's scratch (one partial-sum row per thread block).
 extern "C" int det_bbox_loss_fwd(const void* cls, const void* bbox, int n, int num_classes, const int64_t* labels, const float* targets,
                                  const uint8_t* flags, int reg_mode, int class_agnostic, float beta, float eps, const float* rois,
                                  const float* means, const float* stds, float* out4, float* lse, int dtype, void* stream) {
@@ -391,8 +413,11 @@ extern "C" int det_bbox_loss_fwd(const void* cls, const void* bbox, int n, int n
     const int st = reg_cfg(rc, reg_mode, class_agnostic, beta, eps, rois, means, stds);
     if (st != SWIN_OK) return st;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_T(dtype, (bbox_loss_fwd_kernel<float><<<1, 1024, 0, s>>>((const float*)cls, (const float*)bbox, n, num_classes, labels, targets, flags, rois, rc, out4, lse)),
-               (bbox_loss_fwd_kernel<bf16><<<1, 1024, 0, s>>>((const bf16*)cls, (const bf16*)bbox, n, num_classes, labels, targets, flags, rois, rc, out4, lse)))
+    const int nblk = (n + 15) / 16;
+    float* workspace = lse + n;
+    DISPATCH_T(dtype, (bbox_loss_rows_kernel<float><<<nblk, 1024, 0, s>>>((const float*)cls, (const float*)bbox, n, num_classes, labels, targets, flags, rois, rc, workspace, lse)),
+               (bbox_loss_rows_kernel<bf16><<<nblk, 1024, 0, s>>>((const bf16*)cls, (const bf16*)bbox, n, num_classes, labels, targets, flags, rois, rc, workspace, lse)))
+    bbox_loss_final_kernel<<<1, 256, 0, s>>>(workspace, nblk, out4);
     return swin_launch_status();
 }
 

@@ -66,7 +66,7 @@ class _BBoxLoss(torch.autograd.Function):
         if bbox.numel() != n * (4 if agnostic else 4 * num_classes):
             raise SwinHipError(f"bbox_loss: bbox_pred has {bbox.numel()} elements for {n} RoIs (class_agnostic={agnostic})")
         out = torch.empty(4, device=cls.device, dtype=torch.float32)
-        lse = torch.empty(n, device=cls.device, dtype=torch.float32)
+        lse = torch.empty(n + 4 * ((n + 15) // 16), device=cls.device, dtype=torch.float32)      # + the kernel's partial-sum rows
         ctx.reg_args = (mode, 1 if agnostic else 0, beta, eps, _p(rois), _f4(means) if means is not None else None,
                         _f4(stds) if stds is not None else None)
         call("det_bbox_loss_fwd", _p(cls), _p(bbox), n, num_classes, _p(labels), _p(targets), _p(flags), *ctx.reg_args, _p(out),

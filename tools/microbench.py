@@ -132,6 +132,32 @@ def wgradp():
         print(f"conv3x3 fwd {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
 
 
+def rooflinep():
+    """the two kernels bench.py prices against the MFMA roofline, at the P2 geometry and in bench.py's cache regime (launches rotate over
+    three operand sets, 3 x 131 MB > the 256 MB Infinity Cache): the conv weight gradient (wgrad2_kernel<ConvSrc>) and the halo-staged
+    conv (conv_halo_kernel) -- for the counter passes of tools/pmc_run.sh"""
+    N, H, W = 2, 200, 320
+    sets = [(torch.randn(N, H, W, 256, device="cuda").bfloat16(), torch.randn(N, H, W, 256, device="cuda").bfloat16()) for _ in range(3)]
+    dw = torch.zeros(256, 3, 3, 256, device="cuda")
+    db = torch.zeros(256, device="cuda")
+    w = torch.randn(256, 3, 3, 256, device="cuda").bfloat16() * 0.02
+    y = torch.empty(N, H, W, 256, device="cuda", dtype=torch.bfloat16)
+    k = [0]
+
+    def wg():
+        dy, x = sets[k[0] % 3]; k[0] += 1
+        Fn.call("wgrad_conv3x3_nhwc_bf16", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), N, H, W, 256, 256, Fn._s())
+
+    def cv():
+        _, x = sets[k[0] % 3]; k[0] += 1
+        Fn.call("conv3x3_nhwc_bf16", Fn._p(x), Fn._p(w), Fn._p(db), Fn._p(y), N, H, W, 256, 256, 0, Fn._s())
+    fl = 2.0 * N * H * W * 256 * 256 * 9
+    med, _ = timeit(wg, n=9, warm=3)
+    print(f"wgrad_conv {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
+    med, _ = timeit(cv, n=9, warm=3)
+    print(f"conv3x3 {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
+
+
 def overlap():
     """would a second stream for the weight-gradient kernels pay?  A backward-like chain (data-gradient kernel, then the
     weight-gradient kernel of the same layer) run in one stream vs with the weight gradients on a side stream."""

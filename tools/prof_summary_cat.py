@@ -4,7 +4,10 @@
 def cat(n):
     if 'win_attn' in n or 'dbias_slab' in n or 'rel_bias' in n: return 'attention'
     if 'wgrad' in n: return 'wgrad'
-    if 'gemm_bf16' in n: return 'conv/gemm (mine)'
+    if 'conv_halo' in n or 'gemm_bf16_kernel<ConvA' in n or 'gemm_bf16_kernelI5ConvA' in n or 'splitk_finish' in n or 'conv_dgrad_layout' in n:
+        return 'conv3x3 (mine)'
+    if 'gemm_bf16' in n or 'narrow_dgrad' in n or 'linear_t_layout' in n: return 'linear GEMM (mine)'
+    if 'tail_reduce' in n: return 'block tail reduce (mine)'
     if 'Cijk' in n: return 'hipBLASLt'
     if 'ln_' in n or 'layernorm' in n or 'patch_merge' in n: return 'layernorm'
     if 'gelu' in n: return 'bias_gelu'
@@ -20,4 +23,5 @@ def cat(n):
     if 'multi_tensor' in n: return 'optimizer (torch)'
     if 'rocprim' in n or 'sort' in n.lower() or 'topk' in n.lower(): return 'sort/topk (torch)'
     if 'rocclr' in n: return 'memcpy/fill (runtime)'
+    if 'rpn_' in n or 'flat_' in n or 'anchor' in n or 'mask_target' in n or 'zero_segments' in n: return 'losses/targets (mine)'
     return 'elementwise (torch)'
