@@ -223,6 +223,17 @@ int roi_align_multilevel_fwd(const void* const* feats, const int* Hs, const int*
 int roi_align_multilevel_bwd(float* const* grads, const int* Hs, const int* Ws, const float* scales, int n_levels,
                              const void* grad_output, const float* rois, const int* lvl, int C, int K, int ph,
                              int pw, int sampling_ratio, int aligned, int grad_dtype, void* stream);
+/* The same gradient in GATHER form (round 3): every 8 x 8-pixel tile of every level is written once by the blocks that own it --
+ * no float atomics, no zero fill by the caller (grads[l] (N,H_l,W_l,C) in out_dtype are FULLY written), no cast afterwards, and a
+ * summation order independent of scheduling.  n_sets (<= 4) RoI sets pooled from the same pyramid are differentiated together
+ * (the bbox head's 7x7 and the mask head's 14x14 RoIs of one stage): gouts[s] (K[s], ph[s], pw[s], C) channels-last in grad_dtype.
+ * ph, pw <= 16, else SWIN_ERR_UNSUPPORTED.  workspace: roi_align_gather_workspace_bytes(...) bytes, ZEROED ONCE by the caller and
+ * then reusable call after call (the kernels leave its counters zero). */
+int64_t roi_align_gather_workspace_bytes(const int* Hs, const int* Ws, int n_levels, int N, int K_total);
+int roi_align_multilevel_bwd_gather(void* const* grads, const int* Hs, const int* Ws, const float* scales, int n_levels, int N,
+                                    int n_sets, const void* const* gouts, const float* const* rois, const int* const* lvls,
+                                    const int* Ks, const int* phs, const int* pws, int C, int sampling_ratio, int aligned,
+                                    int grad_dtype, int out_dtype, void* workspace, int64_t workspace_bytes, void* stream);
 /* output / grad_output: (K, ph, pw, C) f32, or bf16 when out_dtype / grad_dtype = 1 (bf16 features only). */
 
 /* ------------------------------------------------------------------------------------

@@ -519,3 +519,314 @@ extern "C" int roi_align_multilevel_bwd(float* const* grads, const int* Hs, cons
     else return SWIN_ERR_UNSUPPORTED;
     return swin_launch_status();
 }
+
+// ----------------------------------------------------------------------------- multi-level NHWC backward, GATHER form (round 3)
+// The scatter form above is bound by the chip's float-atomic rate (~400 K footprint pixels x 256 channels x 4 B per RoI set at
+// 1.3 TB/s), needs the whole pyramid's fp32 accumulator zero-filled first (174 MB at 2x800x1280) and cast afterwards.  Here every
+// 8 x 8-pixel tile of every pyramid level is OWNED by thread blocks that walk the list of RoIs touching it and write the tile's
+// gradient ONCE, in the feature dtype: no atomics on the data path, no zero fill, no cast, and a summation order that does not
+// depend on scheduling (the lists are sorted).  single_level_roi_extractor.py:93-97 differentiated; all RoI sets pooled from the
+// same pyramid (the bbox head's 7x7 and the mask head's 14x14 RoIs of an R-CNN stage) in one pass.
+//   1 roi_gather_count   one thread per RoI: ++count[tile] for every tile its (conservative) footprint rectangle overlaps
+//   2 roi_gather_scan    one block: offsets = exclusive scan of the counts; counts and cursors zeroed for the next use
+//   3 roi_gather_fill    one thread per RoI: list[offset[tile] + cursor[tile]++] = (set, roi)
+//   4 roi_gather_main    block = (tile, 64-channel chunk), thread = (channel, pair of tile rows): per listed RoI the separable
+//                        weights Wy[8][ph], Wx[8][pw] of the tile's rows / columns (the forward's sampling grid, summed per pixel),
+//                        then acc[y][x] += Wx[x][j] * sum_i Wy[y][i] * gout[i][j][c]; a hot tile's cost is shared by its four chunks.
+#define RG_TS 8            // tile side in pixels
+#define RG_CH 64           // channels per block
+#define RG_MAXL 1024       // list entries sorted in LDS (longer lists are walked unsorted)
+
+struct RGLevels { int H[4], W[4], ty[4], tx[4], base[4]; float scale[4]; int n_levels, N, total; };
+struct RGSets { const void* gout[4]; const float* rois[4]; const int* lvl[4]; int K[4], ph[4], pw[4], first[4]; int n, Ktot; };
+
+// footprint rectangle of a RoI on its level in tile units; false: it touches nothing
+__device__ __forceinline__ bool rg_rect(const RGLevels& Lv, const float* roi, int l, int ph, int pw, int sr, int aligned, int& n,
+                                        int& ty0, int& ty1, int& tx0, int& tx1) {
+    const float scale = l == 0 ? Lv.scale[0] : (l == 1 ? Lv.scale[1] : (l == 2 ? Lv.scale[2] : Lv.scale[3]));
+    const RoiGeom g = roi_geom(roi, scale, aligned, ph, pw, sr);
+    n = g.batch;
+    if (n < 0 || n >= Lv.N || g.grid_h <= 0 || g.grid_w <= 0) return false;
+    const int H = l == 0 ? Lv.H[0] : (l == 1 ? Lv.H[1] : (l == 2 ? Lv.H[2] : Lv.H[3]));
+    const int W = l == 0 ? Lv.W[0] : (l == 1 ? Lv.W[1] : (l == 2 ? Lv.W[2] : Lv.W[3]));
+    const float y0 = g.start_h, y1 = g.start_h + g.bin_h * (float)ph, x0 = g.start_w, x1 = g.start_w + g.bin_w * (float)pw;
+    if (!(y1 >= -1.0f) || !(y0 <= (float)H) || !(x1 >= -1.0f) || !(x0 <= (float)W)) return false;
+    const int ylo = min(max((int)floorf(y0), 0), H - 1), yhi = min(max((int)floorf(y1) + 1, 0), H - 1);
+    const int xlo = min(max((int)floorf(x0), 0), W - 1), xhi = min(max((int)floorf(x1) + 1, 0), W - 1);
+    ty0 = ylo / RG_TS; ty1 = yhi / RG_TS; tx0 = xlo / RG_TS; tx1 = xhi / RG_TS;
+    return true;
+}
+
+// 64 threads per RoI: thread q takes tiles q, q + 64, ... of the RoI's rectangle, so the atomics of a RoI (up to ~40 tiles) are in
+// flight together instead of one round trip after the other (one thread per RoI: 39 us for the fill pass of 1280 RoIs)
+template <bool FILL>
+__global__ __launch_bounds__(256) void roi_gather_bin(RGLevels Lv, RGSets S, int sr, int aligned, int* __restrict__ count,
+                                                      const int* __restrict__ offs, int* __restrict__ cursor, int* __restrict__ list) {
+    const int id = blockIdx.x * 4 + (threadIdx.x >> 6), q0 = threadIdx.x & 63;
+    if (id >= S.Ktot) return;
+    const int s = (S.n > 1 && id >= S.first[1]) ? ((S.n > 2 && id >= S.first[2]) ? ((S.n > 3 && id >= S.first[3]) ? 3 : 2) : 1) : 0;
+    const int first_s = s == 0 ? 0 : (s == 1 ? S.first[1] : (s == 2 ? S.first[2] : S.first[3]));
+    const int k = id - first_s;
+    // selects instead of S.x[s] with a run-time s: indexing the kernel-argument struct dynamically faulted in roi_gather_main
+    // (hipcc 7.2, gfx950: 'Memory access fault' as soon as a second set existed; tools/rg_stage.py) -- same rule here
+    const int* lvl_s = s == 0 ? S.lvl[0] : (s == 1 ? S.lvl[1] : (s == 2 ? S.lvl[2] : S.lvl[3]));
+    const float* rois_s = s == 0 ? S.rois[0] : (s == 1 ? S.rois[1] : (s == 2 ? S.rois[2] : S.rois[3]));
+    const int ph = s == 0 ? S.ph[0] : (s == 1 ? S.ph[1] : (s == 2 ? S.ph[2] : S.ph[3]));
+    const int pw = s == 0 ? S.pw[0] : (s == 1 ? S.pw[1] : (s == 2 ? S.pw[2] : S.pw[3]));
+    const int l = lvl_s[k];
+    if (l < 0 || l >= Lv.n_levels) return;
+    int n, ty0, ty1, tx0, tx1;
+    if (!rg_rect(Lv, rois_s + 5 * (int64_t)k, l, ph, pw, sr, aligned, n, ty0, ty1, tx0, tx1)) return;
+    const int nx = tx1 - tx0 + 1, nt = (ty1 - ty0 + 1) * nx;
+    const int ltx = l == 0 ? Lv.tx[0] : (l == 1 ? Lv.tx[1] : (l == 2 ? Lv.tx[2] : Lv.tx[3]));
+    const int lty = l == 0 ? Lv.ty[0] : (l == 1 ? Lv.ty[1] : (l == 2 ? Lv.ty[2] : Lv.ty[3]));
+    const int lbase = l == 0 ? Lv.base[0] : (l == 1 ? Lv.base[1] : (l == 2 ? Lv.base[2] : Lv.base[3]));
+    for (int q = q0; q < nt; q += 64) {
+        const int ty = ty0 + q / nx, tx = tx0 + q % nx;
+        const int t = lbase + (n * lty + ty) * ltx + tx;
+        if (FILL) list[offs[t] + atomicAdd(cursor + t, 1)] = (s << 24) | k;
+        else atomicAdd(count + t, 1);
+    }
+}
+
+// offs[0 .. total] = exclusive scan of count; count and cursor are left zero
+__global__ __launch_bounds__(1024) void roi_gather_scan(int* __restrict__ count, int* __restrict__ offs, int* __restrict__ cursor, int total) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (total + 1023) / 1024;
+    const int b = t * per, e = min(b + per, total);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += count[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = b; i < e; ++i) { const int c = count[i]; offs[i] = run; run += c; count[i] = 0; cursor[i] = 0; }
+    if (t == 1023) offs[total] = part[1023];
+}
+
+template <typename TG, typename TO>
+__global__ __launch_bounds__(256) void roi_gather_main(RGLevels Lv, RGSets S, int C, int sr, int aligned, const int* __restrict__ offs,
+                                                       const int* __restrict__ list, TO* o0, TO* o1, TO* o2, TO* o3) {
+    __shared__ int raw[RG_MAXL], ent[RG_MAXL];
+    __shared__ float Wy[2][RG_TS][16], Wx[2][RG_TS][16];    // double-buffered over the list entries: one barrier per entry
+    __shared__ unsigned short imask[2][RG_TS], jmask[2][2]; // bins with a non-zero weight on each tile row / (per wave) on any tile column
+    const int chunks = (C + RG_CH - 1) / RG_CH;
+    const int tile = blockIdx.x / chunks, chunk = blockIdx.x - tile * chunks;
+    int l = 0;
+    while (l + 1 < Lv.n_levels && tile >= Lv.base[l + 1]) ++l;
+    const int H = Lv.H[l], W = Lv.W[l];
+    const float lscale = Lv.scale[l];
+    int r = tile - Lv.base[l];
+    const int tx = r % Lv.tx[l]; r /= Lv.tx[l];
+    const int ty = r % Lv.ty[l];
+    const int n = r / Lv.ty[l];
+    const int y0 = ty * RG_TS, x0 = tx * RG_TS;
+    const int t = threadIdx.x, c = chunk * RG_CH + (t & 63), rg = t >> 6;
+    const int b = offs[tile], cnt = offs[tile + 1] - b;
+    const bool sorted = cnt <= RG_MAXL;
+    if (sorted) {                                             // rank sort in LDS: the same summation order in every run
+        for (int i = t; i < cnt; i += 256) raw[i] = list[b + i];
+        __syncthreads();
+        for (int i = t; i < cnt; i += 256) {
+            const int v = raw[i];
+            int rank = 0;
+            for (int q = 0; q < cnt; ++q) rank += raw[q] < v ? 1 : 0;
+            ent[rank] = v;                                   // (set, roi) pairs are distinct within a tile's list
+        }
+    }
+    float acc[2][RG_TS];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int x = 0; x < RG_TS; ++x) acc[a][x] = 0.f;
+    // The per-entry chain must not contain a global-memory round trip per step (first version: RoI load -> weights -> barrier ->
+    // 9-16 gradient loads each waited for before its FMA: ~7 us per (tile, RoI) pair).  So: the RoIs of up to 256 entries are
+    // brought into LDS together, the weight tables of entry e + 1 are built (from LDS) while entry e is accumulated, and the
+    // gradient values of an entry are fetched as 4 x 4 blocks of independent predicated loads.
+    __shared__ float roi_lds[256][5];
+    __shared__ int meta_lds[256][2];                         // ph | pw << 8 | set << 16,  roi index
+    struct Ent { int ph, pw; const void* gout; int k; float inv; };
+    for (int e0 = 0; e0 < cnt; e0 += 256) {
+        const int nb = min(256, cnt - e0);
+        __syncthreads();                                      // (the previous batch's tables and RoIs are no longer read)
+        if (t < nb) {
+            const int v = sorted ? ent[e0 + t] : list[b + e0 + t];
+            const int s = v >> 24, k = v & 0xffffff;
+            // (selects, not S.x[s]: indexing the kernel-argument struct with a run-time index faulted, see roi_gather_bin)
+            const float* rois_s = s == 0 ? S.rois[0] : (s == 1 ? S.rois[1] : (s == 2 ? S.rois[2] : S.rois[3]));
+            const int ph = s == 0 ? S.ph[0] : (s == 1 ? S.ph[1] : (s == 2 ? S.ph[2] : S.ph[3]));
+            const int pw = s == 0 ? S.pw[0] : (s == 1 ? S.pw[1] : (s == 2 ? S.pw[2] : S.pw[3]));
+            const float* rp = rois_s + 5 * (int64_t)k;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) roi_lds[t][q] = rp[q];
+            meta_lds[t][0] = ph | (pw << 8) | (s << 16);
+            meta_lds[t][1] = k;
+        }
+        __syncthreads();
+        // entry i of the batch: thread (axis, row, bin) sums the bin's samples that land on its pixel; the non-zero pattern comes
+        // from wave ballots (a wave holds 4 rows x 16 bins of one axis)
+        auto prepare = [&](int i, int buf) -> Ent {
+            const int m0 = meta_lds[i][0], k = meta_lds[i][1];
+            const int ph = m0 & 0xff, pw = (m0 >> 8) & 0xff, s = __builtin_amdgcn_readfirstlane(m0 >> 16);
+            const void* gout_s = s == 0 ? S.gout[0] : (s == 1 ? S.gout[1] : (s == 2 ? S.gout[2] : S.gout[3]));
+            float rv[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) rv[q] = roi_lds[i][q];
+            const RoiGeom g = roi_geom(rv, lscale, aligned, ph, pw, sr);
+            const bool isx = t >= RG_TS * 16;
+            const int q = isx ? t - RG_TS * 16 : t;
+            const int row = q >> 4, bin = q & 15;
+            const int np = isx ? pw : ph, grid = isx ? g.grid_w : g.grid_h, size = isx ? W : H, pix = (isx ? x0 : y0) + row;
+            const float start = isx ? g.start_w : g.start_h, bsz = isx ? g.bin_w : g.bin_h;
+            float wsum = 0.f;
+            if (bin < np && pix < size) {
+                for (int s2 = 0; s2 < grid; ++s2) {
+                    int lo, hi; float lw, hw;
+                    if (!axis_sample(start + (float)bin * bsz + ((float)s2 + .5f) * bsz / (float)grid, size, lo, hi, lw, hw)) continue;
+                    if (lo == pix) wsum += hw;
+                    if (hi == pix) wsum += lw;
+                }
+            }
+            if (isx) Wx[buf][row][bin] = wsum; else Wy[buf][row][bin] = wsum;
+            const unsigned long long nz = __ballot(wsum != 0.f);
+            if ((t & 63) == 0) {
+                const int wv = t >> 6;                         // waves 0, 1: y rows 0-3, 4-7; waves 2, 3: x rows 0-3, 4-7
+                if (wv < 2) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) imask[buf][4 * wv + rr] = (unsigned short)((nz >> (16 * rr)) & 0xffffu);
+                } else {
+                    jmask[buf][wv - 2] = (unsigned short)((nz | (nz >> 16) | (nz >> 32) | (nz >> 48)) & 0xffffu);
+                }
+            }
+            return Ent{ph, pw, gout_s, k, 1.0f / g.count};
+        };
+        Ent cur = prepare(0, 0);
+        __syncthreads();
+        for (int i = 0; i < nb; ++i) {
+            const int buf = i & 1;
+            Ent nxt{};
+            if (i + 1 < nb) nxt = prepare(i + 1, buf ^ 1);  // the other buffer: its last readers passed the barrier below
+            const unsigned iu = (unsigned)imask[buf][2 * rg] | (unsigned)imask[buf][2 * rg + 1];
+            const unsigned jm = (unsigned)jmask[buf][0] | (unsigned)jmask[buf][1];
+            if (iu != 0 && jm != 0 && c < C) {
+                const TG* gob = (const TG*)cur.gout + (int64_t)cur.k * cur.ph * cur.pw * C + c;
+                unsigned jr = jm;
+                while (jr) {
+                    const int j = __builtin_ctz(jr); jr &= jr - 1;
+                    float r0 = 0.f, r1 = 0.f;
+                    unsigned im = iu;
+                    while (im) {
+                        const int i2 = __builtin_ctz(im); im &= im - 1;
+                        const float gv = Elt<TG>::ld(gob + ((int64_t)i2 * cur.pw + j) * C);
+                        r0 += Wy[buf][2 * rg][i2] * gv; r1 += Wy[buf][2 * rg + 1][i2] * gv;
+                    }
+                    r0 *= cur.inv; r1 *= cur.inv;
+#pragma unroll
+                    for (int x = 0; x < RG_TS; ++x) { const float wx = Wx[buf][x][j]; acc[0][x] += wx * r0; acc[1][x] += wx * r1; }
+                }
+            }
+            cur = nxt;
+            __syncthreads();
+        }
+    }
+    if (c >= C) return;
+    TO* out = l == 0 ? o0 : (l == 1 ? o1 : (l == 2 ? o2 : o3));
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int y = y0 + 2 * rg + a;
+        if (y >= H) continue;
+#pragma unroll
+        for (int x = 0; x < RG_TS; ++x) {
+            if (x0 + x >= W) continue;
+            Elt<TO>::st(out + (((int64_t)n * H + y) * W + x0 + x) * C + c, acc[a][x]);
+        }
+    }
+}
+
+static int rg_levels(RGLevels& Lv, const int* Hs, const int* Ws, const float* scales, int n_levels, int N) {
+    int total = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int m = l < n_levels ? l : n_levels - 1;
+        Lv.H[l] = Hs[m]; Lv.W[l] = Ws[m]; Lv.scale[l] = scales[m];
+        if (Lv.H[l] <= 0 || Lv.W[l] <= 0) return -1;
+        Lv.ty[l] = (Lv.H[l] + RG_TS - 1) / RG_TS; Lv.tx[l] = (Lv.W[l] + RG_TS - 1) / RG_TS;
+        Lv.base[l] = total;
+        if (l < n_levels) total += N * Lv.ty[l] * Lv.tx[l];
+    }
+    Lv.n_levels = n_levels; Lv.N = N; Lv.total = total;
+    return total;
+}
+
+// bytes of the persistent workspace of roi_align_multilevel_bwd_gather: [count | cursor | offsets (+1) | list].  The list is sized
+// for the worst case (every RoI covering its level's whole map), so it cannot overflow.  Zero the workspace once; every call
+// leaves the counts zero again.
+extern "C" int64_t roi_align_gather_workspace_bytes(const int* Hs, const int* Ws, int n_levels, int N, int K_total) {
+    if (!Hs || !Ws || n_levels <= 0 || n_levels > 4 || N <= 0 || K_total < 0) return 0;
+    RGLevels Lv;
+    const float one[4] = {1.f, 1.f, 1.f, 1.f};
+    const int total = rg_levels(Lv, Hs, Ws, one, n_levels, N);
+    if (total <= 0) return 0;
+    int per_roi = 0;
+    for (int l = 0; l < n_levels; ++l) per_roi = per_roi > Lv.ty[l] * Lv.tx[l] ? per_roi : Lv.ty[l] * Lv.tx[l];
+    return ((int64_t)3 * total + 16 + (int64_t)K_total * per_roi) * (int64_t)sizeof(int);
+}
+
+// grads[l]: (N, H[l], W[l], C) in out_dtype (SWIN_BF16 or SWIN_F32), FULLY WRITTEN (zeros where no RoI reaches) -- no zero fill by
+// the caller, no cast afterwards.  n_sets RoI sets pooled from the same pyramid: gouts[s] (K[s], ph[s], pw[s], C) channels-last in
+// grad_dtype, rois[s] (K[s], 5), lvls[s] (K[s]) (< 0: skipped).  ph, pw <= 16; K[s] < 2^24.
+extern "C" int roi_align_multilevel_bwd_gather(void* const* grads, const int* Hs, const int* Ws, const float* scales, int n_levels, int N,
+                                               int n_sets, const void* const* gouts, const float* const* rois, const int* const* lvls,
+                                               const int* Ks, const int* phs, const int* pws, int C, int sampling_ratio, int aligned,
+                                               int grad_dtype, int out_dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!grads || !Hs || !Ws || !scales || n_levels <= 0 || n_levels > 4 || N <= 0 || n_sets <= 0 || n_sets > 4 || !gouts || !rois || !lvls ||
+        !Ks || !phs || !pws || C <= 0 || !workspace)
+        return SWIN_ERR_BAD_ARG;
+    RGLevels Lv;
+    const int total = rg_levels(Lv, Hs, Ws, scales, n_levels, N);
+    if (total <= 0) return SWIN_ERR_BAD_ARG;
+    RGSets S;
+    int ktot = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int m = s < n_sets ? s : n_sets - 1;
+        S.gout[s] = gouts[m]; S.rois[s] = rois[m]; S.lvl[s] = lvls[m]; S.K[s] = s < n_sets ? Ks[m] : 0; S.ph[s] = phs[m]; S.pw[s] = pws[m];
+        S.first[s] = ktot;
+        if (s < n_sets) {
+            if (Ks[m] < 0 || Ks[m] >= (1 << 24) || phs[m] <= 0 || pws[m] <= 0) return SWIN_ERR_BAD_ARG;
+            if (phs[m] > 16 || pws[m] > 16) return SWIN_ERR_UNSUPPORTED;
+            if (Ks[m] > 0 && (!gouts[m] || !rois[m] || !lvls[m])) return SWIN_ERR_BAD_ARG;
+            ktot += Ks[m];
+        }
+    }
+    S.n = n_sets; S.Ktot = ktot;
+    if (workspace_bytes < roi_align_gather_workspace_bytes(Hs, Ws, n_levels, N, ktot)) return SWIN_ERR_BAD_ARG;
+    for (int l = 0; l < n_levels; ++l) if (!grads[l]) return SWIN_ERR_BAD_ARG;
+    int* count = (int*)workspace;
+    int* cursor = count + total;
+    int* offs = cursor + total;
+    int* list = offs + total + 16;
+    hipStream_t st = (hipStream_t)stream;
+    const int stage = swin_dev_int("SWIN_RG_STAGE", 4);            // development builds: stop after stage n (fault localisation)
+    if (ktot > 0) roi_gather_bin<false><<<(ktot + 3) / 4, 256, 0, st>>>(Lv, S, sampling_ratio, aligned, count, offs, cursor, list);
+    if (stage < 2) return swin_launch_status();
+    roi_gather_scan<<<1, 1024, 0, st>>>(count, offs, cursor, total);
+    if (stage < 3) return swin_launch_status();
+    if (ktot > 0) roi_gather_bin<true><<<(ktot + 3) / 4, 256, 0, st>>>(Lv, S, sampling_ratio, aligned, count, offs, cursor, list);
+    if (stage < 4) return swin_launch_status();
+    const int chunks = (C + RG_CH - 1) / RG_CH;
+    void* o[4];
+    for (int l = 0; l < 4; ++l) o[l] = grads[l < n_levels ? l : n_levels - 1];
+#define RG_LAUNCH(TG, TO) roi_gather_main<TG, TO><<<total * chunks, 256, 0, st>>>(Lv, S, C, sampling_ratio, aligned, offs, list, (TO*)o[0], (TO*)o[1], (TO*)o[2], (TO*)o[3])
+    if (grad_dtype == SWIN_BF16 && out_dtype == SWIN_BF16) RG_LAUNCH(bf16, bf16);
+    else if (grad_dtype == SWIN_F32 && out_dtype == SWIN_F32) RG_LAUNCH(float, float);
+    else if (grad_dtype == SWIN_BF16 && out_dtype == SWIN_F32) RG_LAUNCH(bf16, float);
+    else if (grad_dtype == SWIN_F32 && out_dtype == SWIN_BF16) RG_LAUNCH(float, bf16);
+    else return SWIN_ERR_UNSUPPORTED;
+#undef RG_LAUNCH
+    return swin_launch_status();
+}

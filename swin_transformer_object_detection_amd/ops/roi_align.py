@@ -12,6 +12,7 @@ import torch
 from .._lib import half_dtype as _H
 import torch.nn as nn
 
+from .. import _lib
 from .._lib import SWIN_BF16, SWIN_F32, SwinHipError, call
 from .functional import _p, _s
 
@@ -132,7 +133,12 @@ class _RoIAlignMultiLevelFn(torch.autograd.Function):
         import ctypes
         rois, lvls = ctx.saved_tensors
         n, C, K, ph, pw, strides, sr, aligned, shapes, in_dtype = ctx.cfg
-        # one flat fp32 accumulator for the whole pyramid: one memset, one cast back to the feature dtype
+        if K > 0:
+            g = gout if gout.dtype in (torch.float32, _H()) else gout.float()
+            grads = _gather_backward(shapes, strides, [(g, rois, lvls, ph, pw)], C, sr, aligned, in_dtype)
+            if grads is not None:
+                return (None, None, None, None, None, None, None) + grads
+        # scatter form: one flat fp32 accumulator for the whole pyramid: one memset, one cast back to the feature dtype
         sizes = [s[0] * s[1] * s[2] * s[3] for s in shapes]
         flat = torch.zeros(sum(sizes), device=gout.device, dtype=torch.float32)
         offs = [sum(sizes[:i]) for i in range(n)]
@@ -152,6 +158,51 @@ class _RoIAlignMultiLevelFn(torch.autograd.Function):
 
 
 _ACC_ON_SIDE = os.environ.get("SWIN_ROI_ACC_SIDE", "1") != "0"      # 0: zero the backward accumulator in backward, on the main stream (A/B)
+_GATHER = os.environ.get("SWIN_ROI_GATHER", "1") != "0"             # 0: the scatter (float-atomic) backward of rounds 1-2 (A/B)
+_GATHER_WS = {}       # (device index, bytes) -> persistent int32 workspace, zeroed once (the kernels leave its counters zero)
+
+
+def _gather_backward(shapes, strides, sets, C, sr, aligned, in_dtype):
+    """Gradient of the pyramid for RoI sets [(gout, rois, lvls, ph, pw), ...] in gather form (roi_align_multilevel_bwd_gather): a
+    tuple of (N, C, H_l, W_l) channels-last gradients in ``in_dtype``, or None when the shapes do not fit that form."""
+    import ctypes
+    n = len(shapes)
+    sets = [t for t in sets if t[0] is not None and t[1].shape[0] > 0]
+    if not _GATHER or not sets or len(sets) > 4 or any(ph > 16 or pw > 16 for _, _, _, ph, pw in sets):
+        return None
+    dev = sets[0][0].device
+    N = shapes[0][0]
+    gdt = sets[0][0].dtype
+    if gdt not in (torch.float32, _H()) or any(t[0].dtype != gdt for t in sets) or in_dtype not in (torch.float32, _H()):
+        return None
+    Hs = (ctypes.c_int * n)(*[s[2] for s in shapes])
+    Ws = (ctypes.c_int * n)(*[s[3] for s in shapes])
+    sc = (ctypes.c_float * n)(*[1.0 / s for s in strides])
+    ktot = sum(t[1].shape[0] for t in sets)
+    nb = int(_lib.lib().roi_align_gather_workspace_bytes(Hs, Ws, n, N, ktot))
+    if nb <= 0:
+        return None
+    key = (dev.index, nb)
+    ws = _GATHER_WS.get(key)
+    if ws is None:
+        ws = _GATHER_WS[key] = torch.zeros((nb + 3) // 4, device=dev, dtype=torch.int32)
+    sizes = [s[0] * s[1] * s[2] * s[3] for s in shapes]
+    flat = torch.empty(sum(sizes), device=dev, dtype=in_dtype)          # fully written by the kernel: no fill, no cast
+    offs = [sum(sizes[:i]) for i in range(n)]
+    esz = flat.element_size()
+    ptrs = (ctypes.c_void_p * n)(*[flat.data_ptr() + esz * o for o in offs])
+    m = len(sets)
+    gouts = [t[0].contiguous(memory_format=torch.channels_last) for t in sets]
+    gp = (ctypes.c_void_p * m)(*[g.data_ptr() for g in gouts])
+    rp = (ctypes.c_void_p * m)(*[t[1].data_ptr() for t in sets])
+    lp = (ctypes.c_void_p * m)(*[t[2].data_ptr() for t in sets])
+    Ks = (ctypes.c_int * m)(*[t[1].shape[0] for t in sets])
+    phs = (ctypes.c_int * m)(*[t[3] for t in sets])
+    pws = (ctypes.c_int * m)(*[t[4] for t in sets])
+    code = lambda d: SWIN_F32 if d == torch.float32 else SWIN_BF16      # noqa: E731
+    call("roi_align_multilevel_bwd_gather", ptrs, Hs, Ws, sc, n, N, m, gp, rp, lp, Ks, phs, pws, C, sr, aligned, code(gdt), code(in_dtype),
+         _p(ws), nb, _s())
+    return tuple(flat[o:o + q].view(s[0], s[2], s[3], s[1]).permute(0, 3, 1, 2) for o, q, s in zip(offs, sizes, shapes))
 
 
 class _RoIAlignMultiLevelGroupFn(torch.autograd.Function):
@@ -194,7 +245,8 @@ class _RoIAlignMultiLevelGroupFn(torch.autograd.Function):
         # The backward's fp32 accumulator (174 MB at 2x800x1280) needs 35-85 us of zero fill at the head of the data-gradient chain.
         # With a second stream it is allocated and zeroed THERE, now, while this stream runs the heads; backward waits for the event.
         ctx.acc = None
-        if _ACC_ON_SIDE and any(f.requires_grad for f in tensors[:n]):
+        gather_ok = _GATHER and all(ph <= 16 and pw <= 16 for ph, pw in specs) and len(specs) <= 4
+        if _ACC_ON_SIDE and not gather_ok and any(f.requires_grad for f in tensors[:n]):
             from .. import mixed
             with mixed.on_side(f0.device) as sd:
                 if sd is not None:
@@ -211,6 +263,15 @@ class _RoIAlignMultiLevelGroupFn(torch.autograd.Function):
         n, C, specs, strides, sr, aligned, shapes, in_dtype = ctx.cfg
         sizes = [s[0] * s[1] * s[2] * s[3] for s in shapes]
         dev = saved[0].device
+        sets = []
+        for gi, ((ph, pw), gout) in enumerate(zip(specs, gouts)):
+            if gout is not None and gout.dtype not in (torch.float32, _H()):
+                gout = gout.float()
+            sets.append((gout, saved[2 * gi], saved[2 * gi + 1], ph, pw))
+        grads = _gather_backward(shapes, strides, sets, C, sr, aligned, in_dtype)
+        if grads is not None:
+            ctx.acc = None
+            return (None, None, None, None, None, None) + grads + (None,) * (2 * len(specs))
         if getattr(ctx, 'acc', None) is not None and ctx.acc[0].numel() == sum(sizes):
             flat, ev = ctx.acc
             ctx.acc = None

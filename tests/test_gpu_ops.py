@@ -1157,3 +1157,72 @@ def test_conv3x3_halo_rejects_unsupported_shapes(ops):
     y2 = torch.zeros(1, 8, 8, 128, device="cuda", dtype=torch.bfloat16)
     rc = _lib.lib().conv3x3_halo_nhwc_bf16(Fn._p(x2), Fn._p(w2), None, None, Fn._p(y2), 1, 8, 8, 64, 128, 0, 4, Fn._s())  # nt = 4 needs Cout % 256 == 0
     assert rc == 2                      # SWIN_ERR_UNSUPPORTED (include/swin_hip.h)
+
+
+@pytest.mark.parametrize("gdt,odt", [(torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+def test_roi_align_gather_backward_equals_scatter_backward(ops, gdt, odt):
+    """roi_align_multilevel_bwd_gather (tiles own their gradient: no atomics, no zero fill, no cast) against the float-atomic
+    scatter form on the same inputs: two RoI sets (7x7 and 14x14) over a 4-level pyramid with map sizes that are not tile multiples,
+    100 RoIs stacked on one spot (single_level_roi_extractor.py:93-97 with many proposals on one object), RoIs partly and wholly
+    outside the image, skipped slots (lvl < 0), degenerate (negative-width) boxes.  Run twice: the workspace is reusable, and the
+    result is bit-identical (sorted lists)."""
+    import ctypes
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    N, C = 2, 256
+    shapes = [(50, 80), (25, 40), (13, 20), (7, 10)]
+    strides = [4, 8, 16, 32]
+    g = torch.Generator().manual_seed(5)
+
+    def make(K, out):
+        r = torch.rand(K, 5, generator=g)
+        r[:, 0] = (torch.arange(K) % N).float()
+        wh = torch.exp(torch.rand(K, 2, generator=g) * 5.0 + 1.5)                    # 4.5 .. 665 px: every level gets RoIs
+        r[:, 1:3] = r[:, 1:3] * torch.tensor([320., 200.]) - 20.0                   # some start outside
+        r[:, 3:] = r[:, 1:3] + wh
+        r[:100, 1:] = torch.tensor([100., 60., 140., 95.]) + torch.rand(100, 4, generator=g) * 2.0   # stacked on one object
+        r[100, 1:] = torch.tensor([-500., -500., -400., -400.])                      # wholly outside
+        r[101, 1:] = torch.tensor([50., 50., 40., 45.])                              # negative width / height
+        scale = torch.sqrt((r[:, 3] - r[:, 1]).clamp(min=1) * (r[:, 4] - r[:, 2]).clamp(min=1))
+        lv = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(0, 3).int()
+        lv[102:110] = -1
+        go = torch.randn(K, out, out, C, generator=g)
+        return r.cuda(), lv.cuda(), go.cuda().to(gdt)
+    sets = [make(300, 7) + (7,), make(150, 14) + (14,)]
+    n = len(shapes)
+    Hs = (ctypes.c_int * n)(*[s[0] for s in shapes]); Ws = (ctypes.c_int * n)(*[s[1] for s in shapes])
+    sc = (ctypes.c_float * n)(*[1.0 / s for s in strides])
+    # scatter form: fp32 accumulators, zeroed, then cast
+    acc = [torch.zeros(N, h, w, C, device="cuda") for h, w in shapes]
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in acc])
+    for r, lv, go, out in sets:
+        Fn.call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, n, Fn._p(go), Fn._p(r), Fn._p(lv), C, r.shape[0], out, out, 0, 1,
+                Fn.SWIN_F32 if gdt == torch.float32 else Fn.SWIN_BF16, Fn._s())
+    ref = [a.to(odt) for a in acc]
+    # gather form
+    ktot = sum(s[0].shape[0] for s in sets)
+    nb = int(_lib.lib().roi_align_gather_workspace_bytes(Hs, Ws, n, N, ktot))
+    assert nb > 0
+    ws = torch.zeros(nb // 4 + 1, device="cuda", dtype=torch.int32)
+    m = len(sets)
+    code = lambda d: Fn.SWIN_F32 if d == torch.float32 else Fn.SWIN_BF16      # noqa: E731
+    runs = []
+    for _ in range(2):
+        outs = [torch.full((N, h, w, C), float("nan"), device="cuda", dtype=odt) for h, w in shapes]
+        op = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
+        gp = (ctypes.c_void_p * m)(*[s[2].data_ptr() for s in sets])
+        rp = (ctypes.c_void_p * m)(*[s[0].data_ptr() for s in sets])
+        lp = (ctypes.c_void_p * m)(*[s[1].data_ptr() for s in sets])
+        Ks = (ctypes.c_int * m)(*[s[0].shape[0] for s in sets])
+        ps = (ctypes.c_int * m)(*[s[3] for s in sets])
+        Fn.call("roi_align_multilevel_bwd_gather", op, Hs, Ws, sc, n, N, m, gp, rp, lp, Ks, ps, ps, C, 0, 1, code(gdt), code(odt),
+                Fn._p(ws), nb, Fn._s())
+        torch.cuda.synchronize()
+        runs.append(outs)
+    for l, (a, b) in enumerate(zip(runs[0], ref)):
+        assert bool(torch.isfinite(a.float()).all()), l
+        assert float(b.float().abs().max()) > 0
+        tol = bf16_tol(b, 1.5) if odt == torch.bfloat16 else 2e-4 * float(b.abs().max())
+        close(a, b, tol, msg=f"level {l}")
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)

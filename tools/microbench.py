@@ -334,6 +334,66 @@ def gelu():
               f"bwd {medb:7.1f} us ({6.0 * h.numel() / medb / 1e3:7.1f} GB/s)")
 
 
+def roig():
+    """RoIAlign backward of one R-CNN stage at the bench geometry: scatter form (2 launches + zero fill + cast) against the gather form"""
+    import ctypes
+    from swin_transformer_object_detection_amd import _lib
+    torch.manual_seed(0)
+    N, C = 2, 256
+    shapes = [(200, 320), (100, 160), (50, 80), (25, 40)]
+    n = 4
+    sets = []
+    for K, out in ((1024, 7), (256, 14)):
+        rois = torch.rand(K, 5, device="cuda")
+        rois[:, 0] = (torch.arange(K, device="cuda") >= K // 2).float()
+        wh = torch.exp(torch.rand(K, 2, device="cuda") * 4.0 + 2.5)          # 12 .. 660 px
+        rois[:, 1:3] = rois[:, 1:3] * torch.tensor([1280., 800.], device="cuda") * 0.8
+        rois[:, 3:] = torch.minimum(rois[:, 1:3] + wh, torch.tensor([1279., 799.], device="cuda"))
+        if len(sys.argv) > 2 and sys.argv[2] == "hot":                       # 16 objects, every RoI a jitter of one of them
+            obj = rois[torch.randint(0, 16, (K,), device="cuda")]
+            rois[:, 1:] = obj[:, 1:] + torch.randn(K, 4, device="cuda") * 6.0
+            rois[:, 3:] = torch.maximum(rois[:, 3:], rois[:, 1:3] + 8.0)
+        scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+        lv = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(0, 3).int()
+        g = torch.randn(K, out, out, C, device="cuda").bfloat16()
+        sets.append((rois, lv, g, out))
+    Hs = (ctypes.c_int * n)(*[s[0] for s in shapes]); Ws = (ctypes.c_int * n)(*[s[1] for s in shapes])
+    sc = (ctypes.c_float * n)(0.25, 0.125, 0.0625, 0.03125)
+    sizes = [N * h * w * C for h, w in shapes]
+
+    def scatter():
+        flat = torch.zeros(sum(sizes), device="cuda")
+        offs = [sum(sizes[:i]) for i in range(n)]
+        ptrs = (ctypes.c_void_p * n)(*[flat.data_ptr() + 4 * o for o in offs])
+        for r, lv, g, out in sets:
+            Fn.call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, n, Fn._p(g), Fn._p(r), Fn._p(lv), C, r.shape[0], out, out, 0, 1, 1, Fn._s())
+        return flat.bfloat16()
+    ktot = sum(s[0].shape[0] for s in sets)
+    nb = int(_lib.lib().roi_align_gather_workspace_bytes(Hs, Ws, n, N, ktot))
+    ws = torch.zeros(nb // 4 + 1, device="cuda", dtype=torch.int32)
+    m = len(sets)
+    gp = (ctypes.c_void_p * m)(*[s[2].data_ptr() for s in sets]); rp = (ctypes.c_void_p * m)(*[s[0].data_ptr() for s in sets])
+    lp = (ctypes.c_void_p * m)(*[s[1].data_ptr() for s in sets])
+    Ks = (ctypes.c_int * m)(*[s[0].shape[0] for s in sets]); ps = (ctypes.c_int * m)(*[s[3] for s in sets])
+
+    def gather():
+        flat = torch.empty(sum(sizes), device="cuda", dtype=torch.bfloat16)
+        offs = [sum(sizes[:i]) for i in range(n)]
+        ptrs = (ctypes.c_void_p * n)(*[flat.data_ptr() + 2 * o for o in offs])
+        Fn.call("roi_align_multilevel_bwd_gather", ptrs, Hs, Ws, sc, n, N, m, gp, rp, lp, Ks, ps, ps, C, 0, 1, 1, 1, Fn._p(ws), nb, Fn._s())
+        return flat
+    a, b = scatter(), gather()
+    torch.cuda.synchronize()
+    total = 2 * sum(((h + 7) // 8) * ((w + 7) // 8) for h, w in shapes)
+    w_ = ws.cpu()
+    per = (w_[2 * total + 1:3 * total + 1] - w_[2 * total:3 * total])
+    err = float((a.float() - b.float()).abs().max() / a.float().abs().max())
+    ms, _ = timeit(scatter, n=10)
+    mg, _ = timeit(gather, n=10)
+    print(f"roi backward, 1024 x 7x7 + 256 x 14x14 RoIs: scatter {ms:7.1f} us   gather {mg:7.1f} us   max rel diff {err:.1e}   "
+          f"(tile, RoI) pairs {int(w_[3 * total])}, max per tile {int(per.max())}, tiles {total}, empty {int((per == 0).sum())}")
+
+
 def roiml():
     import ctypes
     torch.manual_seed(0)
