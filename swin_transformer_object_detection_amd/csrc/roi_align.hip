@@ -530,12 +530,20 @@ extern "C" int roi_align_multilevel_bwd(float* const* grads, const int* Hs, cons
 //   1 roi_gather_count   one thread per RoI: ++count[tile] for every tile its (conservative) footprint rectangle overlaps
 //   2 roi_gather_scan    one block: offsets = exclusive scan of the counts; counts and cursors zeroed for the next use
 //   3 roi_gather_fill    one thread per RoI: list[offset[tile] + cursor[tile]++] = (set, roi)
-//   4 roi_gather_main    block = (tile, 64-channel chunk), thread = (channel, pair of tile rows): per listed RoI the separable
+//   4 roi_gather_main    block = (tile, 256-channel chunk), thread = (4 consecutive channels, pair of tile rows): per listed RoI the separable
 //                        weights Wy[8][ph], Wx[8][pw] of the tile's rows / columns (the forward's sampling grid, summed per pixel),
-//                        then acc[y][x] += Wx[x][j] * sum_i Wy[y][i] * gout[i][j][c]; a hot tile's cost is shared by its four chunks.
+//                        then acc[y][x] += Wx[x][j] * sum_i Wy[y][i] * gout[i][j][c].
 #define RG_TS 8            // tile side in pixels
-#define RG_CH 64           // channels per block
+#define RG_CH 256          // channels per block: a thread owns FOUR consecutive channels (8- / 16-byte loads and stores)
 #define RG_MAXL 1024       // list entries sorted in LDS (longer lists are walked unsorted)
+
+__device__ __forceinline__ f32x4 rg_load4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 rg_load4(const bf16* p) {
+    const bf16x4 v = *(const bf16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void rg_store4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void rg_store4(bf16* p, f32x4 v) { *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
 
 struct RGLevels { int H[4], W[4], ty[4], tx[4], base[4]; float scale[4]; int n_levels, N, total; };
 struct RGSets { const void* gout[4]; const float* rois[4]; const int* lvl[4]; int K[4], ph[4], pw[4], first[4]; int n, Ktot; };
@@ -610,14 +618,24 @@ __global__ __launch_bounds__(1024) void roi_gather_scan(int* __restrict__ count,
     if (t == 1023) offs[total] = part[1023];
 }
 
+// block = (tile, pair of tile rows, 256-channel chunk); its four WAVES take different entries of the tile's list (entry i goes to
+// wave i % 4), each with wave-private weight tables and no block barrier inside the list walk, and fold their accumulators through
+// LDS at the end.  A thread owns 4 consecutive channels of both rows and all 8 columns (64 accumulators).  (First version: the four
+// waves were the four row pairs and walked the whole list together behind one barrier per entry -- 182 us on spread-out RoIs but
+// 573 us inside the training step, where the sampled RoIs pile up on the ground-truth boxes: the longest list sets the time.)
 template <typename TG, typename TO>
 __global__ __launch_bounds__(256) void roi_gather_main(RGLevels Lv, RGSets S, int C, int sr, int aligned, const int* __restrict__ offs,
                                                        const int* __restrict__ list, TO* o0, TO* o1, TO* o2, TO* o3) {
-    __shared__ int raw[RG_MAXL], ent[RG_MAXL];
-    __shared__ float Wy[2][RG_TS][16], Wx[2][RG_TS][16];    // double-buffered over the list entries: one barrier per entry
-    __shared__ unsigned short imask[2][RG_TS], jmask[2][2]; // bins with a non-zero weight on each tile row / (per wave) on any tile column
+    __shared__ __attribute__((aligned(16))) char pool[16384];       // list walk: raw | ent | RoIs | meta;  afterwards: the fold buffer
+    __shared__ float wtab[4][160];                                  // per wave: Wy[2][16] | Wx[8][16] of its current entry
+    int* raw = (int*)pool;                                          // [RG_MAXL]
+    int* ent = raw + RG_MAXL;                                       // [RG_MAXL]
+    float (*roi_lds)[5] = (float (*)[5])(pool + 8192);              // [256][5]
+    int (*meta_lds)[2] = (int (*)[2])(pool + 8192 + 5120);          // [256][2]
     const int chunks = (C + RG_CH - 1) / RG_CH;
-    const int tile = blockIdx.x / chunks, chunk = blockIdx.x - tile * chunks;
+    int bid = blockIdx.x;
+    const int chunk = bid % chunks; bid /= chunks;
+    const int rp = bid & 3, tile = bid >> 2;
     int l = 0;
     while (l + 1 < Lv.n_levels && tile >= Lv.base[l + 1]) ++l;
     const int H = Lv.H[l], W = Lv.W[l];
@@ -626,52 +644,45 @@ __global__ __launch_bounds__(256) void roi_gather_main(RGLevels Lv, RGSets S, in
     const int tx = r % Lv.tx[l]; r /= Lv.tx[l];
     const int ty = r % Lv.ty[l];
     const int n = r / Lv.ty[l];
-    const int y0 = ty * RG_TS, x0 = tx * RG_TS;
-    const int t = threadIdx.x, c = chunk * RG_CH + (t & 63), rg = t >> 6;
+    const int y0 = ty * RG_TS + 2 * rp, x0 = tx * RG_TS;            // this block's two rows
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, c = chunk * RG_CH + 4 * lane;      // C % 4 == 0 (host-checked)
+    if (y0 >= H) return;                                            // (block-uniform: the tile's lower rows are outside the map)
     const int b = offs[tile], cnt = offs[tile + 1] - b;
     const bool sorted = cnt <= RG_MAXL;
-    if (sorted) {                                             // rank sort in LDS: the same summation order in every run
+    if (sorted) {                                                   // rank sort in LDS: the same summation order in every run
         for (int i = t; i < cnt; i += 256) raw[i] = list[b + i];
         __syncthreads();
         for (int i = t; i < cnt; i += 256) {
             const int v = raw[i];
             int rank = 0;
             for (int q = 0; q < cnt; ++q) rank += raw[q] < v ? 1 : 0;
-            ent[rank] = v;                                   // (set, roi) pairs are distinct within a tile's list
+            ent[rank] = v;                                         // (set, roi) pairs are distinct within a tile's list
         }
     }
-    float acc[2][RG_TS];
+    f32x4 acc[2][RG_TS];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int x = 0; x < RG_TS; ++x) acc[a][x] = 0.f;
-    // The per-entry chain must not contain a global-memory round trip per step (first version: RoI load -> weights -> barrier ->
-    // 9-16 gradient loads each waited for before its FMA: ~7 us per (tile, RoI) pair).  So: the RoIs of up to 256 entries are
-    // brought into LDS together, the weight tables of entry e + 1 are built (from LDS) while entry e is accumulated, and the
-    // gradient values of an entry are fetched as 4 x 4 blocks of independent predicated loads.
-    __shared__ float roi_lds[256][5];
-    __shared__ int meta_lds[256][2];                         // ph | pw << 8 | set << 16,  roi index
-    struct Ent { int ph, pw; const void* gout; int k; float inv; };
+        for (int x = 0; x < RG_TS; ++x) acc[a][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    volatile float* wt = wtab[wv];
     for (int e0 = 0; e0 < cnt; e0 += 256) {
         const int nb = min(256, cnt - e0);
-        __syncthreads();                                      // (the previous batch's tables and RoIs are no longer read)
-        if (t < nb) {
+        __syncthreads();                                            // (ent is complete; the previous batch's RoIs are no longer read)
+        if (t < nb) {                                               // the batch's RoIs into LDS together: one memory round trip
             const int v = sorted ? ent[e0 + t] : list[b + e0 + t];
             const int s = v >> 24, k = v & 0xffffff;
             // (selects, not S.x[s]: indexing the kernel-argument struct with a run-time index faulted, see roi_gather_bin)
             const float* rois_s = s == 0 ? S.rois[0] : (s == 1 ? S.rois[1] : (s == 2 ? S.rois[2] : S.rois[3]));
             const int ph = s == 0 ? S.ph[0] : (s == 1 ? S.ph[1] : (s == 2 ? S.ph[2] : S.ph[3]));
             const int pw = s == 0 ? S.pw[0] : (s == 1 ? S.pw[1] : (s == 2 ? S.pw[2] : S.pw[3]));
-            const float* rp = rois_s + 5 * (int64_t)k;
+            const float* rpn = rois_s + 5 * (int64_t)k;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) roi_lds[t][q] = rp[q];
+            for (int q = 0; q < 5; ++q) roi_lds[t][q] = rpn[q];
             meta_lds[t][0] = ph | (pw << 8) | (s << 16);
             meta_lds[t][1] = k;
         }
         __syncthreads();
-        // entry i of the batch: thread (axis, row, bin) sums the bin's samples that land on its pixel; the non-zero pattern comes
-        // from wave ballots (a wave holds 4 rows x 16 bins of one axis)
-        auto prepare = [&](int i, int buf) -> Ent {
+        for (int i = wv; i < nb; i += 4) {                          // this wave's entries; no block barrier in here
             const int m0 = meta_lds[i][0], k = meta_lds[i][1];
             const int ph = m0 & 0xff, pw = (m0 >> 8) & 0xff, s = __builtin_amdgcn_readfirstlane(m0 >> 16);
             const void* gout_s = s == 0 ? S.gout[0] : (s == 1 ? S.gout[1] : (s == 2 ? S.gout[2] : S.gout[3]));
@@ -679,72 +690,84 @@ __global__ __launch_bounds__(256) void roi_gather_main(RGLevels Lv, RGSets S, in
 #pragma unroll
             for (int q = 0; q < 5; ++q) rv[q] = roi_lds[i][q];
             const RoiGeom g = roi_geom(rv, lscale, aligned, ph, pw, sr);
-            const bool isx = t >= RG_TS * 16;
-            const int q = isx ? t - RG_TS * 16 : t;
-            const int row = q >> 4, bin = q & 15;
-            const int np = isx ? pw : ph, grid = isx ? g.grid_w : g.grid_h, size = isx ? W : H, pix = (isx ? x0 : y0) + row;
-            const float start = isx ? g.start_w : g.start_h, bsz = isx ? g.bin_w : g.bin_h;
-            float wsum = 0.f;
-            if (bin < np && pix < size) {
-                for (int s2 = 0; s2 < grid; ++s2) {
-                    int lo, hi; float lw, hw;
-                    if (!axis_sample(start + (float)bin * bsz + ((float)s2 + .5f) * bsz / (float)grid, size, lo, hi, lw, hw)) continue;
-                    if (lo == pix) wsum += hw;
-                    if (hi == pix) wsum += lw;
-                }
-            }
-            if (isx) Wx[buf][row][bin] = wsum; else Wy[buf][row][bin] = wsum;
-            const unsigned long long nz = __ballot(wsum != 0.f);
-            if ((t & 63) == 0) {
-                const int wv = t >> 6;                         // waves 0, 1: y rows 0-3, 4-7; waves 2, 3: x rows 0-3, 4-7
-                if (wv < 2) {
+            // weight tables: entry idx of [Wy row 0 | Wy row 1 | Wx col 0..7] x 16 bins; lane handles idx = lane, lane + 64, lane + 128
+            unsigned iu = 0, jm = 0;
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) imask[buf][4 * wv + rr] = (unsigned short)((nz >> (16 * rr)) & 0xffffu);
-                } else {
-                    jmask[buf][wv - 2] = (unsigned short)((nz | (nz >> 16) | (nz >> 32) | (nz >> 48)) & 0xffffu);
+            for (int pass = 0; pass < 3; ++pass) {
+                const int idx = lane + 64 * pass;
+                const bool live = idx < 160;
+                const bool isx = idx >= 32;
+                const int q = isx ? idx - 32 : idx;
+                const int row = q >> 4, bin = q & 15;
+                const int np = isx ? pw : ph, grid = isx ? g.grid_w : g.grid_h, size = isx ? W : H, pix = (isx ? x0 : y0) + row;
+                const float start = isx ? g.start_w : g.start_h, bsz = isx ? g.bin_w : g.bin_h;
+                float wsum = 0.f;
+                if (live && bin < np && pix < size) {
+                    for (int s2 = 0; s2 < grid; ++s2) {
+                        int lo, hi; float lw, hw;
+                        if (!axis_sample(start + (float)bin * bsz + ((float)s2 + .5f) * bsz / (float)grid, size, lo, hi, lw, hw)) continue;
+                        if (lo == pix) wsum += hw;
+                        if (hi == pix) wsum += lw;
+                    }
                 }
+                if (live) wt[idx] = wsum;
+                const unsigned long long nz = __ballot(wsum != 0.f);
+                const unsigned fold = (unsigned)((nz | (nz >> 16) | (nz >> 32) | (nz >> 48)) & 0xffffu);
+                if (pass == 0) {                                    // lanes 0-31: Wy rows 0, 1;  lanes 32-63: Wx columns 0, 1
+                    iu = (unsigned)((nz | (nz >> 16)) & 0xffffu);
+                    jm = (unsigned)(((nz >> 32) | (nz >> 48)) & 0xffffu);
+                } else jm |= fold;                                  // Wx columns 2-5, 6-7
             }
-            return Ent{ph, pw, gout_s, k, 1.0f / g.count};
-        };
-        Ent cur = prepare(0, 0);
-        __syncthreads();
-        for (int i = 0; i < nb; ++i) {
-            const int buf = i & 1;
-            Ent nxt{};
-            if (i + 1 < nb) nxt = prepare(i + 1, buf ^ 1);  // the other buffer: its last readers passed the barrier below
-            const unsigned iu = (unsigned)imask[buf][2 * rg] | (unsigned)imask[buf][2 * rg + 1];
-            const unsigned jm = (unsigned)jmask[buf][0] | (unsigned)jmask[buf][1];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (iu != 0 && jm != 0 && c < C) {
-                const TG* gob = (const TG*)cur.gout + (int64_t)cur.k * cur.ph * cur.pw * C + c;
+                const TG* gob = (const TG*)gout_s + (int64_t)k * ph * pw * C + c;
+                const float inv = 1.0f / g.count;
                 unsigned jr = jm;
                 while (jr) {
                     const int j = __builtin_ctz(jr); jr &= jr - 1;
-                    float r0 = 0.f, r1 = 0.f;
+                    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
                     unsigned im = iu;
                     while (im) {
                         const int i2 = __builtin_ctz(im); im &= im - 1;
-                        const float gv = Elt<TG>::ld(gob + ((int64_t)i2 * cur.pw + j) * C);
-                        r0 += Wy[buf][2 * rg][i2] * gv; r1 += Wy[buf][2 * rg + 1][i2] * gv;
+                        const f32x4 gv = rg_load4(gob + ((int64_t)i2 * pw + j) * C);
+                        r0 += wt[i2] * gv; r1 += wt[16 + i2] * gv;
                     }
-                    r0 *= cur.inv; r1 *= cur.inv;
+                    r0 *= inv; r1 *= inv;
 #pragma unroll
-                    for (int x = 0; x < RG_TS; ++x) { const float wx = Wx[buf][x][j]; acc[0][x] += wx * r0; acc[1][x] += wx * r1; }
+                    for (int x = 0; x < RG_TS; ++x) { const float wx = wt[32 + 16 * x + j]; acc[0][x] += wx * r0; acc[1][x] += wx * r1; }
                 }
             }
-            cur = nxt;
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();                        // the table is rewritten for the wave's next entry
         }
     }
-    if (c >= C) return;
+    // ---- fold the four waves: round q handles columns 2q, 2q + 1 -- every wave leaves its partial sums in LDS, wave q adds and stores
     TO* out = l == 0 ? o0 : (l == 1 ? o1 : (l == 2 ? o2 : o3));
+    f32x4* fold = (f32x4*)pool;                                     // [4 waves][4 values][64 lanes] = 16 KB
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int y = y0 + 2 * rg + a;
-        if (y >= H) continue;
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();                                            // (first round: everybody is done with raw / ent / RoIs)
 #pragma unroll
-        for (int x = 0; x < RG_TS; ++x) {
-            if (x0 + x >= W) continue;
-            Elt<TO>::st(out + (((int64_t)n * H + y) * W + x0 + x) * C + c, acc[a][x]);
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int xx = 0; xx < 2; ++xx) fold[(wv * 4 + a * 2 + xx) * 64 + lane] = acc[a][2 * q + xx];
+        __syncthreads();
+        if (wv == q && c < C) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int y = y0 + a;
+                if (y >= H) continue;
+#pragma unroll
+                for (int xx = 0; xx < 2; ++xx) {
+                    const int x = x0 + 2 * q + xx;
+                    if (x >= W) continue;
+                    f32x4 v = fold[(0 * 4 + a * 2 + xx) * 64 + lane];
+#pragma unroll
+                    for (int w2 = 1; w2 < 4; ++w2) v += fold[(w2 * 4 + a * 2 + xx) * 64 + lane];
+                    rg_store4(out + (((int64_t)n * H + y) * W + x) * C + c, v);
+                }
+            }
         }
     }
 }
@@ -798,7 +821,7 @@ extern "C" int roi_align_multilevel_bwd_gather(void* const* grads, const int* Hs
         S.first[s] = ktot;
         if (s < n_sets) {
             if (Ks[m] < 0 || Ks[m] >= (1 << 24) || phs[m] <= 0 || pws[m] <= 0) return SWIN_ERR_BAD_ARG;
-            if (phs[m] > 16 || pws[m] > 16) return SWIN_ERR_UNSUPPORTED;
+            if (phs[m] > 16 || pws[m] > 16 || C % 4 != 0) return SWIN_ERR_UNSUPPORTED;
             if (Ks[m] > 0 && (!gouts[m] || !rois[m] || !lvls[m])) return SWIN_ERR_BAD_ARG;
             ktot += Ks[m];
         }
@@ -821,7 +844,7 @@ extern "C" int roi_align_multilevel_bwd_gather(void* const* grads, const int* Hs
     const int chunks = (C + RG_CH - 1) / RG_CH;
     void* o[4];
     for (int l = 0; l < 4; ++l) o[l] = grads[l < n_levels ? l : n_levels - 1];
-#define RG_LAUNCH(TG, TO) roi_gather_main<TG, TO><<<total * chunks, 256, 0, st>>>(Lv, S, C, sampling_ratio, aligned, offs, list, (TO*)o[0], (TO*)o[1], (TO*)o[2], (TO*)o[3])
+#define RG_LAUNCH(TG, TO) roi_gather_main<TG, TO><<<total * 4 * chunks, 256, 0, st>>>(Lv, S, C, sampling_ratio, aligned, offs, list, (TO*)o[0], (TO*)o[1], (TO*)o[2], (TO*)o[3])
     if (grad_dtype == SWIN_BF16 && out_dtype == SWIN_BF16) RG_LAUNCH(bf16, bf16);
     else if (grad_dtype == SWIN_F32 && out_dtype == SWIN_F32) RG_LAUNCH(float, float);
     else if (grad_dtype == SWIN_BF16 && out_dtype == SWIN_F32) RG_LAUNCH(bf16, float);

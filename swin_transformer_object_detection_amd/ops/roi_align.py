@@ -168,7 +168,7 @@ def _gather_backward(shapes, strides, sets, C, sr, aligned, in_dtype):
     import ctypes
     n = len(shapes)
     sets = [t for t in sets if t[0] is not None and t[1].shape[0] > 0]
-    if not _GATHER or not sets or len(sets) > 4 or any(ph > 16 or pw > 16 for _, _, _, ph, pw in sets):
+    if not _GATHER or not sets or len(sets) > 4 or C % 4 != 0 or any(ph > 16 or pw > 16 for _, _, _, ph, pw in sets):
         return None
     dev = sets[0][0].device
     N = shapes[0][0]
