@@ -11,7 +11,7 @@ def cat(n):
     if 'Cijk' in n: return 'hipBLASLt'
     if 'ln_' in n or 'layernorm' in n or 'patch_merge' in n: return 'layernorm'
     if 'gelu' in n: return 'bias_gelu'
-    if 'roi_align' in n: return 'roi_align'
+    if 'roi_align' in n or 'roi_gather' in n: return 'roi_align'
     if 'nms' in n: return 'nms'
     if 'rpn_topk' in n: return 'rpn select (mine)'
     if 'ts_mlp' in n: return 'fused mlp (mine)'
