@@ -182,7 +182,7 @@ def _gather_backward(shapes, strides, sets, C, sr, aligned, in_dtype):
     nb = int(_lib.lib().roi_align_gather_workspace_bytes(Hs, Ws, n, N, ktot))
     if nb <= 0:
         return None
-    key = (dev.index, nb)
+    key = (dev.index, nb, N, tuple((s[2], s[3]) for s in shapes))      # the layout inside the workspace follows the pyramid's tile counts
     ws = _GATHER_WS.get(key)
     if ws is None:
         ws = _GATHER_WS[key] = torch.zeros((nb + 3) // 4, device=dev, dtype=torch.int32)
