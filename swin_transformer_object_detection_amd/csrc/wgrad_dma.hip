@@ -122,7 +122,7 @@ __device__ __forceinline__ void wgrad2_body(char* lds2, const int block_id, cons
     {
         int L = block_id;
         const int tiles = g1 * g2;
-        if (xcd_map) {                      // a split's tiles on ONE XCD (blocks b and b + 8 share one): its dY / X rows are fetched into that
+        if (xcd_map & 1) {                  // a split's tiles on ONE XCD (blocks b and b + 8 share one): its dY / X rows are fetched into that
             const int xcd = L & 7, q = L >> 3;      // L2 once and hit by the other tiles.  splits % 8 == 0 (host).
             bz = (q / tiles) * 8 + xcd;
             L = q % tiles;
@@ -256,6 +256,9 @@ __device__ __forceinline__ void wgrad2_body(char* lds2, const int block_id, cons
         compute(it % NBUF);
     }
     const int c = lane & 31, h = lane >> 5;
+    // One split and nobody else adding into this dW / db during the launch (xcd_map bit 2, set by the grouped launcher): a tile has a
+    // single writer, so its sums go out as plain read-modify-writes instead of float atomics (1.3 TB/s chip-wide, guide G12).
+    const bool plain = (xcd_map & 4) != 0;
     // ---- fold the k-groups through LDS (the ring is free: every DMA has landed and been consumed)
     if (WKG > 1) {
         float* red = reinterpret_cast<float*>(lds2);             // [128][128] fp32 = 64 KB (+ 128 bias sums behind it)
@@ -303,7 +306,9 @@ __device__ __forceinline__ void wgrad2_body(char* lds2, const int block_id, cons
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int n1 = n1_0 + w1 * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (n1 < N1) atomicAdd(dw + (int64_t)n1 * N2 + n2, acc[i][j][reg]);
+                if (n1 >= N1) continue;
+                float* d = dw + (int64_t)n1 * N2 + n2;
+                if (plain) *d += acc[i][j][reg]; else atomicAdd(d, acc[i][j][reg]);
             }
         }
     if (do_bias && c == 0) {                     // every column of accb holds the same sums: lane 0 of each half adds its 16 rows
@@ -312,7 +317,8 @@ __device__ __forceinline__ void wgrad2_body(char* lds2, const int block_id, cons
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int n1 = n1_0 + w1 * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (n1 < N1) atomicAdd(dbias + n1, accb[i][reg]);
+                if (n1 >= N1) continue;
+                if (plain) dbias[n1] += accb[i][reg]; else atomicAdd(dbias + n1, accb[i][reg]);
             }
     }
 }
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_group_kernel(const GTab tab) {
     while (pi + 1 < tab.n && id >= tab.first_block[pi + 1]) ++pi;        // block-uniform scalar search over <= 32 entries
     const GProb& q = tab.p[pi];
     PlainSrc X{q.x, q.N2};
-    wgrad2_body<PlainSrc, 2, 1>(lds2, id - tab.first_block[pi], q.dy, X, q.dw, q.db, q.T, q.N1, q.N2, q.per, q.g2, q.g1, q.splits, 0);
+    wgrad2_body<PlainSrc, 2, 1>(lds2, id - tab.first_block[pi], q.dy, X, q.dw, q.db, q.T, q.N1, q.N2, q.per, q.g2, q.g1, q.splits, q.pad ? 4 : 0);
 }
 
 template <typename XSrc> inline void set_step(XSrc&, int) {}
@@ -657,6 +663,10 @@ int launch_group(const Pending* pp, int n, hipStream_t s) {
         int64_t per = (stages + splits - 1) / splits * ST;
         splits = (q.T + per - 1) / per;
         q.per = per; q.splits = (int)splits;
+        // pad = 1: plain read-modify-write epilogue -- one split, and no other problem of this launch accumulates into the same dW / db
+        q.pad = splits == 1 ? 1 : 0;
+        for (int k = 0; k < n && q.pad; ++k)
+            if (k != i && (pp[k].dw == pp[i].dw || (pp[i].db && pp[k].db == pp[i].db))) q.pad = 0;
         tab.first_block[i] = (int)nblk;
         nblk += splits * q.g1 * q.g2;
         if (nblk > (int64_t)1 << 30) return SWIN_ERR_UNSUPPORTED;
