@@ -540,3 +540,55 @@ def test_fpn_bf16_hip_conv_vs_oracle(pkg):
         _close(o, r, _bf16_tol(r, 4), f"out{i}")              # two chained bf16 roundings (lateral sum, conv output)
     for i in range(4):
         _close(x1[i].grad, x0[i].grad, _bf16_tol(x0[i].grad, 6), f"gin{i}")
+
+
+@pytest.mark.parametrize("hot", [False, True])
+def test_roi_align_backward_stage_geometry_gather_vs_fp32_oracle_sum(pkg, hot):
+    """The RoIAlign backward of one R-CNN stage at the benchmark's geometry -- 1024 RoIs pooled 7x7 and 256 pooled 14x14 from the
+    four levels of a 2x800x1280 pyramid (single_level_roi_extractor.py:93-97) -- through the autograd path the detector uses
+    (ops.roi_align_multilevel_group, gather-form backward) against the fp32 scatter kernel on the same inputs; `hot` piles every
+    RoI on one of 16 objects, as the sampled RoIs of a training step pile up on the ground-truth boxes."""
+    import ctypes
+    from swin_transformer_object_detection_amd import ops
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    torch.manual_seed(3)
+    N, C = 2, 256
+    shapes = [(200, 320), (100, 160), (50, 80), (25, 40)]
+    strides = [4, 8, 16, 32]
+    sets = []
+    for K, out in ((1024, 7), (256, 14)):
+        rois = torch.rand(K, 5, device="cuda")
+        rois[:, 0] = (torch.arange(K, device="cuda") >= K // 2).float()
+        wh = torch.exp(torch.rand(K, 2, device="cuda") * 4.0 + 2.5)
+        rois[:, 1:3] = rois[:, 1:3] * torch.tensor([1280., 800.], device="cuda") * 0.8
+        rois[:, 3:] = torch.minimum(rois[:, 1:3] + wh, torch.tensor([1279., 799.], device="cuda"))
+        if hot:
+            obj = rois[torch.randint(0, 16, (K,), device="cuda")]
+            rois[:, 1:] = obj[:, 1:] + torch.randn(K, 4, device="cuda") * 6.0
+            rois[:, 3:] = torch.maximum(rois[:, 3:], rois[:, 1:3] + 8.0)
+        scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+        lv = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(0, 3).int()
+        sets.append((rois, lv, out))
+    feats = [torch.randn(N, C, h, w, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for h, w in shapes]
+    outs = ops.roi_align_multilevel_group(feats, sets, strides, 0, True, out_dtype=torch.bfloat16)
+    gys = [torch.randn(o.shape, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last) for o in outs]
+    torch.autograd.backward(outs, gys)
+    # fp32 scatter reference
+    n = 4
+    Hs = (ctypes.c_int * n)(*[s[0] for s in shapes]); Ws = (ctypes.c_int * n)(*[s[1] for s in shapes])
+    sc = (ctypes.c_float * n)(*[1.0 / s for s in strides])
+    acc = [torch.zeros(N, h, w, C, device="cuda") for h, w in shapes]
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in acc])
+    for (r, lv, out), g in zip(sets, gys):
+        gn = g.permute(0, 2, 3, 1).contiguous()
+        Fn.call("roi_align_multilevel_bwd", ptrs, Hs, Ws, sc, n, Fn._p(gn), Fn._p(r.float().contiguous()), Fn._p(lv), C, r.shape[0], out, out, 0, 1,
+                Fn.SWIN_BF16, Fn._s())
+    torch.cuda.synchronize()
+    for l, (f, a) in enumerate(zip(feats, acc)):
+        ref = a.permute(0, 3, 1, 2)
+        if float(ref.abs().max()) == 0:              # no RoI mapped to this level: the gather form must have written zeros
+            assert float(f.grad.float().abs().max()) == 0, l
+            continue
+        _close(f.grad, ref, _bf16_tol(ref, 1.5), f"level {l}")
+    assert float(acc[0].abs().max()) > 0
