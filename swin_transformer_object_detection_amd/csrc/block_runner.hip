@@ -28,13 +28,21 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
     const float scale = fv[0], eps = fv[1];
     const int64_t L = (int64_t)H * W, T = (int64_t)B * L;
     void* ws = const_cast<void*>(p[34]);
-    CHK(swin_gemm_bf16(p[1], p[4], p[5], const_cast<void*>(p[19]), T, 3 * C, C, 0, ws, stream));
+    // narrow stages: the token-stationary kernels of csrc/ts_linear.hip (qkv; proj + residual + norm2 in one launch)
+    const bool ts = C == 96 || C == 128 || C == 192 || C == 256;
+    if (ts) CHK(swin_ts_linear_bf16(p[1], p[4], p[5], const_cast<void*>(p[19]), T, 3 * C, C, stream));
+    else CHK(swin_gemm_bf16(p[1], p[4], p[5], const_cast<void*>(p[19]), T, 3 * C, C, 0, ws, stream));
     if (p[7]) CHK(swin_rel_bias_expand((const float*)p[7], (float*)p[8], nH, stream));     // null: 8 already holds this step's expansion
     CHK(swin_window_attn_fwd(p[19], (const float*)p[6], (const float*)p[8], const_cast<void*>(p[21]), (float*)p[20], B, H, W, C, nH,
                              shift, scale, SWIN_BF16, stream));
-    CHK(swin_gemm_bf16(p[21], p[9], p[10], const_cast<void*>(p[22]), T, C, C, 0, ws, stream));
-    CHK(swin_add_layernorm_fwd(p[0], p[22], (const float*)p[2], L, (const float*)p[11], (const float*)p[12], const_cast<void*>(p[23]),
-                               const_cast<void*>(p[24]), (float*)p[25], (float*)p[26], T, C, eps, SWIN_BF16, stream));
+    if (ts) {
+        CHK(swin_ts_proj_add_ln_bf16(p[21], p[9], p[10], p[0], (const float*)p[2], L, (const float*)p[11], (const float*)p[12],
+                                     const_cast<void*>(p[23]), const_cast<void*>(p[24]), (float*)p[25], (float*)p[26], T, C, eps, stream));
+    } else {
+        CHK(swin_gemm_bf16(p[21], p[9], p[10], const_cast<void*>(p[22]), T, C, C, 0, ws, stream));
+        CHK(swin_add_layernorm_fwd(p[0], p[22], (const float*)p[2], L, (const float*)p[11], (const float*)p[12], const_cast<void*>(p[23]),
+                                   const_cast<void*>(p[24]), (float*)p[25], (float*)p[26], T, C, eps, SWIN_BF16, stream));
+    }
     if (iv[6]) {
         CHK(swin_mlp_fwd_bf16(p[24], p[13], (const float*)p[14], p[15], (const float*)p[35], const_cast<void*>(p[29]), T, C, stream));
     } else {

@@ -784,8 +784,13 @@ def test_fused_swin_block_equals_per_op_blocks(fused_mlp, monkeypatch):
         bad = {n: round(rel(gp0[n], gp1[n]), 4) for n in gp0 if rel(gp0[n], gp1[n]) > 0.05}
         assert not bad, bad
         return
+    # forward outputs: at the narrow widths the runner computes qkv and proj + residual + norm2 with the token-stationary kernels
+    # (csrc/ts_linear.hip) while the per-op path calls the library GEMM + add_layernorm: same rounding points, another fp32
+    # summation order -> isolated one-ulp differences that travel through the following blocks
+    ulp = 2.0 ** -8
     for a, b in zip(o0, o1):
-        assert torch.equal(a, b)
+        assert float((a - b).abs().max()) <= 6 * ulp * float(a.abs().max())
+        assert float((a - b).abs().mean()) <= 0.25 * ulp * float(a.abs().max())
     # the input gradient: identical kernels except at C = 192, where the runner takes the fc2 data gradient and the GELU backward as
     # ONE launch of the hand-written GEMM (round 3) while the per-op path runs the library GEMM + bias_gelu_bwd -- two GEMM kernels
     # may round a product differently by one bf16 ulp, which then travels through the remaining blocks

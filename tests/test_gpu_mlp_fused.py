@@ -129,3 +129,70 @@ def test_mlp_gelu_epilogue_gemms_vs_oracle(fn, T, C):
     assert float((hp2.float() - hpre.float()).abs().max()) <= _tol(hpre_ref, 1.01)       # two GEMM kernels: at most an ulp apart
     same = hp2 == hpre
     assert bool((h2[same] == h[same]).all())                                               # same pre-activation -> same GELU bits
+
+
+@pytest.mark.parametrize("C", [96, 128, 192, 256])
+@pytest.mark.parametrize("T", [1, 37, 1000, 2 * 25 * 40 + 5])
+def test_token_stationary_qkv_and_proj_ln_equal_the_library_chain(C, T):
+    """csrc/ts_linear.hip against the launches it replaces in swin_block_fwd: swin_gemm_bf16 for qkv (swin_transformer.py:129) and
+    swin_gemm_bf16 + swin_add_layernorm_fwd for proj / residual / DropPath scale / norm2 (:150-151, :252-253).  The rounding points
+    are the same, the fp32 summation order is not: a 16-bit output may differ by one ulp where the sum sits on a rounding boundary."""
+    import ctypes
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    H = _lib.half_dtype()
+    g = torch.Generator().manual_seed(C + T)
+    dev = torch.device("cuda", 0)
+    x = torch.randn(T, C, generator=g).to(dev, H)
+    o = torch.randn(T, C, generator=g).to(dev, H)
+    n1 = torch.randn(T, C, generator=g).to(dev, H)
+    wqkv = (torch.randn(3 * C, C, generator=g) * C ** -0.5).to(dev, H)
+    bqkv = (torch.randn(3 * C, generator=g) * 0.1).to(dev, H)
+    wproj = (torch.randn(C, C, generator=g) * C ** -0.5).to(dev, H)
+    bproj = (torch.randn(C, generator=g) * 0.1).to(dev, H)
+    gamma = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    ws = torch.empty(_lib.lib().swin_gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+
+    def ulp_close(a, b, what):
+        a, b = a.float(), b.float()
+        tol = 2.0 ** (-10 if H == torch.float16 else -7) * b.abs().clamp(min=2.0 ** -6)       # one ulp of the value (floor for tiny values)
+        bad = (a - b).abs() > tol
+        assert float(bad.float().mean()) <= 2e-3 and float(((a - b).abs() / tol).max()) <= 2.01, (what, int(bad.sum()))
+    # qkv
+    for bias in (bqkv, None):
+        q0 = torch.empty(T, 3 * C, device=dev, dtype=H)
+        q1 = torch.full_like(q0, float("nan"))
+        Fn.call("swin_gemm_bf16", Fn._p(n1), Fn._p(wqkv), Fn._p(bias), Fn._p(q0), T, 3 * C, C, 0, Fn._p(ws), Fn._s())
+        Fn.call("swin_ts_linear_bf16", Fn._p(n1), Fn._p(wqkv), Fn._p(bias), Fn._p(q1), T, 3 * C, C, Fn._s())
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(q1.float()).all())
+        ulp_close(q1, q0, "qkv")
+    # proj + residual + norm2, with and without a DropPath scale (two samples of unequal length: the row -> sample map)
+    L = max(T // 2, 1)
+    for dp in (None, torch.tensor([1.25, 0.0, 0.5], device=dev)[: (T + L - 1) // L]):
+        y = torch.empty(T, C, device=dev, dtype=H)
+        x1a, n2a = torch.empty_like(x), torch.empty_like(x)
+        ma, ra = torch.empty(T, device=dev), torch.empty(T, device=dev)
+        Fn.call("swin_gemm_bf16", Fn._p(o), Fn._p(wproj), Fn._p(bproj), Fn._p(y), T, C, C, 0, Fn._p(ws), Fn._s())
+        Fn.call("swin_add_layernorm_fwd", Fn._p(x), Fn._p(y), Fn._p(dp), L, Fn._p(gamma), Fn._p(beta), Fn._p(x1a), Fn._p(n2a), Fn._p(ma), Fn._p(ra),
+                T, C, 1e-5, Fn.SWIN_BF16, Fn._s())
+        x1b, n2b = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+        mb, rb = torch.empty(T, device=dev), torch.empty(T, device=dev)
+        Fn.call("swin_ts_proj_add_ln_bf16", Fn._p(o), Fn._p(wproj), Fn._p(bproj), Fn._p(x), Fn._p(dp), L, Fn._p(gamma), Fn._p(beta), Fn._p(x1b),
+                Fn._p(n2b), Fn._p(mb), Fn._p(rb), T, C, 1e-5, Fn._s())
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(n2b.float()).all())
+        # x1 = x + dp * y: a one-ulp difference of y arrives scaled by dp and need not be small against x1 itself
+        eps16 = 2.0 ** (-10 if H == torch.float16 else -7)
+        tol1 = eps16 * (x1a.float().abs() + 1.25 * y.float().abs() + 2.0 ** -6)
+        d1 = (x1b.float() - x1a.float()).abs()
+        assert float((d1 > tol1).float().mean()) == 0.0 and float((d1 > 0).float().mean()) <= 2e-3, int((d1 > tol1).sum())
+        assert float((mb - ma).abs().max()) <= 2e-3 and float(((rb - ra).abs() / ra).max()) <= 2e-3
+        # n2 follows x1: compare through the LayerNorm of the fused kernel's own x1 where x1 agrees, loosely elsewhere
+        assert float((n2b.float() - n2a.float()).abs().max()) <= 0.06 * float(n2a.float().abs().max())
+        same = (x1b == x1a).all(dim=1)
+        if bool(same.any()):
+            ulp_close(n2b[same], n2a[same], "n2")
