@@ -485,11 +485,13 @@ int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1, const void
 int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, const float* b1, const void* w2, void* dx, void* h,
                       void* dhpre, int64_t T, int C, void* stream);
 /* Token-stationary Linear layers of the attention branch for C in {96, 128, 192, 256} (csrc/ts_linear.hip; a wave owns 32 tokens):
- *   swin_ts_linear_bf16:      y (T,N) = x (T,C) w (N,C)^T + bias (N, 16-bit or NULL)  -- the qkv projection (swin_transformer.py:129)
+ *   swin_ts_linear_bf16:      y (T,N) = [relu](x (T,C) w (N,C)^T + bias (N, 16-bit or NULL)), N % 64 == 0  -- the qkv projection
+ *                             (swin_transformer.py:129), the FPN laterals of the narrow stages (fpn.py:171-174), the mask head's
+ *                             2x2 deconvolution as a GEMM with its ReLU (fcn_mask_head.py:122-126)
  *   swin_ts_proj_add_ln_bf16: x1 = x + dp[row / rows_per_sample] * (o w^T + bias);  n2 = LayerNorm(x1)  -- proj, residual, DropPath
  *                             scale and norm2 (swin_transformer.py:150-151, 252-253) in one launch; mean / rstd (T) f32 for the backward.
  * Same rounding points as the library GEMM + swin_add_layernorm_fwd chain.  Other C: SWIN_ERR_UNSUPPORTED. */
-int swin_ts_linear_bf16(const void* x, const void* w, const void* bias, void* y, int64_t T, int N, int C, void* stream);
+int swin_ts_linear_bf16(const void* x, const void* w, const void* bias, void* y, int64_t T, int N, int C, int relu, void* stream);
 int swin_ts_proj_add_ln_bf16(const void* o, const void* w, const void* bias, const void* x, const float* dp, int64_t rows_per_sample,
                              const float* gamma, const float* beta, void* x1, void* n2, float* mean, float* rstd, int64_t T, int C,
                              float eps, void* stream);

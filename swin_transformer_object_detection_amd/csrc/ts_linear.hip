@@ -20,7 +20,7 @@ __device__ __forceinline__ int tile_ch(int q, int h) { return (q < 8 ? 8 * h + q
 
 template <int C, int WAVES, int CH>
 __global__ __launch_bounds__(WAVES * 64) void ts_linear_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W, const bf16* __restrict__ bias,
-                                                               bf16* __restrict__ Y, int64_t T, int N) {
+                                                               bf16* __restrict__ Y, int64_t T, int N, int relu) {
     using I = WImg<CH, C>;
     constexpr int KS = C / 16, HT = CH / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // two chunk images | bias as f32 [N]
@@ -55,7 +55,10 @@ __global__ __launch_bounds__(WAVES * 64) void ts_linear_kernel(const bf16* __res
             if (tok < T) {
                 bf16x8 o0, o1;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { o0[e] = (bf16)a[e]; o1[e] = (bf16)a[8 + e]; }
+                for (int e = 0; e < 8; ++e) {
+                    o0[e] = (bf16)(relu ? fmaxf(a[e], 0.f) : a[e]);
+                    o1[e] = (bf16)(relu ? fmaxf(a[8 + e], 0.f) : a[8 + e]);
+                }
                 *(bf16x8*)(Y + tok * N + n0 + 8 * h) = o0;
                 *(bf16x8*)(Y + tok * N + n0 + 16 + 8 * h) = o1;
             }
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(WAVES * 64) void ts_proj_add_ln_kernel(const bf16* 
 }
 
 template <int C, int WAVES, int CH>
-int launch_linear(const void* x, const void* w, const void* bias, void* y, int64_t T, int N, hipStream_t s) {
+int launch_linear(const void* x, const void* w, const void* bias, void* y, int64_t T, int N, int relu, hipStream_t s) {
     if (N % CH != 0) return SWIN_ERR_UNSUPPORTED;
     const size_t lds = 2 * (size_t)WImg<CH, C>::BYTES + (size_t)N * sizeof(float);
     static bool attr_set[16] = {};
@@ -159,7 +162,7 @@ int launch_linear(const void* x, const void* w, const void* bias, void* y, int64
         attr_set[dev] = true;
     }
     const unsigned blocks = (unsigned)((T + WAVES * 32 - 1) / (WAVES * 32));
-    kern<<<blocks, WAVES * 64, lds, s>>>((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)y, T, N);
+    kern<<<blocks, WAVES * 64, lds, s>>>((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)y, T, N, relu);
     return swin_launch_status();
 }
 
@@ -183,17 +186,17 @@ int launch_proj(const void* o, const void* w, const void* bias, const void* x, c
 
 }  // namespace
 
-// y (T, N) = x (T, C) w (N, C)^T + bias (N; 16-bit, may be NULL).  C in {96, 128, 192, 256}, N a multiple of 96 (C = 96, 192) or 128
-// (C = 128, 256) -- the qkv projection's 3C; else SWIN_ERR_UNSUPPORTED.
-extern "C" int swin_ts_linear_bf16(const void* x, const void* w, const void* bias, void* y, int64_t T, int N, int C, void* stream) {
+// y (T, N) = [relu](x (T, C) w (N, C)^T + bias (N; 16-bit, may be NULL)).  C in {96, 128, 192, 256}, N a multiple of 64 (of 96 / 128 at
+// C = 96, 192 / 128 the whole-chunk variants are used: the qkv projection's 3C); else SWIN_ERR_UNSUPPORTED.
+extern "C" int swin_ts_linear_bf16(const void* x, const void* w, const void* bias, void* y, int64_t T, int N, int C, int relu, void* stream) {
     if (T == 0) return SWIN_OK;
     if (!x || !w || !y || T < 0 || N <= 0) return SWIN_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     switch (C) {
-        case 96: return launch_linear<96, 8, 96>(x, w, bias, y, T, N, s);
-        case 128: return launch_linear<128, 8, 128>(x, w, bias, y, T, N, s);
-        case 192: return launch_linear<192, 8, 96>(x, w, bias, y, T, N, s);
-        case 256: return launch_linear<256, 8, 64>(x, w, bias, y, T, N, s);
+        case 96: return N % 96 == 0 ? launch_linear<96, 8, 96>(x, w, bias, y, T, N, relu, s) : launch_linear<96, 8, 64>(x, w, bias, y, T, N, relu, s);
+        case 128: return N % 128 == 0 ? launch_linear<128, 8, 128>(x, w, bias, y, T, N, relu, s) : launch_linear<128, 8, 64>(x, w, bias, y, T, N, relu, s);
+        case 192: return N % 96 == 0 ? launch_linear<192, 8, 96>(x, w, bias, y, T, N, relu, s) : launch_linear<192, 8, 64>(x, w, bias, y, T, N, relu, s);
+        case 256: return launch_linear<256, 8, 64>(x, w, bias, y, T, N, relu, s);
         default: return SWIN_ERR_UNSUPPORTED;
     }
 }

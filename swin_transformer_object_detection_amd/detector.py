@@ -969,7 +969,7 @@ class FCNMaskHead(nn.Module):
         tok = x.permute(0, 2, 3, 1).reshape(P * H * W, C)
         w = _cast(self.upsample.weight, dt).permute(2, 3, 1, 0).reshape(4 * Co, C)     # rows (ky,kx,co)
         b = _cast(self.upsample.bias, dt).repeat(4)
-        return F.relu(ops.linear(tok, w, b, dt), inplace=True)                         # (P*H*W, 4*Co)
+        return ops.linear(tok, w, b, dt, relu=True)                                    # (P*H*W, 4*Co); ReLU in the GEMM's epilogue
 
     def _deconv2x2_relu(self, x, dt):
         """_deconv_rows followed by the 2x2 pixel shuffle -> (P, Co, 2H, 2W) channels-last view."""

@@ -593,7 +593,10 @@ _MIN_T = int(os.environ.get("SWIN_LINEAR_MIN_T", "1024"))   # rows below which n
 _DIRECT_GEMM = os.environ.get("SWIN_TORCH_GEMM") != "1"      # A/B switch (development): 1 = torch.nn.functional.linear / mm
 
 
-def gemm_bf16(a, b, bias=None, b_is_kn=False, out_shape=None):
+_TS_K = (96, 128, 192, 256)
+
+
+def gemm_bf16(a, b, bias=None, b_is_kn=False, out_shape=None, relu=False):
     """c (M,N) = a (M,K) @ (b.T if b is (N,K) else b) [+ bias] in bf16 with fp32 accumulation, straight on hipBLASLt
     through the C ABI (swin_gemm_bf16: cached plans, no framework dispatch).  2-D contiguous bf16 GPU tensors."""
     M, K = a.shape
@@ -603,8 +606,16 @@ def gemm_bf16(a, b, bias=None, b_is_kn=False, out_shape=None):
     if ws is None:
         ws = _GEMM_WS[dev] = torch.empty(_lib.lib().swin_gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
     c = torch.empty((M, N) if out_shape is None else out_shape, dtype=_H(), device=dev)   # not a view
+    if not b_is_kn and K in _TS_K and M >= 4096 and N % 32 == 0:
+        # narrow contraction, long token axis (qkv / proj of stages 1-2, the FPN laterals of those stages, the mask head's
+        # deconvolution as a GEMM): HBM-bound -- the token-stationary kernel (csrc/ts_linear.hip) instead of the library
+        rc = _lib.lib().swin_ts_linear_bf16(_p(a), _p(b), _p(bias), _p(c), M, N, K, 1 if relu else 0, _s())
+        if rc == 0:
+            return c
+        if rc != 2:                                            # 2 = SWIN_ERR_UNSUPPORTED: this N has no chunking -> library
+            raise SwinHipError(f"swin_ts_linear_bf16 failed with status {rc}")
     call("swin_gemm_bf16", _p(a), _p(b), _p(bias), _p(c), M, N, K, 1 if b_is_kn else 0, _p(ws), _s())
-    return c
+    return c.relu_() if relu else c
 
 
 class _LinearBf16(torch.autograd.Function):
@@ -614,9 +625,9 @@ class _LinearBf16(torch.autograd.Function):
     ``b`` may be a constant bf16 copy of ``b_master`` (mixed.const): the bias gradient then goes to ``b_master``."""
 
     @staticmethod
-    def forward(ctx, x, w, b, w_master, b_master):
+    def forward(ctx, x, w, b, w_master, b_master, relu=False):
         from .. import mixed
-        ctx.save_for_backward(x, w)
+        ctx.relu = bool(relu)
         ctx.has_bias = b is not None
         ctx.masters = (w_master, b_master)
         ctx.bias_to_master = b is not None and not ctx.needs_input_grad[2] and b_master is not None and b_master.requires_grad
@@ -627,13 +638,25 @@ class _LinearBf16(torch.autograd.Function):
             ctx.counted = True
         x2 = x.reshape(-1, w.shape[1])
         if _DIRECT_GEMM and x2.is_contiguous() and w.is_contiguous() and (b is None or (b.dtype == _H() and b.is_contiguous())):
-            return gemm_bf16(x2, w, b, out_shape=tuple(x.shape[:-1]) + (w.shape[0],))
-        return torch.nn.functional.linear(x, w, b)
+            y = gemm_bf16(x2, w, b, out_shape=tuple(x.shape[:-1]) + (w.shape[0],), relu=ctx.relu)      # ReLU in the kernel's epilogue where it has one
+        else:
+            y = torch.nn.functional.linear(x, w, b)
+            if ctx.relu:
+                y = y.relu_()
+        if ctx.relu:
+            ctx.save_for_backward(x, w, y)
+        else:
+            ctx.save_for_backward(x, w)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         from .. import mixed
-        x, w = ctx.saved_tensors
+        if ctx.relu:
+            x, w, y = ctx.saved_tensors
+            dy = torch.ops.aten.threshold_backward(dy, y, 0)        # the gradient at the ReLU's input
+        else:
+            x, w = ctx.saved_tensors
         w_master, b_master = ctx.masters
         N1, N2 = w.shape
         dy2 = dy.reshape(-1, N1)
@@ -680,10 +703,10 @@ class _LinearBf16(torch.autograd.Function):
                     db = dbf.to(dy.dtype)
         elif ctx.counted:
             mixed.use_end(w_master)
-        return dx, dw, db, None, dbm
+        return dx, dw, db, None, dbm, None
 
 
-def linear(x, weight, bias=None, dtype=None):
+def linear(x, weight, bias=None, dtype=None, relu=False):
     """nn.Linear on the compute-dtype copies of fp32 master parameters ``weight`` / ``bias`` (resolved through
     mixed.weight).  bf16 GPU tensors with 8-aligned widths and a long token axis use the hand-written
     weight/bias-gradient kernel; anything else is the plain library path."""
@@ -697,8 +720,9 @@ def linear(x, weight, bias=None, dtype=None):
         b = mixed.const(bias, dtype)                                # bf16 constant; gradient delivered to the master
         if b is None:
             b = mixed.weight(bias, dtype)
-        return _LinearBf16.apply(x, w, b, weight, bias)
-    return torch.nn.functional.linear(x, w, mixed.weight(bias, dtype))
+        return _LinearBf16.apply(x, w, b, weight, bias, relu)
+    y = torch.nn.functional.linear(x, w, mixed.weight(bias, dtype))
+    return torch.relu_(y) if relu else y
 
 
 # --------------------------------------------------------------------------------------

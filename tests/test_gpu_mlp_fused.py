@@ -166,10 +166,19 @@ def test_token_stationary_qkv_and_proj_ln_equal_the_library_chain(C, T):
         q0 = torch.empty(T, 3 * C, device=dev, dtype=H)
         q1 = torch.full_like(q0, float("nan"))
         Fn.call("swin_gemm_bf16", Fn._p(n1), Fn._p(wqkv), Fn._p(bias), Fn._p(q0), T, 3 * C, C, 0, Fn._p(ws), Fn._s())
-        Fn.call("swin_ts_linear_bf16", Fn._p(n1), Fn._p(wqkv), Fn._p(bias), Fn._p(q1), T, 3 * C, C, Fn._s())
+        Fn.call("swin_ts_linear_bf16", Fn._p(n1), Fn._p(wqkv), Fn._p(bias), Fn._p(q1), T, 3 * C, C, 0, Fn._s())
         torch.cuda.synchronize()
         assert bool(torch.isfinite(q1.float()).all())
         ulp_close(q1, q0, "qkv")
+    # N = 256 (an FPN lateral: the 64-row chunk variant) with the ReLU epilogue
+    wl = (torch.randn(256, C, generator=g) * C ** -0.5).to(dev, H)
+    bl = (torch.randn(256, generator=g) * 0.1).to(dev, H)
+    l0 = torch.empty(T, 256, device=dev, dtype=H)
+    l1 = torch.full_like(l0, float("nan"))
+    Fn.call("swin_gemm_bf16", Fn._p(n1), Fn._p(wl), Fn._p(bl), Fn._p(l0), T, 256, C, 0, Fn._p(ws), Fn._s())
+    Fn.call("swin_ts_linear_bf16", Fn._p(n1), Fn._p(wl), Fn._p(bl), Fn._p(l1), T, 256, C, 1, Fn._s())
+    torch.cuda.synchronize()
+    ulp_close(l1, torch.relu(l0), "lateral + relu")
     # proj + residual + norm2, with and without a DropPath scale (two samples of unequal length: the row -> sample map)
     L = max(T // 2, 1)
     for dp in (None, torch.tensor([1.25, 0.0, 0.5], device=dev)[: (T + L - 1) // L]):
