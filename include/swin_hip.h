@@ -484,6 +484,13 @@ int swin_mlp_fwd_bf16(const void* x, const void* w1, const float* b1, const void
                       int C, void* stream);
 int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, const float* b1, const void* w2, void* dx, void* h,
                       void* dhpre, int64_t T, int C, void* stream);
+/* swin_mlp_fwd_bf16 with the block's second residual and the next LayerNorm in its epilogue (swin_transformer.py:253, :211):
+ *   x2 (T,C) = x1 + dp[row / rows_per_sample] * Mlp(x);  nn = LayerNorm(x2; gamma, beta, eps), mean / rstd (T) f32.
+ *   gamma NULL: residual only (nn / mean / rstd unused).  dp NULL: scale 1.  C in {96, 192}.  Same rounding points as
+ *   swin_mlp_fwd_bf16 + swin_add_layernorm_fwd. */
+int swin_mlp_add_ln_fwd_bf16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* x1,
+                             const float* dp, int64_t rows_per_sample, const float* gamma, const float* beta, void* x2, void* nn,
+                             float* mean, float* rstd, int64_t T, int C, float eps, void* stream);
 /* Token-stationary Linear layers of the attention branch for C in {96, 128, 192, 256} (csrc/ts_linear.hip; a wave owns 32 tokens):
  *   swin_ts_linear_bf16:      y (T,N) = [relu](x (T,C) w (N,C)^T + bias (N, 16-bit or NULL)), N % 64 == 0  -- the qkv projection
  *                             (swin_transformer.py:129), the FPN laterals of the narrow stages (fpn.py:171-174), the mask head's

@@ -44,7 +44,10 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
                                    const_cast<void*>(p[24]), (float*)p[25], (float*)p[26], T, C, eps, SWIN_BF16, stream));
     }
     if (iv[6]) {
-        CHK(swin_mlp_fwd_bf16(p[24], p[13], (const float*)p[14], p[15], (const float*)p[35], const_cast<void*>(p[29]), T, C, stream));
+        // fused MLP with the second residual and the next norm in its epilogue: the block's last launch
+        return swin_mlp_add_ln_fwd_bf16(p[24], p[13], (const float*)p[14], p[15], (const float*)p[35], p[23], (const float*)p[3], L,
+                                        (const float*)p[17], (const float*)p[18], const_cast<void*>(p[30]), const_cast<void*>(p[31]),
+                                        (float*)p[32], (float*)p[33], T, C, eps, stream);
     } else {
         // fc1 with the GELU in its epilogue (hand-written GEMM: hpre and h leave the kernel together) when the width allows
         if (C % 64 == 0) {

@@ -87,10 +87,19 @@ template <int C, int CH> struct TsGeom {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
+// Optional epilogue of the forward kernel (x1 != null): the block's second residual and the NEXT LayerNorm in the same launch --
+//   x2 = x1 + dp[row / rows_per_sample] * y;   nn = LayerNorm(x2; gamma, beta)   (swin_transformer.py:253 and :211 of the next block)
+// -- instead of storing y for a separate swin_add_layernorm_fwd.  A token's output row sits in lanes r and r + 32 (16 channels per
+// 32-channel tile each), so the statistics cost one cross-lane add each.  gamma == null: residual only (x2 stored, no norm).
+struct MlpEpi {
+    const bf16* x1; const float* dp; int64_t rows_per_sample; const float* gamma; const float* beta;
+    bf16* x2; bf16* nn; float* mean; float* rstd; float eps;
+};
+
 template <int C, int WAVES, int CH, int OCC, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_fwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W1,
                                                                const float* __restrict__ b1, const bf16* __restrict__ W2,
-                                                               const float* __restrict__ b2, bf16* __restrict__ Y, int64_t T) {
+                                                               const float* __restrict__ b2, bf16* __restrict__ Y, int64_t T, MlpEpi E) {
     using G = TsGeom<C, CH>;
     using I1 = WImg<CH, C>;                                          // W1 chunk: CH hidden rows x C
     using I2 = WImg<C, CH>;                                          // W2 chunk: C rows x CH hidden
@@ -178,6 +187,60 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_fwd_kernel(const bf16*
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next chunk's DMA has landed (this wave's part)
         __syncthreads();                                            // ... everyone's; and everyone is done with this buffer
     }
+    if (E.x1) {
+        // ---- residual + next LayerNorm epilogue.  Rounding points of the three-launch chain: y to 16 bits, x2 to 16 bits, statistics
+        // of the rounded x2, two-pass variance (csrc/layernorm.hip)
+        const float sc = E.dp ? E.dp[tokc / E.rows_per_sample] : 1.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c0 = 32 * ct + 16 * s + 8 * h;
+                const bf16x8 xr = *(const bf16x8*)(E.x1 + tokc * C + c0);
+                const float4 ba = *(const float4*)(b2 + c0), bb = *(const float4*)(b2 + c0 + 4);
+                const float bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = (float)(bf16)(yacc[ct][8 * s + e] + bv[e]);
+                    const float x2 = (float)(bf16)((float)xr[e] + sc * y);
+                    yacc[ct][8 * s + e] = x2;
+                    sum += x2;
+                }
+            }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum / (float)C;
+        float qs = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const float d = yacc[ct][q] - mean; qs += d * d; }
+        qs += __shfl_xor(qs, 32);
+        const float rstd = rsqrtf(qs / (float)C + E.eps);
+        if (tok >= T) return;
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c0 = 32 * ct + 16 * s + 8 * h;
+                bf16x8 o1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o1[e] = (bf16)yacc[ct][8 * s + e];
+                *(bf16x8*)(E.x2 + tok * C + c0) = o1;
+                if (E.gamma) {
+                    const float4 g0 = *(const float4*)(E.gamma + c0), g1 = *(const float4*)(E.gamma + c0 + 4);
+                    const float4 t0 = *(const float4*)(E.beta + c0), t1 = *(const float4*)(E.beta + c0 + 4);
+                    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                    const float tt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                    bf16x8 o2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o2[e] = (bf16)((yacc[ct][8 * s + e] - mean) * rstd * gg[e] + tt[e]);
+                    *(bf16x8*)(E.nn + tok * C + c0) = o2;
+                }
+            }
+        if (E.gamma && h == 0) { E.mean[tok] = mean; E.rstd[tok] = rstd; }
+        return;
+    }
     // ---- epilogue: + b2, bf16, two 16-byte stores per channel tile (registers 0..7 = channels 8h.., 8..15 = 16+8h..) ----
     if (tok < T) {
 #pragma unroll
@@ -198,7 +261,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_fwd_kernel(const bf16*
 }
 
 template <int C, int WAVES, int CH, int OCC, int ABL = 0>
-int launch_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t T, hipStream_t s) {
+int launch_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t T, hipStream_t s,
+               MlpEpi epi = MlpEpi{}) {
     using G = TsGeom<C, CH>;
     const size_t lds = 2 * (size_t)(WImg<CH, C>::BYTES + WImg<C, CH>::BYTES) + G::HID * sizeof(float);
     static bool attr_set[16] = {};
@@ -211,7 +275,7 @@ int launch_fwd(const void* x, const void* w1, const float* b1, const void* w2, c
         attr_set[dev] = true;
     }
     const unsigned blocks = (unsigned)((T + WAVES * 32 - 1) / (WAVES * 32));
-    kern<<<blocks, WAVES * 64, lds, s>>>((const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, (bf16*)y, T);
+    kern<<<blocks, WAVES * 64, lds, s>>>((const bf16*)x, (const bf16*)w1, b1, (const bf16*)w2, b2, (bf16*)y, T, epi);
     return swin_launch_status();
 }
 
@@ -376,6 +440,24 @@ extern "C" int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, 
     switch (C) {
         case 96: return launch_bwd<96, 8, 128, 2>(x, dy, w1, b1, w2, dx, h, dhpre, T, s);
         case 192: return launch_bwd<192, 4, 64, 1>(x, dy, w1, b1, w2, dx, h, dhpre, T, s);
+        default: return SWIN_ERR_UNSUPPORTED;
+    }
+}
+
+// swin_mlp_fwd_bf16 with the block's second residual and the next LayerNorm in its epilogue (csrc/ts_mlp.hip, MlpEpi):
+//   x2 (T,C) = x1 + dp[row / rows_per_sample] * Mlp(x);   nn = LayerNorm(x2; gamma, beta, eps), mean / rstd (T) f32 -- gamma NULL:
+//   residual only (nn, mean, rstd unused).  C in {96, 192}.
+extern "C" int swin_mlp_add_ln_fwd_bf16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* x1,
+                                        const float* dp, int64_t rows_per_sample, const float* gamma, const float* beta, void* x2, void* nn,
+                                        float* mean, float* rstd, int64_t T, int C, float eps, void* stream) {
+    if (T == 0) return SWIN_OK;
+    if (!x || !w1 || !b1 || !w2 || !b2 || !x1 || !x2 || T < 0 || rows_per_sample <= 0) return SWIN_ERR_BAD_ARG;
+    if (gamma && (!beta || !nn || !mean || !rstd)) return SWIN_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const MlpEpi epi{(const bf16*)x1, dp, rows_per_sample, gamma, beta, (bf16*)x2, (bf16*)nn, mean, rstd, eps};
+    switch (C) {
+        case 96: return launch_fwd<96, 8, 128, 2>(x, w1, b1, w2, b2, nullptr, T, s, epi);
+        case 192: return launch_fwd<192, 4, 64, 1>(x, w1, b1, w2, b2, nullptr, T, s, epi);
         default: return SWIN_ERR_UNSUPPORTED;
     }
 }

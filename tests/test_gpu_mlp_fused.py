@@ -205,3 +205,50 @@ def test_token_stationary_qkv_and_proj_ln_equal_the_library_chain(C, T):
         same = (x1b == x1a).all(dim=1)
         if bool(same.any()):
             ulp_close(n2b[same], n2a[same], "n2")
+
+
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("T,with_norm", [(1, True), (1000, True), (2 * 25 * 40 + 5, False)])
+def test_fused_mlp_with_residual_and_next_norm_equals_the_two_launch_chain(C, T, with_norm):
+    """swin_mlp_add_ln_fwd_bf16 (the fused MLP with x2 = x1 + dp * y and the next LayerNorm in its epilogue) against
+    swin_mlp_fwd_bf16 followed by swin_add_layernorm_fwd: the MLP arithmetic is the same code, so y and x2 must agree bit for bit;
+    the norm sees another summation order for its statistics (one ulp on isolated outputs)."""
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    H = _lib.half_dtype()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3 * C + T)
+    n2 = torch.randn(T, C, generator=g).to(dev, H)
+    x1 = torch.randn(T, C, generator=g).to(dev, H)
+    w1 = (torch.randn(4 * C, C, generator=g) * C ** -0.5).to(dev, H)
+    w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).to(dev, H)
+    b1 = (torch.randn(4 * C, generator=g) * 0.1).to(dev)
+    b2 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    gamma = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    L = max(T // 2, 1)
+    dp = torch.tensor([1.25, 0.5, 0.0], device=dev)[: (T + L - 1) // L]
+    y = torch.empty(T, C, device=dev, dtype=H)
+    Fn.call("swin_mlp_fwd_bf16", Fn._p(n2), Fn._p(w1), Fn._p(b1), Fn._p(w2), Fn._p(b2), Fn._p(y), T, C, Fn._s())
+    x2a, nna = torch.empty_like(x1), torch.empty_like(x1)
+    ma, ra = torch.empty(T, device=dev), torch.empty(T, device=dev)
+    if with_norm:
+        Fn.call("swin_add_layernorm_fwd", Fn._p(x1), Fn._p(y), Fn._p(dp), L, Fn._p(gamma), Fn._p(beta), Fn._p(x2a), Fn._p(nna), Fn._p(ma), Fn._p(ra),
+                T, C, 1e-5, Fn.SWIN_BF16, Fn._s())
+    else:
+        Fn.call("swin_add_layernorm_fwd", Fn._p(x1), Fn._p(y), Fn._p(dp), L, None, None, Fn._p(x2a), None, None, None, T, C, 1e-5, Fn.SWIN_BF16, Fn._s())
+    x2b, nnb = torch.full_like(x1, float("nan")), torch.full_like(x1, float("nan"))
+    mb, rb = torch.empty(T, device=dev), torch.empty(T, device=dev)
+    Fn.call("swin_mlp_add_ln_fwd_bf16", Fn._p(n2), Fn._p(w1), Fn._p(b1), Fn._p(w2), Fn._p(b2), Fn._p(x1), Fn._p(dp), L,
+            Fn._p(gamma) if with_norm else None, Fn._p(beta) if with_norm else None, Fn._p(x2b), Fn._p(nnb) if with_norm else None,
+            Fn._p(mb) if with_norm else None, Fn._p(rb) if with_norm else None, T, C, 1e-5, Fn._s())
+    torch.cuda.synchronize()
+    assert torch.equal(x2b, x2a)
+    if with_norm:
+        assert float((mb - ma).abs().max()) <= 1e-5 and float(((rb - ra).abs() / ra).max()) <= 1e-5
+        eps16 = 2.0 ** (-10 if H == torch.float16 else -7)
+        d = (nnb.float() - nna.float()).abs()
+        assert float((d > eps16 * (nna.float().abs() + 2.0 ** -6)).float().mean()) == 0.0
+        assert float((d > 0).float().mean()) <= 2e-3
