@@ -81,6 +81,8 @@ extern "C" int swin_block_fwd(const void* const* p, const int64_t* iv, const flo
 //  workspaces: 51 attention backward  52 LayerNorm backward (norm2)  53 LayerNorm backward (next norm)  54 gemm
 //  56 w2t|null: the TRANSPOSED fc2 weight (4C, C) -- with it (and C % 64 == 0, no fused MLP) the fc2 data gradient and the GELU backward are
 //     ONE launch (swin_linear_dgelu_hip_bf16), dh (30) is never written and db1 (43) comes from the dW1 launch
+//  57 wproj^T|null: the TRANSPOSED proj weight (C, C) at the narrow widths -- the proj data gradient then runs on the token-stationary
+//     kernel (swin_ts_linear_bf16)
 //  55 weight-gradient stream (a hipStream_t, or null = `stream`): the four weight-gradient GEMMs are enqueued there, each
 //     after an event recorded on `stream` behind the kernel that produced its dY operand; the caller joins the two
 //     streams before anything reads the accumulators and keeps the operands alive until then.
@@ -157,7 +159,8 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
                            (const float*)p[14], L, (float*)p[46], (float*)p[47], T, C, SWIN_BF16, M(52), stream));
     const void* dy = own_dy ? p[33] : p[26];
     // proj
-    CHK(swin_gemm_bf16(dy, p[17], nullptr, M(34), T, C, C, 1, gws, stream));
+    if (p[57]) CHK(swin_ts_linear_bf16(dy, p[57], nullptr, M(34), T, C, C, 0, stream));       // do = dy Wproj as a Linear with Wproj^T (entry 57)
+    else CHK(swin_gemm_bf16(dy, p[17], nullptr, M(34), T, C, C, 1, gws, stream));
     // window attention
     {   // the per-wave bias-gradient slabs go straight into the (169, nH) table in the block's tail launch
         int n_slabs = 0, slab_stride = 0;

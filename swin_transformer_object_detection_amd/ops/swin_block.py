@@ -397,14 +397,16 @@ class _SwinBlockFn(torch.autograd.Function):
             mixed.side_keep(flat, qkv, n1, dx2, dy2, dnn if has_next else None, ws_attn, ws_ln2, ws_ln3, dbexp, mean2, lse)
             mixed.side_mark(dev)
         w2t = None if getattr(ctx, 'fused_mlp', False) or C % 64 != 0 else mixed.linear_t_weight(m_w2, w2)
-        ptrs = (ctypes.c_void_p * 57)(
+        # narrow stages: the proj data gradient on the token-stationary kernel (csrc/ts_linear.hip) needs the transposed weight
+        wpt = mixed.linear_t_weight(m_wproj, wproj) if C in (96, 128, 192, 256) else None
+        ptrs = (ctypes.c_void_p * 58)(
             _ptr(n1), _ptr(qkv), _ptr(bias_exp), _ptr(lse), _ptr(o), _ptr(x1), _ptr(mean2), _ptr(rstd2), _ptr(n2), _ptr(hpre),
             _ptr(h), _ptr(x2), _ptr(mean3), _ptr(rstd3), _ptr(dp0), _ptr(dp1), _ptr(wqkv), _ptr(wproj), _ptr(w1), _ptr(w2),
             _ptr(n2w), _ptr(nnw) if has_next else None, _ptr(b1), _ptr(qkv_bias), _ptr(dx2), _ptr(dnn) if has_next else None, _ptr(dx),
             _ptr(dn1), _ptr(dx1), _ptr(dy2), _ptr(dh), _ptr(dhpre), _ptr(dn2), _ptr(dy), _ptr(do), _ptr(dqkv), _ptr(dbexp),
             _ptr(a_wqkv), _ptr(a_bqkv), _ptr(a_bpad), _ptr(a_wproj), _ptr(a_bproj), _ptr(a_w1), _ptr(a_b1), _ptr(a_w2), _ptr(a_b2),
             _ptr(a_n2w), _ptr(a_n2b), _ptr(a_nnw), _ptr(a_nnb), _ptr(a_tab), _ptr(ws_attn), _ptr(ws_ln2), _ptr(ws_ln3), _ptr(gws),
-            side.cuda_stream if side is not None else None, _ptr(w2t))
+            side.cuda_stream if side is not None else None, _ptr(w2t), _ptr(wpt))
         iv = (ctypes.c_int64 * 8)(B, H, W, C, nH, shift, 1 if getattr(ctx, 'fused_mlp', False) else 0, 1 if record else 0)
         fv = (ctypes.c_float * 1)(scale)
         call("swin_block_bwd", ptrs, iv, fv, _s())
