@@ -491,6 +491,14 @@ int swin_mlp_bwd_bf16(const void* x, const void* dy, const void* w1, const float
 int swin_mlp_add_ln_fwd_bf16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* x1,
                              const float* dp, int64_t rows_per_sample, const float* gamma, const float* beta, void* x2, void* nn,
                              float* mean, float* rstd, int64_t T, int C, float eps, void* stream);
+/* swin_mlp_bwd_bf16 with the backward of norm2 and of the first residual in its epilogue (swin_transformer.py:252 differentiated):
+ *   dx (T,C) = LayerNorm-backward(dn2; x1, mean, rstd, gamma) + dres (dres NULL: none);  dy = dx * dp[row / rows_per_sample] (dy NULL:
+ *   not wanted; dp NULL: 1);  partials: swin_mlp_ln_bwd_partial_rows(T, C) rows of [dgamma | dbeta] (2 C floats), one per thread
+ *   block -- add them with swin_tail_reduce (kind 0).  dn2 itself is not stored.  h / dhpre as in swin_mlp_bwd_bf16.  C in {96, 192}. */
+int64_t swin_mlp_ln_bwd_partial_rows(int64_t T, int C);
+int swin_mlp_ln_bwd_bf16(const void* x, const void* dy2, const void* w1, const float* b1, const void* w2, void* h, void* dhpre,
+                         const void* x1, const float* mean, const float* rstd, const float* gamma, const void* dres, const float* dp,
+                         int64_t rows_per_sample, void* dx, void* dy, float* partials, int64_t T, int C, void* stream);
 /* Token-stationary Linear layers of the attention branch for C in {96, 128, 192, 256} (csrc/ts_linear.hip; a wave owns 32 tokens):
  *   swin_ts_linear_bf16:      y (T,N) = [relu](x (T,C) w (N,C)^T + bias (N, 16-bit or NULL)), N % 64 == 0  -- the qkv projection
  *                             (swin_transformer.py:129), the FPN laterals of the narrow stages (fpn.py:171-174), the mask head's

@@ -136,6 +136,8 @@ SIGNATURES = {
     "swin_mlp_fwd_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i, _p],
     "swin_mlp_bwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p],
     "swin_mlp_add_ln_fwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _p],
+    "swin_mlp_ln_bwd_partial_rows": [_i64, _i],
+    "swin_mlp_ln_bwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _i, _p],
     "swin_ts_linear_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],
     "swin_ts_proj_add_ln_bf16": [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _p],
     "nms_prepare_workspace_bytes": [_i, _i64],
@@ -149,7 +151,7 @@ SIGNATURES = {
 _RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_gemm_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
             "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64, "det_bn_workspace_bytes": _i64,
             "det_rpn_topk_decode_workspace_bytes": _i64, "nms_prepare_workspace_bytes": _i64,
-            "conv3x3_splitk_workspace_bytes": _i64, "roi_align_gather_workspace_bytes": _i64}
+            "conv3x3_splitk_workspace_bytes": _i64, "roi_align_gather_workspace_bytes": _i64, "swin_mlp_ln_bwd_partial_rows": _i64}
 
 _lib = None
 

@@ -133,8 +133,20 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
         dx1 = p[24];
     }
     const void* hbuf;                          // the hidden activation h the fc2 weight gradient contracts with
+    // dy = the gradient entering the attention branch: dx scaled by DropPath, or dx itself.  With a second stream it is ALWAYS the
+    // private copy (33): dx (26) is handed to autograd, which adds a second gradient into it IN PLACE when x has two consumers
+    // (the first block of a stage: x also feeds norm1) -- while the proj weight gradient would still be reading it on the other
+    // stream (found by test_weight_gradient_stream_gives_the_same_gradients: 30 % error on those four proj.weight gradients).
+    const bool record = iv[7] != 0;
+    const bool own_dy = p[14] || side || record;        // (recorded weight gradients read dy long after dx was handed to autograd)
+    if (!p[46] || !p[47]) return SWIN_ERR_BAD_ARG;
     if (iv[6]) {
-        CHK(swin_mlp_bwd_bf16(p[8], dy2, p[18], (const float*)p[22], p[19], M(32), M(30), M(31), T, C, stream));
+        // fused MLP backward with the backward of norm2 and of the first residual in its epilogue (csrc/ts_mlp.hip): dn2 (32) is never
+        // stored; the block's [dgamma | dbeta] partial rows go to the tail launch
+        CHK(swin_mlp_ln_bwd_bf16(p[8], dy2, p[18], (const float*)p[22], p[19], M(30), M(31), p[5], (const float*)p[6], (const float*)p[7],
+                                 (const float*)p[20], dx1, (const float*)p[14], L, M(26), own_dy ? M(33) : nullptr, (float*)M(52), T, C, stream));
+        swin_tail_push(SwinTailProb{(const float*)p[52], (float*)p[46], (float*)p[47], SWIN_TAIL_COLSUM, (int)swin_mlp_ln_bwd_partial_rows(T, C),
+                                    2 * C, C, 0, 0});
         hbuf = p[30];
     } else {
         // fc2: dh = dy2 w2; GELU; fc1: dn2 = dhpre w1
@@ -147,16 +159,10 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
         CHK(swin_gemm_bf16(p[31], p[18], nullptr, M(32), T, C, 4 * C, 1, gws, stream));
         hbuf = p[10];
     }
-    // first residual + norm2
-    if (!p[46] || !p[47]) return SWIN_ERR_BAD_ARG;
-    // dy = the gradient entering the attention branch: dx scaled by DropPath, or dx itself.  With a second stream it is ALWAYS the
-    // private copy (33): dx (26) is handed to autograd, which adds a second gradient into it IN PLACE when x has two consumers
-    // (the first block of a stage: x also feeds norm1) -- while the proj weight gradient would still be reading it on the other
-    // stream (found by test_weight_gradient_stream_gives_the_same_gradients: 30 % error on those four proj.weight gradients).
-    const bool record = iv[7] != 0;
-    const bool own_dy = p[14] || side || record;        // (recorded weight gradients read dy long after dx was handed to autograd)
-    CHK(swin_layernorm_bwd(p[32], p[5], (const float*)p[20], (const float*)p[6], (const float*)p[7], dx1, M(26), own_dy ? M(33) : nullptr,
-                           (const float*)p[14], L, (float*)p[46], (float*)p[47], T, C, SWIN_BF16, M(52), stream));
+    // first residual + norm2 (already done in the fused MLP's epilogue)
+    if (!iv[6])
+        CHK(swin_layernorm_bwd(p[32], p[5], (const float*)p[20], (const float*)p[6], (const float*)p[7], dx1, M(26), own_dy ? M(33) : nullptr,
+                               (const float*)p[14], L, (float*)p[46], (float*)p[47], T, C, SWIN_BF16, M(52), stream));
     const void* dy = own_dy ? p[33] : p[26];
     // proj
     if (p[57]) CHK(swin_ts_linear_bf16(dy, p[57], nullptr, M(34), T, C, C, 0, stream));       // do = dy Wproj as a Linear with Wproj^T (entry 57)

@@ -286,11 +286,21 @@ int launch_fwd(const void* x, const void* w1, const float* b1, const void* w2, c
 //   dH_t   = W2^T rows (pi) . dYt             A = transposed read of the W2 chunk image [C][CH]
 //   h = gelu(Hpre), dhpre = dH * gelu'(Hpre)  -> both written once, bf16, 16-byte stores (8 contiguous hidden units per lane)
 //   dXt   += W1^T rows (pi) . dhpre           A = transposed read of the W1 chunk image [CH][C]; B = the dhpre accumulators
+// Optional epilogue of the backward kernel (x1 != null): the backward of norm2 and of the first residual (swin_transformer.py:252)
+// on the data gradient dn2 the kernel has just produced, instead of storing dn2 for a separate swin_layernorm_bwd:
+//   xh = (x1 - mean) rstd;  g = dn2 gamma;  dx = rstd (g - mean_c(g) - xh mean_c(g xh)) + dres;  dy = dx * dp[row / rows_per_sample]
+// and the block's partial sums of dgamma = sum_t dn2 xh, dbeta = sum_t dn2 as one row [dgamma | dbeta] of `partials` per thread
+// block (the block runner's tail launch adds the rows).  dn2 is rounded to 16 bits first, as the stored tensor was.
+struct MlpBwdEpi {
+    const bf16* x1; const float* mean; const float* rstd; const float* gamma; const bf16* dres; const float* dp; int64_t rows_per_sample;
+    bf16* dx; bf16* dy; float* partials;
+};
+
 template <int C, int WAVES, int CH, int OCC>
 __global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_bwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY,
                                                                const bf16* __restrict__ W1, const float* __restrict__ b1,
                                                                const bf16* __restrict__ W2, bf16* __restrict__ dX,
-                                                               bf16* __restrict__ Hout, bf16* __restrict__ dHpre, int64_t T) {
+                                                               bf16* __restrict__ Hout, bf16* __restrict__ dHpre, int64_t T, MlpBwdEpi E) {
     using G = TsGeom<C, CH>;
     using I1 = WImg<CH, C>;
     using I2 = WImg<C, CH>;
@@ -371,6 +381,89 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_bwd_kernel(const bf16*
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (E.x1) {
+        // (the weight images are dead: the last chunk's barrier has passed) per-wave reduction scratch: [2 arrays][32 tokens][33] floats
+        float* red = (float*)smem + wave * (2 * 32 * 33);
+        float* wsum = (float*)smem + WAVES * (2 * 32 * 33);               // [WAVES][2 C] column sums of the waves
+        const bool live = tok < T;
+        const float m = E.mean[tokc], rs = E.rstd[tokc];
+        const float sc = E.dp ? E.dp[tokc / E.rows_per_sample] : 1.f;
+        float s1 = 0.f, s2 = 0.f;
+        float colsum[G::CT];
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) {
+            float ag[16], ab[16];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c0 = 32 * ct + 16 * s + 8 * h;
+                const bf16x8 xr = *(const bf16x8*)(E.x1 + tokc * C + c0);
+                const float4 g0 = *(const float4*)(E.gamma + c0), g1 = *(const float4*)(E.gamma + c0 + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = live ? (float)(bf16)xacc[ct][8 * s + e] : 0.f;
+                    const float xh = ((float)xr[e] - m) * rs;
+                    ag[8 * s + e] = d * xh; ab[8 * s + e] = d;
+                    const float g = d * gg[e];
+                    s1 += g; s2 += g * xh;
+                    xacc[ct][8 * s + e] = g;
+                }
+            }
+            // column sums over the wave's 32 tokens of this tile's 32 channels: through LDS (rows padded to 33 floats)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ch = (q < 8 ? 8 * h + q : 16 + 8 * h + (q - 8));
+                red[r * 33 + ch] = ag[q];
+                red[32 * 33 + r * 33 + ch] = ab[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                const float* col = red + (lane >> 5) * (32 * 33) + (lane & 31);      // lanes 0-31: dgamma of channel lane; 32-63: dbeta
+                float a = 0.f;
+#pragma unroll
+                for (int tkn = 0; tkn < 32; ++tkn) a += col[tkn * 33];
+                colsum[ct] = a;
+            }
+            __builtin_amdgcn_wave_barrier();                        // the scratch is rewritten for the next tile
+        }
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);          // the token's other half of every tile lives in lane r ^ 32
+        s1 /= (float)C; s2 /= (float)C;
+        if (live) {
+#pragma unroll
+            for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int c0 = 32 * ct + 16 * s + 8 * h;
+                    const bf16x8 xr = *(const bf16x8*)(E.x1 + tok * C + c0);
+                    bf16x8 rr;
+                    if (E.dres) rr = *(const bf16x8*)(E.dres + tok * C + c0);
+                    bf16x8 o, o2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xh = ((float)xr[e] - m) * rs;
+                        float d = rs * (xacc[ct][8 * s + e] - s1 - xh * s2);
+                        if (E.dres) d += (float)rr[e];
+                        o[e] = (bf16)d;
+                        o2[e] = (bf16)(d * sc);
+                    }
+                    *(bf16x8*)(E.dx + tok * C + c0) = o;
+                    if (E.dy) *(bf16x8*)(E.dy + tok * C + c0) = o2;
+                }
+        }
+        // the block's [dgamma | dbeta] partial row: waves -> LDS -> one row of `partials`
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) wsum[wave * (2 * C) + (lane >> 5) * C + 32 * ct + (lane & 31)] = colsum[ct];
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += NT) {
+            float a = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WAVES; ++w2) a += wsum[w2 * (2 * C) + i];
+            E.partials[(int64_t)blockIdx.x * (2 * C) + i] = a;
+        }
+        return;
+    }
     if (tok < T) {
 #pragma unroll
         for (int ct = 0; ct < G::CT; ++ct) {
@@ -382,7 +475,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_bwd_kernel(const bf16*
 
 template <int C, int WAVES, int CH, int OCC>
 int launch_bwd(const void* x, const void* dy, const void* w1, const float* b1, const void* w2, void* dx, void* hout, void* dhpre,
-               int64_t T, hipStream_t s) {
+               int64_t T, hipStream_t s, MlpBwdEpi epi = MlpBwdEpi{}) {
     using G = TsGeom<C, CH>;
     const size_t lds = 2 * (size_t)(WImg<CH, C>::BYTES + WImg<C, CH>::BYTES) + G::HID * sizeof(float);
     static bool attr_set[16] = {};
@@ -395,8 +488,10 @@ int launch_bwd(const void* x, const void* dy, const void* w1, const float* b1, c
         attr_set[dev] = true;
     }
     const unsigned blocks = (unsigned)((T + WAVES * 32 - 1) / (WAVES * 32));
+    static_assert(2 * (size_t)(WImg<CH, C>::BYTES + WImg<C, CH>::BYTES) >= (size_t)WAVES * (2 * 32 * 33 + 2 * C) * sizeof(float),
+                  "the epilogue's reduction scratch reuses the weight images");
     kern<<<blocks, WAVES * 64, lds, s>>>((const bf16*)x, (const bf16*)dy, (const bf16*)w1, b1, (const bf16*)w2, (bf16*)dx, (bf16*)hout,
-                                         (bf16*)dhpre, T);
+                                         (bf16*)dhpre, T, epi);
     return swin_launch_status();
 }
 
@@ -458,6 +553,31 @@ extern "C" int swin_mlp_add_ln_fwd_bf16(const void* x, const void* w1, const flo
     switch (C) {
         case 96: return launch_fwd<96, 8, 128, 2>(x, w1, b1, w2, b2, nullptr, T, s, epi);
         case 192: return launch_fwd<192, 4, 64, 1>(x, w1, b1, w2, b2, nullptr, T, s, epi);
+        default: return SWIN_ERR_UNSUPPORTED;
+    }
+}
+
+// rows of the `partials` workspace of swin_mlp_ln_bwd_bf16 (one [dgamma | dbeta] row of 2 C floats per thread block)
+extern "C" int64_t swin_mlp_ln_bwd_partial_rows(int64_t T, int C) {
+    if (T <= 0) return 0;
+    return C == 96 ? (T + 255) / 256 : (C == 192 ? (T + 127) / 128 : 0);
+}
+
+// swin_mlp_bwd_bf16 with the backward of norm2 and of the first residual in its epilogue (MlpBwdEpi): dn2 is not stored; instead
+//   dx (T,C) = LayerNorm-backward(dn2; x1, mean, rstd, gamma) + dres,   dy (T,C) = dx * dp[row / rows_per_sample] (dy NULL: not wanted;
+//   dp NULL: scale 1), and `partials` (swin_mlp_ln_bwd_partial_rows(T, C) rows of 2 C floats) receives the per-block sums of
+//   [dgamma | dbeta] -- add the rows (swin_tail_reduce kind 0).  h / dhpre as in swin_mlp_bwd_bf16.  C in {96, 192}.
+extern "C" int swin_mlp_ln_bwd_bf16(const void* x, const void* dy2, const void* w1, const float* b1, const void* w2, void* h, void* dhpre,
+                                    const void* x1, const float* mean, const float* rstd, const float* gamma, const void* dres, const float* dp,
+                                    int64_t rows_per_sample, void* dx, void* dy, float* partials, int64_t T, int C, void* stream) {
+    if (T == 0) return SWIN_OK;
+    if (!x || !dy2 || !w1 || !b1 || !w2 || !h || !dhpre || !x1 || !mean || !rstd || !gamma || !dx || !partials || T < 0 || rows_per_sample <= 0)
+        return SWIN_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const MlpBwdEpi epi{(const bf16*)x1, mean, rstd, gamma, (const bf16*)dres, dp, rows_per_sample, (bf16*)dx, (bf16*)dy, partials};
+    switch (C) {
+        case 96: return launch_bwd<96, 8, 128, 2>(x, dy2, w1, b1, w2, nullptr, h, dhpre, T, s, epi);
+        case 192: return launch_bwd<192, 4, 64, 1>(x, dy2, w1, b1, w2, nullptr, h, dhpre, T, s, epi);
         default: return SWIN_ERR_UNSUPPORTED;
     }
 }

@@ -371,6 +371,8 @@ class _SwinBlockFn(torch.autograd.Function):
         lib = _lib.lib()
         ws_attn = _scratch(dev, 'attn_bwd', lib.swin_window_attn_bwd_workspace_bytes(B, H, W, nH, SWIN_BF16))
         ln_bytes = lib.swin_layernorm_bwd_workspace_bytes(T, C, SWIN_BF16)
+        if getattr(ctx, 'fused_mlp', False):        # norm2's backward runs in the fused MLP's epilogue: one partial row per thread block
+            ln_bytes = max(ln_bytes, lib.swin_mlp_ln_bwd_partial_rows(T, C) * 2 * C * 4)
         ws_ln2 = _scratch(dev, 'ln2', ln_bytes)
         ws_ln3 = _scratch(dev, 'ln3', ln_bytes)
         gws = _scratch(dev, 'gemm', lib.swin_gemm_workspace_bytes())

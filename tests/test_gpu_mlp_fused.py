@@ -252,3 +252,60 @@ def test_fused_mlp_with_residual_and_next_norm_equals_the_two_launch_chain(C, T,
         d = (nnb.float() - nna.float()).abs()
         assert float((d > eps16 * (nna.float().abs() + 2.0 ** -6)).float().mean()) == 0.0
         assert float((d > 0).float().mean()) <= 2e-3
+
+
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("T,with_dres,with_dp", [(1, True, True), (777, True, False), (2 * 25 * 40 + 5, False, True)])
+def test_fused_mlp_backward_with_norm2_backward_equals_the_two_launch_chain(C, T, with_dres, with_dp):
+    """swin_mlp_ln_bwd_bf16 (fused MLP backward with the backward of norm2 and of the first residual in its epilogue) against
+    swin_mlp_bwd_bf16 followed by swin_layernorm_bwd: h / dhpre bit-equal (same code); dx, dy and the [dgamma | dbeta] sums equal up
+    to the summation order of the row statistics / column sums."""
+    import ctypes
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    H = _lib.half_dtype()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5 * C + T)
+    x1 = torch.randn(T, C, generator=g).to(dev, H)
+    gamma = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    n2 = torch.empty_like(x1); mean = torch.empty(T, device=dev); rstd = torch.empty(T, device=dev)
+    Fn.call("swin_layernorm_fwd", Fn._p(x1), Fn._p(gamma), Fn._p(beta), Fn._p(n2), Fn._p(mean), Fn._p(rstd), T, C, 1e-5, Fn.SWIN_BF16, Fn._s())
+    dy2 = (torch.randn(T, C, generator=g) * 0.1).to(dev, H)
+    dres = (torch.randn(T, C, generator=g) * 0.1).to(dev, H) if with_dres else None
+    w1 = (torch.randn(4 * C, C, generator=g) * C ** -0.5).to(dev, H)
+    w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).to(dev, H)
+    b1 = (torch.randn(4 * C, generator=g) * 0.1).to(dev)
+    L = max(T // 2, 1)
+    dp = torch.tensor([1.25, 0.5, 0.0], device=dev)[: (T + L - 1) // L] if with_dp else None
+    # chain
+    dn2 = torch.empty_like(x1); ha = torch.empty(T, 4 * C, device=dev, dtype=H); da = torch.empty_like(ha)
+    Fn.call("swin_mlp_bwd_bf16", Fn._p(n2), Fn._p(dy2), Fn._p(w1), Fn._p(b1), Fn._p(w2), Fn._p(dn2), Fn._p(ha), Fn._p(da), T, C, Fn._s())
+    dxa = torch.empty_like(x1); dya = torch.empty_like(x1)
+    dga, dba = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ws = Fn._ln_ws(T, C, x1)
+    Fn.call("swin_layernorm_bwd", Fn._p(dn2), Fn._p(x1), Fn._p(gamma), Fn._p(mean), Fn._p(rstd), Fn._p(dres), Fn._p(dxa), Fn._p(dya), Fn._p(dp), L,
+            Fn._p(dga), Fn._p(dba), T, C, Fn.SWIN_BF16, Fn._p(ws), Fn._s())
+    # fused
+    rows = int(_lib.lib().swin_mlp_ln_bwd_partial_rows(T, C))
+    assert rows >= 1
+    part = torch.full((rows, 2 * C), float("nan"), device=dev)
+    hb = torch.full_like(ha, float("nan")); db_ = torch.full_like(ha, float("nan"))
+    dxb = torch.full_like(x1, float("nan")); dyb = torch.full_like(x1, float("nan"))
+    Fn.call("swin_mlp_ln_bwd_bf16", Fn._p(n2), Fn._p(dy2), Fn._p(w1), Fn._p(b1), Fn._p(w2), Fn._p(hb), Fn._p(db_), Fn._p(x1), Fn._p(mean), Fn._p(rstd),
+            Fn._p(gamma), Fn._p(dres), Fn._p(dp), L, Fn._p(dxb), Fn._p(dyb), Fn._p(part), T, C, Fn._s())
+    torch.cuda.synchronize()
+    assert torch.equal(hb, ha) and torch.equal(db_, da)
+    eps16 = 2.0 ** (-10 if H == torch.float16 else -7)
+    for a, b, nm in ((dxb, dxa, "dx"), (dyb, dya, "dy")):
+        assert bool(torch.isfinite(a.float()).all()), nm
+        d = (a.float() - b.float()).abs()
+        tol = eps16 * (b.float().abs() + 1.25 * dn2.float().abs().amax(dim=1, keepdim=True) * 0.25 + 2.0 ** -8)
+        assert float((d > tol).float().mean()) == 0.0, (nm, float(d.max()))
+        assert float((d > 0).float().mean()) <= 5e-3, nm
+    sums = part.sum(0)
+    scale = float(torch.maximum(dga.abs().max(), dba.abs().max())) + 1e-6
+    assert float((sums[:C] - dga).abs().max()) <= 2e-4 * scale + 1e-5
+    assert float((sums[C:] - dba).abs().max()) <= 2e-4 * scale + 1e-5
