@@ -499,6 +499,15 @@ int64_t swin_mlp_ln_bwd_partial_rows(int64_t T, int C);
 int swin_mlp_ln_bwd_bf16(const void* x, const void* dy2, const void* w1, const float* b1, const void* w2, void* h, void* dhpre,
                          const void* x1, const float* mean, const float* rstd, const float* gamma, const void* dres, const float* dp,
                          int64_t rows_per_sample, void* dx, void* dy, float* partials, int64_t T, int C, void* stream);
+/* ... and with the backward of the block's NEXT norm and second residual as its prologue: the MLP half of a block's backward in one
+ * launch.  dx1 (T,C) = LayerNorm-backward(dnn; x2, mean3, rstd3, gamma3) + dres3 is written (and consumed by the epilogue as its
+ * residual gradient); dy2 = dx1 * dp1[...] is written when dp1 != NULL (the fc2 weight gradient's operand; else it equals dx1);
+ * partials3: [dgamma3 | dbeta3] rows like `partials`. */
+int swin_mlp_ln2_bwd_bf16(const void* x, const void* w1, const float* b1, const void* w2, void* h, void* dhpre, const void* x1,
+                          const float* mean, const float* rstd, const float* gamma, const float* dp, int64_t rows_per_sample, void* dx,
+                          void* dy, float* partials, const void* dnn, const void* x2, const float* mean3, const float* rstd3,
+                          const float* gamma3, const void* dres3, const float* dp1, void* dx1, void* dy2, float* partials3, int64_t T,
+                          int C, void* stream);
 /* Token-stationary Linear layers of the attention branch for C in {96, 128, 192, 256} (csrc/ts_linear.hip; a wave owns 32 tokens):
  *   swin_ts_linear_bf16:      y (T,N) = [relu](x (T,C) w (N,C)^T + bias (N, 16-bit or NULL)), N % 64 == 0  -- the qkv projection
  *                             (swin_transformer.py:129), the FPN laterals of the narrow stages (fpn.py:171-174), the mask head's

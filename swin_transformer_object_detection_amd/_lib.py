@@ -138,6 +138,7 @@ SIGNATURES = {
     "swin_mlp_add_ln_fwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _p],
     "swin_mlp_ln_bwd_partial_rows": [_i64, _i],
     "swin_mlp_ln_bwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _i, _p],
+    "swin_mlp_ln2_bwd_bf16": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p],
     "swin_ts_linear_bf16": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],
     "swin_ts_proj_add_ln_bf16": [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _p],
     "nms_prepare_workspace_bytes": [_i, _i64],

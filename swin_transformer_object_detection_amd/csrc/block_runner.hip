@@ -122,11 +122,14 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     const bool gelu_epi = !iv[6] && p[56] && C % 64 == 0;
     const bool db1_from_wgrad = iv[6] || gelu_epi;
     if ((p[45] && !p[44]) || (p[43] && db1_from_wgrad && !p[42]) || (p[41] && !p[40]) || (p[38] && !p[37])) return SWIN_ERR_UNSUPPORTED;
+    // fused MLP and a next norm: the backward of that norm and of the second residual is the PROLOGUE of the fused MLP backward
+    const bool mlp_half_fused = iv[6] && p[21];
     if (p[21]) {                              // second residual + next norm
         if (!p[25] || !p[48] || !p[49]) return SWIN_ERR_BAD_ARG;
-        CHK(swin_layernorm_bwd(p[25], p[11], (const float*)p[21], (const float*)p[12], (const float*)p[13], p[24], M(28),
-                               p[15] ? M(29) : nullptr, (const float*)p[15], L, (float*)p[48], (float*)p[49], T, C, SWIN_BF16, M(53),
-                               stream));
+        if (!mlp_half_fused)
+            CHK(swin_layernorm_bwd(p[25], p[11], (const float*)p[21], (const float*)p[12], (const float*)p[13], p[24], M(28),
+                                   p[15] ? M(29) : nullptr, (const float*)p[15], L, (float*)p[48], (float*)p[49], T, C, SWIN_BF16, M(53),
+                                   stream));
         if (!p[15]) dy2 = p[28];
     } else {
         if (!p[24]) return SWIN_ERR_BAD_ARG;
@@ -140,7 +143,18 @@ extern "C" int swin_block_bwd(const void* const* p, const int64_t* iv, const flo
     const bool record = iv[7] != 0;
     const bool own_dy = p[14] || side || record;        // (recorded weight gradients read dy long after dx was handed to autograd)
     if (!p[46] || !p[47]) return SWIN_ERR_BAD_ARG;
-    if (iv[6]) {
+    if (mlp_half_fused) {
+        // next-norm backward -> fused MLP backward -> norm2 backward: ONE launch (csrc/ts_mlp.hip); dx1 (28), dy2 (29, with DropPath) and the
+        // two sets of [dgamma | dbeta] partial rows (52: norm2, 53: next norm) are its only outputs besides dx / dy / h / dhpre
+        const int rows = (int)swin_mlp_ln_bwd_partial_rows(T, C);
+        CHK(swin_mlp_ln2_bwd_bf16(p[8], p[18], (const float*)p[22], p[19], M(30), M(31), p[5], (const float*)p[6], (const float*)p[7],
+                                  (const float*)p[20], (const float*)p[14], L, M(26), own_dy ? M(33) : nullptr, (float*)M(52), p[25], p[11],
+                                  (const float*)p[12], (const float*)p[13], (const float*)p[21], p[24], (const float*)p[15], M(28), M(29),
+                                  (float*)M(53), T, C, stream));
+        swin_tail_push(SwinTailProb{(const float*)p[53], (float*)p[48], (float*)p[49], SWIN_TAIL_COLSUM, rows, 2 * C, C, 0, 0});
+        swin_tail_push(SwinTailProb{(const float*)p[52], (float*)p[46], (float*)p[47], SWIN_TAIL_COLSUM, rows, 2 * C, C, 0, 0});
+        hbuf = p[30];
+    } else if (iv[6]) {
         // fused MLP backward with the backward of norm2 and of the first residual in its epilogue (csrc/ts_mlp.hip): dn2 (32) is never
         // stored; the block's [dgamma | dbeta] partial rows go to the tail launch
         CHK(swin_mlp_ln_bwd_bf16(p[8], dy2, p[18], (const float*)p[22], p[19], M(30), M(31), p[5], (const float*)p[6], (const float*)p[7],

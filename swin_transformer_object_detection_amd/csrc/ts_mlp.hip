@@ -294,6 +294,13 @@ int launch_fwd(const void* x, const void* w1, const float* b1, const void* w2, c
 struct MlpBwdEpi {
     const bf16* x1; const float* mean; const float* rstd; const float* gamma; const bf16* dres; const float* dp; int64_t rows_per_sample;
     bf16* dx; bf16* dy; float* partials;
+    // Optional PROLOGUE (p_dnn != null): the backward of the block's NEXT norm and of its second residual (swin_transformer.py:253 and
+    // the following :211) produces the kernel's dY operand instead of reading it:
+    //   dx1 = LayerNorm-backward(dnn; x2, mean3, rstd3, gamma3) + dres3;   dY = dx1 * dp1[row / rows_per_sample]
+    // dx1 is stored (p_dx1: it is `dres` of the epilogue), dY is stored when it differs from dx1 (p_dy2 != null: the fc2 weight
+    // gradient reads it), and the block's [dgamma3 | dbeta3] partial row goes to p_partials.
+    const bf16* p_dnn; const bf16* p_x2; const float* p_mean; const float* p_rstd; const float* p_gamma; const bf16* p_dres;
+    const float* p_dp; bf16* p_dx1; bf16* p_dy2; float* p_partials;
 };
 
 template <int C, int WAVES, int CH, int OCC>
@@ -316,13 +323,91 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void ts_mlp_bwd_kernel(const bf16*
         dma_image<CH, C, WAVES>(W1 + (int64_t)j * CH * C, C, smem + buf * BUF, wave, lane);
         dma_image<C, CH, WAVES>(W2 + (int64_t)j * CH, G::HID, smem + buf * BUF + I1::BYTES, wave, lane);
     };
+    bf16x8 xf[G::KS], df[G::KS];
+    if (E.p_dnn) {
+        // ---- prologue (before the first weight DMA: the reduction scratch below is the weight images' LDS)
+        // A lane's fragment pieces are channels 16 s + 8 h .. + 7 of its token, s = 0 .. KS - 1: half of the row, the other half in lane
+        // r ^ 32 -- the same split as the accumulator layout of the epilogue (channel tile ct, half s' <-> s = 2 ct + s').
+        float* red = (float*)smem + wave * (2 * 32 * 33);
+        float* wsum = (float*)smem + WAVES * (2 * 32 * 33);
+        const bool live = tok < T;
+        const float m3 = E.p_mean[tokc], rs3 = E.p_rstd[tokc];
+        const float sc1 = E.p_dp ? E.p_dp[tokc / E.rows_per_sample] : 1.f;
+        float g[G::KS][8];
+        float s1 = 0.f, s2 = 0.f;
+        float colsum[G::CT];
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const int s = 2 * ct + sp, c0 = 16 * s + 8 * h;
+                const bf16x8 dn = *(const bf16x8*)(E.p_dnn + tokc * C + c0);
+                const bf16x8 xr = *(const bf16x8*)(E.p_x2 + tokc * C + c0);
+                const float4 g0 = *(const float4*)(E.p_gamma + c0), g1 = *(const float4*)(E.p_gamma + c0 + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = live ? (float)dn[e] : 0.f;
+                    const float xh = ((float)xr[e] - m3) * rs3;
+                    const float gv = d * gg[e];
+                    s1 += gv; s2 += gv * xh;
+                    g[s][e] = gv;
+                    red[r * 33 + 16 * sp + 8 * h + e] = d * xh;
+                    red[32 * 33 + r * 33 + 16 * sp + 8 * h + e] = d;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                const float* col = red + (lane >> 5) * (32 * 33) + (lane & 31);
+                float a = 0.f;
+#pragma unroll
+                for (int tkn = 0; tkn < 32; ++tkn) a += col[tkn * 33];
+                colsum[ct] = a;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        s1 /= (float)C; s2 /= (float)C;
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+            const int c0 = 16 * s + 8 * h;
+            const bf16x8 xr = *(const bf16x8*)(E.p_x2 + tokc * C + c0);
+            bf16x8 rr;
+            if (E.p_dres) rr = *(const bf16x8*)(E.p_dres + tokc * C + c0);
+            bf16x8 o, o2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = ((float)xr[e] - m3) * rs3;
+                float d = rs3 * (g[s][e] - s1 - xh * s2);
+                if (E.p_dres) d += (float)rr[e];
+                o[e] = (bf16)d;
+                o2[e] = (bf16)(d * sc1);
+            }
+            if (live) {
+                *(bf16x8*)(E.p_dx1 + tok * C + c0) = o;
+                if (E.p_dy2) *(bf16x8*)(E.p_dy2 + tok * C + c0) = o2;
+            }
+            df[s] = o2;
+        }
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) wsum[wave * (2 * C) + (lane >> 5) * C + 32 * ct + (lane & 31)] = colsum[ct];
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += NT) {
+            float a = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WAVES; ++w2) a += wsum[w2 * (2 * C) + i];
+            E.p_partials[(int64_t)blockIdx.x * (2 * C) + i] = a;
+        }
+        __syncthreads();                                            // the scratch becomes the weight images
+    }
     stage(0, 0);
     for (int i = tid; i < G::HID; i += NT) b1s[i] = b1[i];
-    bf16x8 xf[G::KS], df[G::KS];
 #pragma unroll
     for (int s = 0; s < G::KS; ++s) {
         xf[s] = *(const bf16x8*)(X + tokc * C + 16 * s + 8 * h);
-        df[s] = *(const bf16x8*)(dY + tokc * C + 16 * s + 8 * h);
+        if (!E.p_dnn) df[s] = *(const bf16x8*)(dY + tokc * C + 16 * s + 8 * h);
     }
     f32x16 xacc[G::CT];
 #pragma unroll
@@ -574,10 +659,35 @@ extern "C" int swin_mlp_ln_bwd_bf16(const void* x, const void* dy2, const void* 
     if (!x || !dy2 || !w1 || !b1 || !w2 || !h || !dhpre || !x1 || !mean || !rstd || !gamma || !dx || !partials || T < 0 || rows_per_sample <= 0)
         return SWIN_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const MlpBwdEpi epi{(const bf16*)x1, mean, rstd, gamma, (const bf16*)dres, dp, rows_per_sample, (bf16*)dx, (bf16*)dy, partials};
+    const MlpBwdEpi epi{(const bf16*)x1, mean, rstd, gamma, (const bf16*)dres, dp, rows_per_sample, (bf16*)dx, (bf16*)dy, partials,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     switch (C) {
         case 96: return launch_bwd<96, 8, 128, 2>(x, dy2, w1, b1, w2, nullptr, h, dhpre, T, s, epi);
         case 192: return launch_bwd<192, 4, 64, 1>(x, dy2, w1, b1, w2, nullptr, h, dhpre, T, s, epi);
+        default: return SWIN_ERR_UNSUPPORTED;
+    }
+}
+
+// swin_mlp_ln_bwd_bf16 with, in addition, the backward of the block's NEXT norm and second residual as its PROLOGUE (MlpBwdEpi p_*): the
+// MLP half of a Swin block's backward in ONE launch.  dnn: gradient of the next norm's output; x2 / mean3 / rstd3 / gamma3: that norm's
+// saved input, statistics and weight; dres3: gradient of the residual stream behind it (NULL: none); dp1: the second DropPath scale (NULL: 1).
+// Writes dx1 (T,C) (and reads it back as the epilogue's residual gradient), dy2 (T,C) when dp1 != NULL (the fc2 weight gradient's
+// operand; with dp1 NULL it equals dx1), partials3: swin_mlp_ln_bwd_partial_rows(T, C) rows of [dgamma3 | dbeta3].
+extern "C" int swin_mlp_ln2_bwd_bf16(const void* x, const void* w1, const float* b1, const void* w2, void* h, void* dhpre, const void* x1,
+                                     const float* mean, const float* rstd, const float* gamma, const float* dp, int64_t rows_per_sample, void* dx,
+                                     void* dy, float* partials, const void* dnn, const void* x2, const float* mean3, const float* rstd3,
+                                     const float* gamma3, const void* dres3, const float* dp1, void* dx1, void* dy2, float* partials3, int64_t T,
+                                     int C, void* stream) {
+    if (T == 0) return SWIN_OK;
+    if (!x || !w1 || !b1 || !w2 || !h || !dhpre || !x1 || !mean || !rstd || !gamma || !dx || !partials || !dnn || !x2 || !mean3 || !rstd3 || !gamma3 ||
+        !dx1 || !partials3 || (dp1 && !dy2) || T < 0 || rows_per_sample <= 0)
+        return SWIN_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const MlpBwdEpi epi{(const bf16*)x1, mean, rstd, gamma, (const bf16*)dx1, dp, rows_per_sample, (bf16*)dx, (bf16*)dy, partials,
+                        (const bf16*)dnn, (const bf16*)x2, mean3, rstd3, gamma3, (const bf16*)dres3, dp1, (bf16*)dx1, dp1 ? (bf16*)dy2 : nullptr, partials3};
+    switch (C) {
+        case 96: return launch_bwd<96, 8, 128, 2>(x, nullptr, w1, b1, w2, nullptr, h, dhpre, T, s, epi);
+        case 192: return launch_bwd<192, 4, 64, 1>(x, nullptr, w1, b1, w2, nullptr, h, dhpre, T, s, epi);
         default: return SWIN_ERR_UNSUPPORTED;
     }
 }

@@ -309,3 +309,80 @@ def test_fused_mlp_backward_with_norm2_backward_equals_the_two_launch_chain(C, T
     scale = float(torch.maximum(dga.abs().max(), dba.abs().max())) + 1e-6
     assert float((sums[:C] - dga).abs().max()) <= 2e-4 * scale + 1e-5
     assert float((sums[C:] - dba).abs().max()) <= 2e-4 * scale + 1e-5
+
+
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("T,with_dres,with_dp", [(1, True, True), (777, False, False), (2 * 25 * 40 + 5, True, True)])
+def test_mlp_half_of_the_block_backward_in_one_launch_equals_the_three_launch_chain(C, T, with_dres, with_dp):
+    """swin_mlp_ln2_bwd_bf16 (next-norm backward as prologue, fused MLP backward, norm2 backward as epilogue) against
+    swin_layernorm_bwd -> swin_mlp_bwd_bf16 -> swin_layernorm_bwd."""
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    H = _lib.half_dtype()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(7 * C + T)
+    x1 = torch.randn(T, C, generator=g).to(dev, H)
+    x2 = torch.randn(T, C, generator=g).to(dev, H)
+    g2 = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev); b2n = (0.1 * torch.randn(C, generator=g)).to(dev)
+    g3 = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev); b3n = (0.1 * torch.randn(C, generator=g)).to(dev)
+    n2 = torch.empty_like(x1); m2 = torch.empty(T, device=dev); r2 = torch.empty(T, device=dev)
+    nn = torch.empty_like(x1); m3 = torch.empty(T, device=dev); r3 = torch.empty(T, device=dev)
+    Fn.call("swin_layernorm_fwd", Fn._p(x1), Fn._p(g2), Fn._p(b2n), Fn._p(n2), Fn._p(m2), Fn._p(r2), T, C, 1e-5, Fn.SWIN_BF16, Fn._s())
+    Fn.call("swin_layernorm_fwd", Fn._p(x2), Fn._p(g3), Fn._p(b3n), Fn._p(nn), Fn._p(m3), Fn._p(r3), T, C, 1e-5, Fn.SWIN_BF16, Fn._s())
+    dnn = (torch.randn(T, C, generator=g) * 0.1).to(dev, H)
+    dres3 = (torch.randn(T, C, generator=g) * 0.1).to(dev, H) if with_dres else None
+    w1 = (torch.randn(4 * C, C, generator=g) * C ** -0.5).to(dev, H)
+    w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).to(dev, H)
+    b1 = (torch.randn(4 * C, generator=g) * 0.1).to(dev)
+    L = max(T // 2, 1)
+    ns = (T + L - 1) // L
+    dp0 = torch.tensor([1.25, 0.5, 0.0], device=dev)[:ns] if with_dp else None
+    dp1 = torch.tensor([0.8, 1.25, 1.0], device=dev)[:ns] if with_dp else None
+    ws = Fn._ln_ws(T, C, x1)
+    # chain
+    dx1a = torch.empty_like(x1); dy2a = torch.empty_like(x1)
+    dg3a, db3a = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    Fn.call("swin_layernorm_bwd", Fn._p(dnn), Fn._p(x2), Fn._p(g3), Fn._p(m3), Fn._p(r3), Fn._p(dres3), Fn._p(dx1a), Fn._p(dy2a) if with_dp else None,
+            Fn._p(dp1), L, Fn._p(dg3a), Fn._p(db3a), T, C, Fn.SWIN_BF16, Fn._p(ws), Fn._s())
+    torch.cuda.synchronize()
+    dy2_in = dy2a if with_dp else dx1a
+    dn2 = torch.empty_like(x1); ha = torch.empty(T, 4 * C, device=dev, dtype=H); da = torch.empty_like(ha)
+    Fn.call("swin_mlp_bwd_bf16", Fn._p(n2), Fn._p(dy2_in), Fn._p(w1), Fn._p(b1), Fn._p(w2), Fn._p(dn2), Fn._p(ha), Fn._p(da), T, C, Fn._s())
+    dxa = torch.empty_like(x1); dya = torch.empty_like(x1)
+    dg2a, db2a = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ws2 = Fn._ln_ws(T, C, x1)
+    Fn.call("swin_layernorm_bwd", Fn._p(dn2), Fn._p(x1), Fn._p(g2), Fn._p(m2), Fn._p(r2), Fn._p(dx1a), Fn._p(dxa), Fn._p(dya), Fn._p(dp0), L,
+            Fn._p(dg2a), Fn._p(db2a), T, C, Fn.SWIN_BF16, Fn._p(ws2), Fn._s())
+    # one launch
+    rows = int(_lib.lib().swin_mlp_ln_bwd_partial_rows(T, C))
+    p2 = torch.full((rows, 2 * C), float("nan"), device=dev); p3 = torch.full((rows, 2 * C), float("nan"), device=dev)
+    hb = torch.full_like(ha, float("nan")); db_ = torch.full_like(ha, float("nan"))
+    dxb = torch.full_like(x1, float("nan")); dyb = torch.full_like(x1, float("nan"))
+    dx1b = torch.full_like(x1, float("nan")); dy2b = torch.full_like(x1, float("nan"))
+    Fn.call("swin_mlp_ln2_bwd_bf16", Fn._p(n2), Fn._p(w1), Fn._p(b1), Fn._p(w2), Fn._p(hb), Fn._p(db_), Fn._p(x1), Fn._p(m2), Fn._p(r2), Fn._p(g2),
+            Fn._p(dp0), L, Fn._p(dxb), Fn._p(dyb), Fn._p(p2), Fn._p(dnn), Fn._p(x2), Fn._p(m3), Fn._p(r3), Fn._p(g3), Fn._p(dres3), Fn._p(dp1),
+            Fn._p(dx1b), Fn._p(dy2b), Fn._p(p3), T, C, Fn._s())
+    torch.cuda.synchronize()
+    eps16 = 2.0 ** (-10 if H == torch.float16 else -7)
+
+    def near(a, b, ref_scale, nm, frac=2e-2):
+        assert bool(torch.isfinite(a.float()).all()), nm
+        d = (a.float() - b.float()).abs()
+        tol = 2 * eps16 * (b.float().abs() + ref_scale + 2.0 ** -8)
+        assert float((d > tol).float().mean()) == 0.0, (nm, float(d.max()))
+        assert float((d > 0).float().mean()) <= frac, (nm, float((d > 0).float().mean()))
+    rs = float(dnn.float().abs().max())
+    near(dx1b, dx1a, 0.25 * rs, "dx1", 5e-3)
+    if with_dp:
+        near(dy2b, dy2a, 0.25 * rs, "dy2", 5e-3)
+    # downstream of dx1 / dy2, one-ulp differences there travel through the MLP: compare in the L2 norm
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-20))     # noqa: E731
+    assert rel(hb, ha) == 0.0                                   # h depends on n2 only
+    assert rel(db_, da) <= 5e-3 and rel(dxb, dxa) <= 5e-3 and rel(dyb, dya) <= 5e-3
+    for part, dgr, dbr in ((p3, dg3a, db3a), (p2, dg2a, db2a)):
+        sums = part.sum(0)
+        scale = float(torch.maximum(dgr.abs().max(), dbr.abs().max())) + 1e-6
+        assert float((sums[:C] - dgr).abs().max()) <= 5e-3 * scale + 1e-5
+        assert float((sums[C:] - dbr).abs().max()) <= 5e-3 * scale + 1e-5
