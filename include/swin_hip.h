@@ -196,6 +196,14 @@ int wgrad_conv3x3_nhwc_bf16(const void* dy, const void* x, float* dw, float* dbi
 int swin_wgrad_record(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2);
 int swin_wgrad_pending(int64_t* tiles);
 int swin_wgrad_flush(void* stream);
+/* The grouped launch for layers whose dimensions are multiples of 96 (csrc/wgrad96.hip; swin_wgrad_flush routes to it): n <= 32
+ * problems, N1 % 96 == 0 and N2 % 96 == 0 -- qkv / proj / fc1 / fc2 / PatchMerging.reduction of Swin-T and Swin-S at every stage.
+ * A wave owns a 96 x 96 piece of dW, a block a tile of up to 384 x 192; the launch's (problem, cluster of <= 8 tiles, stage) sequence
+ * is cut into equal ranges, one per group of eight blocks that walk a cluster's tiles in step on one XCD.
+ * dy / x / dw / db / T / N1 / N2: host arrays of n entries (db or db[i] NULL = no bias gradient).
+ * SWIN_ERR_UNSUPPORTED for any other shape.  Outputs ACCUMULATE. */
+int swin_wgrad96_group(const void* const* dy, const void* const* x, float* const* dw, float* const* db, const int64_t* T,
+                       const int* N1, const int* N2, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * mmcv.ops.RoIAlign / roi_align ('avg', aligned flag) -- call sites

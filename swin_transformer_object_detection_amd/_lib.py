@@ -76,6 +76,7 @@ SIGNATURES = {
     "swin_wgrad_record": [_p, _p, _p, _p, _i64, _i, _i],
     "swin_wgrad_pending": [_p],
     "swin_wgrad_flush": [_p],
+    "swin_wgrad96_group": [_p, _p, _p, _p, _p, _p, _p, _i, _p],
     "swin_nms_workspace_bytes": [_i64],
     "nms_sorted": [_p, _i64, _f, _i, _i, _p, _p, _p, _i, _p, _p],
     "nms_sorted_batch": [_p, _i, _i64, _f, _i, _i, _p, _p, _p, _i, _p, _p],

@@ -19,6 +19,7 @@
 // activation for a 3x3 / pad 1 convolution (fpn.py:195-197, rpn_head.py:43, fcn_mask_head.py:119-121) with Cin % 128 == 0, so
 // that a 128-column tile lies inside ONE filter tap: the tap's pixel offset is block-uniform and the border test is per row.
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 #include "common.h"
@@ -678,6 +679,12 @@ int launch_group(const Pending* pp, int n, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int wgrad_linear_bf16(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2, void* stream);
+// csrc/wgrad96.hip
+int wgrad96_class(int64_t T, int N1, int N2);
+int wgrad96_launch(const void* const* dy, const void* const* x, float* const* dw, float* const* db, const int64_t* T, const int* N1,
+                   const int* N2, int n, int blocks, hipStream_t s);
+
 // Called by the C ABI entry points of csrc/wgrad_gemm.hip; SWIN_ERR_UNSUPPORTED = not this kernel's shape (the caller falls
 // back to the register-staged kernel).
 int wgrad2_linear(const void* dy, const void* x, float* dw, float* dbias, int64_t T, int N1, int N2, void* stream) {
@@ -723,13 +730,51 @@ extern "C" int swin_wgrad_pending(int64_t* tiles) {
 extern "C" int swin_wgrad_flush(void* stream) {
     const int dev = cur_device();
     if (dev < 0) return SWIN_ERR_UNSUPPORTED;
-    std::vector<Pending>& v = g_pending[dev];
+    std::vector<Pending>& all = g_pending[dev];
     int rc = SWIN_OK;
+#ifdef SWIN_DEV
+    if (swin_dev_int("SWIN_WGRAD_DUMP", 0)) {
+        fprintf(stderr, "wgrad flush: %zu problems\n", all.size());
+        for (const Pending& q : all) fprintf(stderr, "  T=%lld N1=%d N2=%d db=%d narrow=%d\n", (long long)q.T, q.N1, q.N2, q.db != nullptr, wgrad96_class(q.T, q.N1, q.N2));
+    }
+#endif
+    // layers whose dimensions are multiples of 96 (Swin-T / Swin-S, every stage) go to csrc/wgrad96.hip, up to 32 problems per launch
+    std::vector<Pending> v, nar;
+    // (t >= 4096: at stage 4, t = 2000, the 128-tile form owns whole tiles with plain read-modify-write epilogues -- measured equal
+    // alone and better next to the FPN laterals that share its launch)
+    for (const Pending& q : all)
+        (q.T >= swin_dev_int("SWIN_WGRAD96_MIN_T", 4096) && wgrad96_class(q.T, q.N1, q.N2) >= 0 && swin_dev_int("SWIN_WGRAD96", 1) ? nar : v).push_back(q);
+    if (!nar.empty() && v.size() <= 2) {                         // a straggler or two of the other form (PatchMerging at t = 2000) ride along
+        bool ok = true;
+        for (const Pending& q : v) ok = ok && wgrad96_class(q.T, q.N1, q.N2) >= 0;
+        if (ok) { nar.insert(nar.end(), v.begin(), v.end()); v.clear(); }
+    }
+    for (size_t i = 0; i < nar.size(); i += 32) {
+        const int n = (int)std::min((size_t)32, nar.size() - i);
+        const void* dy[32]; const void* x[32]; float* dw[32]; float* db[32]; int64_t T[32]; int N1[32], N2[32];
+        for (int k = 0; k < n; ++k) {
+            const Pending& q = nar[i + k];
+            dy[k] = q.dy; x[k] = q.x; dw[k] = q.dw; db[k] = q.db; T[k] = q.T; N1[k] = q.N1; N2[k] = q.N2;
+        }
+        const int st = wgrad96_launch(dy, x, dw, db, T, N1, N2, n, swin_dev_int("SWIN_WGRAD96_BLOCKS", 0), (hipStream_t)stream);
+        if (st != SWIN_OK && rc == SWIN_OK) rc = st;
+    }
+    // One or two problems of a few tiles left on their own (the patch embedding's 96 x 48 once the backbone's layers went the other
+    // way): the grouped launch would cut each into hundreds of splits -- the single-problem entry streams them.
+    int64_t left_tiles = 0;
+    for (const Pending& q : v) left_tiles += (int64_t)((q.N1 + TN - 1) / TN) * ((q.N2 + TN - 1) / TN);
+    if (!v.empty() && v.size() <= 2 && left_tiles <= 8) {
+        for (const Pending& q : v) {
+            const int st = wgrad_linear_bf16(q.dy, q.x, q.dw, q.db, q.T, q.N1, q.N2, stream);
+            if (st != SWIN_OK && rc == SWIN_OK) rc = st;
+        }
+        v.clear();
+    }
     for (size_t i = 0; i < v.size(); i += GMAX) {
         const int n = (int)std::min((size_t)GMAX, v.size() - i);
         const int st = launch_group(v.data() + i, n, (hipStream_t)stream);
         if (st != SWIN_OK && rc == SWIN_OK) rc = st;
     }
-    v.clear();
+    all.clear();
     return rc;
 }

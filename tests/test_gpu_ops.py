@@ -471,6 +471,73 @@ def test_linear_wgrad_grouped_launch(ops):
             assert float((db - rb).abs().max()) <= 2e-3 * float(rb.abs().max()) + 1e-3, tuple(dw.shape)
 
 
+def test_linear_wgrad96_group(ops):
+    """swin_wgrad96_group (csrc/wgrad96.hip): every tile class of the Linear layers whose dimensions are multiples of 96 -- qkv / proj /
+    fc1 / fc2 at C = 96 ... 768, PatchMerging.reduction -- in ONE launch: equal ranges of the work sequence per group of blocks (tile
+    segments that start and end mid-contraction, several segments per block, clusters of 1 / 2 / 6 / 8 / 24 / 32 tiles); token counts that are not multiples of the stage rows, accumulation INTO non-zero buffers, one problem without bias gradient, two
+    problems adding into the same dW.  Then the same problems through swin_wgrad_record / swin_wgrad_flush (which routes them here)
+    next to a shape of the 128-tile form.  Against fp32 matmuls."""
+    import ctypes
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops.functional import _p, _s, call
+    shapes = [(20011, 288, 96), (16400, 96, 96), (17000, 384, 96), (16999, 96, 384), (16384, 576, 192), (18001, 192, 192),
+              (16500, 768, 192), (16500, 192, 768), (16390, 192, 384), (2000, 1536, 384), (1999, 384, 1536), (2001, 1152, 384),
+              (500, 2304, 768), (777, 768, 3072), (130, 480, 96), (33, 96, 672), (40000, 96, 96)]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    probs, refs = [], []
+    for k, (T, N1, N2) in enumerate(shapes):
+        dy = (torch.randn(T, N1, device="cuda", generator=g) * 0.1).bfloat16()
+        x = torch.randn(T, N2, device="cuda", generator=g).bfloat16()
+        dw = torch.full((N1, N2), 0.5, device="cuda")
+        db = torch.full((N1,), -0.25, device="cuda") if k != 2 else None
+        probs.append((dy, x, dw, db))
+        refs.append((0.5 + dy.float().t() @ x.float(), -0.25 + dy.float().sum(0)))
+    last = len(shapes) - 1
+    probs[last] = (probs[last][0], probs[last][1], probs[1][2], probs[1][3])           # the same accumulator twice
+    refs[1] = (refs[1][0] + refs[last][0] - 0.5, refs[1][1] + refs[last][1] + 0.25)
+
+    def run(direct):
+        n = len(probs)
+        if direct:
+            pa = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in ts])
+            call("swin_wgrad96_group", pa([q[0] for q in probs]), pa([q[1] for q in probs]), pa([q[2] for q in probs]),
+                 pa([q[3] for q in probs]), (ctypes.c_int64 * n)(*[q[0].shape[0] for q in probs]),
+                 (ctypes.c_int * n)(*[q[0].shape[1] for q in probs]), (ctypes.c_int * n)(*[q[1].shape[1] for q in probs]), n, _s())
+        else:
+            for dy, x, dw, db in probs:
+                call("swin_wgrad_record", _p(dy), _p(x), _p(dw), _p(db), dy.shape[0], dy.shape[1], x.shape[1])
+            call("swin_wgrad_flush", _s())
+        torch.cuda.synchronize()
+
+    def check():
+        for (dy, x, dw, db), (rw, rb) in list(zip(probs, refs))[:last]:
+            assert float((dw - rw).abs().max()) <= 2e-3 * float(rw.abs().max()) + 1e-4, tuple(dw.shape)
+            if db is not None:
+                assert float((db - rb).abs().max()) <= 2e-3 * float(rb.abs().max()) + 1e-3, tuple(dw.shape)
+
+    run(True)
+    check()
+    # again through the recording API, next to a problem of the 128-tile form
+    for dy, x, dw, db in probs[:last]:
+        dw.fill_(0.5)
+        if db is not None:
+            db.fill_(-0.25)
+    dy3 = (torch.randn(8000, 256, device="cuda", generator=g) * 0.1).bfloat16()
+    x3 = torch.randn(8000, 1024, device="cuda", generator=g).bfloat16()
+    dw3 = torch.zeros(256, 1024, device="cuda")
+    call("swin_wgrad_record", _p(dy3), _p(x3), _p(dw3), _p(None), 8000, 256, 1024)
+    run(False)
+    check()
+    r3 = dy3.float().t() @ x3.float()
+    assert float((dw3 - r3).abs().max()) <= 2e-3 * float(r3.abs().max()) + 1e-4
+    # a shape that is not this kernel's is refused, not mangled
+    n = 1
+    bad = _lib.lib().swin_wgrad96_group((ctypes.c_void_p * n)(probs[0][0].data_ptr()), (ctypes.c_void_p * n)(probs[0][1].data_ptr()),
+                                        (ctypes.c_void_p * n)(probs[0][2].data_ptr()), None, (ctypes.c_int64 * n)(20011),
+                                        (ctypes.c_int * n)(280), (ctypes.c_int * n)(96), n, _s())
+    assert bad == 2                     # SWIN_ERR_UNSUPPORTED (include/swin_hip.h)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_roi_align_multilevel_group_equals_separate_calls(ops, dtype):
     """The grouped form (bbox 7x7 + mask 14x14 RoIs of one stage, one shared fp32 backward accumulator) == two separate

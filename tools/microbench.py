@@ -132,6 +132,29 @@ def wgradp():
         print(f"conv3x3 fwd {N}x{H}x{W}: {med:7.1f} us {fl / med / 1e6:7.1f} TFLOP/s")
 
 
+def wgradn():
+    """the backbone's grouped Linear weight gradients, a stage's worth per launch (qkv / proj / fc1 / fc2 of its blocks), distinct
+    operands per problem so that nothing is cache-resident; through swin_wgrad_record / _flush.  With the -DSWIN_DEV library,
+    SWIN_WGRAD96=0 sends them to the 128-tile grouped kernel instead (before / after), SWIN_WGRAD96_MODE=0/1 forces the work split."""
+    for name, T, C, nblk in (("stage 1", 128000, 96, 2), ("stage 2", 32000, 192, 2), ("stage 3", 8000, 384, 6), ("stage 4", 2000, 768, 2)):
+        probs = []
+        for _ in range(nblk):
+            for (N1, N2) in ((3 * C, C), (C, C), (4 * C, C), (C, 4 * C)):
+                dy = (torch.randn(T, N1, device="cuda") * 0.1).bfloat16()
+                x = torch.randn(T, N2, device="cuda").bfloat16()
+                probs.append((dy, x, torch.zeros(N1, N2, device="cuda"), torch.zeros(N1, device="cuda")))
+        nbytes = sum(q[0].numel() + q[1].numel() for q in probs) * 2
+        flops = sum(2.0 * T * q[2].numel() for q in probs)
+
+        def run():
+            for dy, x, dw, db in probs:
+                Fn.call("swin_wgrad_record", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), T, dy.shape[1], x.shape[1])
+            Fn.call("swin_wgrad_flush", Fn._s())
+        med, mn = timeit(run, n=10)
+        print(f"wgrad group {name} (T={T}, C={C}, {len(probs)} problems, {nbytes / 1e6:.0f} MB, {flops / 1e9:.0f} GFLOP): {med:7.1f} us (min {mn:.1f})  "
+              f"{nbytes / med / 1e6:5.2f} TB/s  {flops / med / 1e6:6.1f} TFLOP/s")
+
+
 def rooflinep():
     """the two kernels bench.py prices against the MFMA roofline, at the P2 geometry and in bench.py's cache regime (launches rotate over
     three operand sets, 3 x 131 MB > the 256 MB Infinity Cache): the conv weight gradient (wgrad2_kernel<ConvSrc>) and the halo-staged
