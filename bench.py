@@ -185,11 +185,20 @@ def gemm_rooflines(device, steps=18):
     y = torch.empty_like(sets[0][0])
     dw = torch.zeros(C, 3, 3, C, device=device)
     db = torch.zeros(C, device=device)
-    T, N1, N2 = PER_GPU_BATCH * (IMG_H // 16) * (IMG_W // 16), 1536, 384
-    ldy = torch.randn(T, N1, generator=g).to(device=device, dtype=_HD())
-    lx = torch.randn(T, N2, generator=g).to(device=device, dtype=_HD())
-    ldw = torch.zeros(N1, N2, device=device)
-    ldb = torch.zeros(N1, device=device)
+    # stage 3's Linear weight gradients as the step launches them: recorded, then ONE grouped launch (six blocks x qkv / proj / fc1 / fc2)
+    T, C3 = PER_GPU_BATCH * (IMG_H // 16) * (IMG_W // 16), 384
+    lin = []
+    for _ in range(6):
+        for (N1, N2) in ((3 * C3, C3), (C3, C3), (4 * C3, C3), (C3, 4 * C3)):
+            lin.append(((torch.randn(T, N1, generator=g) * 0.1).to(device=device, dtype=_HD()), torch.randn(T, N2, generator=g).to(device=device, dtype=_HD()),
+                        torch.zeros(N1, N2, device=device), torch.zeros(N1, device=device)))
+    lin_flops = sum(2.0 * T * q[2].numel() for q in lin)
+    lin_mb = sum(q[0].numel() + q[1].numel() for q in lin) * 2 / 1e6
+
+    def lin_wgrad():
+        for dy_, x_, dw_, db_ in lin:
+            Fn.call("swin_wgrad_record", Fn._p(dy_), Fn._p(x_), Fn._p(dw_), Fn._p(db_), T, dy_.shape[1], x_.shape[1])
+        Fn.call("swin_wgrad_flush", Fn._s())
     Tm, Cm = PER_GPU_BATCH * (IMG_H // 4) * (IMG_W // 4), 96
     mx = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=_HD())
     mdy = torch.randn(Tm, Cm, generator=g).to(device=device, dtype=_HD())
@@ -219,9 +228,8 @@ def gemm_rooflines(device, steps=18):
          "wgrad2_conv@P2", conv_flops, conv_wgrad, "cold"),
         ("conv_halo_kernel<4> (3x3 conv forward / data gradient, P2 2x200x320x256, halo-staged)", "conv_halo_kernel", "conv_halo@P2", conv_flops,
          conv_fwd, "cold"),
-        (f"wgrad3_kernel (fc1 weight gradient alone, stage 3: T={T}, {N1}x{N2}; inside the step these run grouped: wgrad2_group_kernel)",
-         "wgrad2_group_kernel", None, 2.0 * T * N1 * N2,
-         lambda: Fn.call("wgrad_linear_bf16", Fn._p(ldy), Fn._p(lx), Fn._p(ldw), Fn._p(ldb), T, N1, N2, Fn._s()), "warm (18 MB of operands)"),
+        (f"wgrad96_kernel (the Linear weight gradients of stage 3 in one grouped launch, as in the step: 24 problems, T={T}, C={C3}; "
+         "96x96 pieces per wave, groups of eight blocks per XCD)", "wgrad96_kernel", None, lin_flops, lin_wgrad, f"cold ({lin_mb:.0f} MB of operands)"),
         (f"ts_mlp_bwd_kernel (fused MLP data gradient with fc1 recompute, stage 1: T={Tm}, C={Cm})", "ts_mlp_bwd_kernel", None, 24.0 * Tm * Cm * Cm,
          lambda: Fn.call("swin_mlp_bwd_bf16", Fn._p(mx), Fn._p(mdy), Fn._p(mw1), Fn._p(mb1), Fn._p(mw2), Fn._p(my), Fn._p(mh),
                          Fn._p(mdh), Tm, Cm, Fn._s()), "warm"),

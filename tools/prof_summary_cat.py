@@ -4,6 +4,7 @@
 def cat(n):
     if 'win_attn' in n or 'dbias_slab' in n or 'rel_bias' in n: return 'attention'
     if 'wgrad' in n: return 'wgrad'
+    if 'ts_linear' in n or 'ts_proj_add_ln' in n: return 'linear GEMM (mine)'
     if 'conv_halo' in n or 'gemm_bf16_kernel<ConvA' in n or 'gemm_bf16_kernelI5ConvA' in n or 'splitk_finish' in n or 'conv_dgrad_layout' in n:
         return 'conv3x3 (mine)'
     if 'gemm_bf16' in n or 'narrow_dgrad' in n or 'linear_t_layout' in n: return 'linear GEMM (mine)'
