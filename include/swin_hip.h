@@ -264,6 +264,16 @@ int nms_sorted(const float* boxes_sorted, int64_t n, float iou_threshold, int of
 int nms_sorted_batch(const float* boxes_sorted, int batch, int64_t n, float iou_threshold, int offset, int max_num,
                      uint8_t* keep_flags, int32_t* num_kept, int32_t* kept_pos, int kept_cap, void* workspace,
                      void* stream);
+/* nms_sorted_batch for candidates that carry a class / level id whose boxes were offset apart (mmcv batched_nms, rpn_head.py:233:
+ * boxes of different ids never overlap): the greedy scan of the whole list = the scans of the ids' sub-lists, which run side by
+ * side (five lists of <= 2000 instead of one of 8780 for the RPN: 32 dependent steps instead of 138).  order (batch, n): source
+ * index of sorted position i (nms_prepare_sorted_batch); idxs (batch, n) int64 in [0, groups) by SOURCE index; gmax: no group has
+ * more members (the caller's bound); groups <= 8, iou_threshold > 0.  Same outputs, bit for bit, as nms_sorted_batch.
+ * workspace: nms_grouped_workspace_bytes(batch, n, groups, gmax). */
+int64_t nms_grouped_workspace_bytes(int batch, int64_t n, int groups, int gmax);
+int nms_sorted_batch_grouped(const float* boxes_sorted, const int32_t* order, const int64_t* idxs, int batch, int64_t n, int groups,
+                             int gmax, float iou_threshold, int offset, int max_num, uint8_t* keep_flags, int32_t* num_kept,
+                             int32_t* kept_pos, int kept_cap, void* workspace, void* stream);
 
 /* ---- training targets of the detector heads (csrc/det_targets.hip) --------------------------------------------
  * det_max_iou_assign replaces MaxIoUAssigner.assign (mmdet/core/bbox/assigners/max_iou_assigner.py:128-212 with

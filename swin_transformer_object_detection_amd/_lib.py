@@ -80,6 +80,8 @@ SIGNATURES = {
     "swin_nms_workspace_bytes": [_i64],
     "nms_sorted": [_p, _i64, _f, _i, _i, _p, _p, _p, _i, _p, _p],
     "nms_sorted_batch": [_p, _i, _i64, _f, _i, _i, _p, _p, _p, _i, _p, _p],
+    "nms_sorted_batch_grouped": [_p, _p, _p, _i, _i64, _i, _i, _f, _i, _i, _p, _p, _p, _i, _p, _p],
+    "nms_grouped_workspace_bytes": [_i, _i64, _i, _i],
     "roi_align_multilevel_fwd": [_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "roi_align_multilevel_bwd": [_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "roi_align_gather_workspace_bytes": [_p, _p, _i, _i, _i],
@@ -152,7 +154,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"swin_nms_workspace_bytes": _i64, "swin_gemm_workspace_bytes": _i64, "swin_layernorm_bwd_workspace_bytes": _i64, "swin_window_attn_bwd_workspace_bytes": _i64,
             "det_assign_workspace_bytes": _i64, "det_random_sample_workspace_bytes": _i64, "det_bn_workspace_bytes": _i64,
-            "det_rpn_topk_decode_workspace_bytes": _i64, "nms_prepare_workspace_bytes": _i64,
+            "det_rpn_topk_decode_workspace_bytes": _i64, "nms_prepare_workspace_bytes": _i64, "nms_grouped_workspace_bytes": _i64,
             "conv3x3_splitk_workspace_bytes": _i64, "roi_align_gather_workspace_bytes": _i64, "swin_mlp_ln_bwd_partial_rows": _i64}
 
 _lib = None

@@ -47,12 +47,17 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
 // -- so a block costs about two memory latencies instead of cnt/4.  Stops as soon as `max_num` boxes are kept
 // (> 0): the callers slice `dets[:max_per_img]` (rpn_head.py:235, bbox_nms.py:86-88), so later boxes never matter.
 #define NMS_RT 1024
-__global__ __launch_bounds__(NMS_RT) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks,
+// n_dyn (nullable): the number of boxes of batch entry blockIdx.x read from device memory (<= n_rows, the entry's row stride) --
+// the per-group lists of nms_sorted_batch_grouped; col_stride: words per mask row.
+__global__ __launch_bounds__(NMS_RT) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n_rows, int col_stride,
                                                             uint8_t* __restrict__ keep, int32_t* __restrict__ num_kept,
-                                                            int max_num, int32_t* __restrict__ kept_pos, int kept_cap) {
+                                                            int max_num, int32_t* __restrict__ kept_pos, int kept_cap,
+                                                            const int32_t* __restrict__ n_dyn) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];   // col_blocks words
-    mask += (int64_t)blockIdx.x * n * col_blocks;                        // image of a batched call
-    keep += (int64_t)blockIdx.x * n;
+    const int n = n_dyn ? min(n_dyn[blockIdx.x], n_rows) : n_rows;
+    const int col_blocks = (n + 63) / 64;
+    mask += (int64_t)blockIdx.x * n_rows * col_stride;                   // image of a batched call
+    keep += (int64_t)blockIdx.x * n_rows;
     num_kept += blockIdx.x;
     if (kept_pos) kept_pos += (int64_t)blockIdx.x * kept_cap;
     __shared__ uint64_t kept_bits;
@@ -68,12 +73,12 @@ __global__ __launch_bounds__(NMS_RT) void nms_reduce_kernel(const uint64_t* __re
     // greedy scan on SCALAR registers: `r` is wave-uniform, the word of a kept row comes by v_readlane, and the loop
     // visits only the surviving bits (ctz) -- no LDS round trip and no 64 serial iterations on the critical path
     uint64_t dnext = 0;
-    if (t < 64 && t < n) dnext = mask[(int64_t)t * col_blocks];
+    if (t < 64 && t < n) dnext = mask[(int64_t)t * col_stride];
     for (; b < col_blocks; ++b) {
         const int lim = min(64, n - b * 64);
         if (t < 64) {
             const uint64_t dcur = dnext;
-            if (b + 1 < col_blocks && (b + 1) * 64 + t < n) dnext = mask[(int64_t)((b + 1) * 64 + t) * col_blocks + b + 1];
+            if (b + 1 < col_blocks && (b + 1) * 64 + t < n) dnext = mask[(int64_t)((b + 1) * 64 + t) * col_stride + b + 1];
             const unsigned dlo = (unsigned)dcur, dhi = (unsigned)(dcur >> 32);
             uint64_t r = remv[b], kb = 0;
             const uint64_t valid = lim == 64 ? ~0ull : ((1ull << lim) - 1);
@@ -103,10 +108,10 @@ __global__ __launch_bounds__(NMS_RT) void nms_reduce_kernel(const uint64_t* __re
         const int ncol = col_blocks - (b + 1), ngrp = (cnt + 3) >> 2;
         for (int it = t; it < ncol * ngrp; it += NMS_RT) {
             const int j = b + 1 + it % ncol, k0 = (it / ncol) << 2;
-            const uint64_t a0 = mask[(int64_t)kept_rows[k0] * col_blocks + j];
-            const uint64_t a1 = k0 + 1 < cnt ? mask[(int64_t)kept_rows[k0 + 1] * col_blocks + j] : 0;
-            const uint64_t a2 = k0 + 2 < cnt ? mask[(int64_t)kept_rows[k0 + 2] * col_blocks + j] : 0;
-            const uint64_t a3 = k0 + 3 < cnt ? mask[(int64_t)kept_rows[k0 + 3] * col_blocks + j] : 0;
+            const uint64_t a0 = mask[(int64_t)kept_rows[k0] * col_stride + j];
+            const uint64_t a1 = k0 + 1 < cnt ? mask[(int64_t)kept_rows[k0 + 1] * col_stride + j] : 0;
+            const uint64_t a2 = k0 + 2 < cnt ? mask[(int64_t)kept_rows[k0 + 2] * col_stride + j] : 0;
+            const uint64_t a3 = k0 + 3 < cnt ? mask[(int64_t)kept_rows[k0 + 3] * col_stride + j] : 0;
             const uint64_t acc = (a0 | a1) | (a2 | a3);
             if (acc) atomicOr(&remv[j], (unsigned long long)acc);
         }
@@ -141,7 +146,7 @@ extern "C" int nms_sorted(const float* boxes_sorted, int64_t n, float iou_thresh
     nms_mask_kernel<<<grid, 64, 0, s>>>((const float4*)boxes_sorted, (int)n, iou_threshold, (float)offset,
                                         (uint64_t*)workspace, col_blocks);
     nms_reduce_kernel<<<1, NMS_RT, (size_t)col_blocks * 8, s>>>((const uint64_t*)workspace, (int)n, col_blocks, keep_flags,
-                                                            num_kept, max_num, kept_pos, kept_cap);
+                                                            num_kept, max_num, kept_pos, kept_cap, nullptr);
     return swin_launch_status();
 }
 
@@ -160,7 +165,171 @@ extern "C" int nms_sorted_batch(const float* boxes_sorted, int batch, int64_t n,
     nms_mask_kernel<<<grid, 64, 0, s>>>((const float4*)boxes_sorted, (int)n, iou_threshold, (float)offset, (uint64_t*)workspace,
                                         col_blocks);
     nms_reduce_kernel<<<batch, NMS_RT, (size_t)col_blocks * 8, s>>>((const uint64_t*)workspace, (int)n, col_blocks, keep_flags,
-                                                                   num_kept, max_num, kept_pos, kept_cap);
+                                                                   num_kept, max_num, kept_pos, kept_cap, nullptr);
+    return swin_launch_status();
+}
+
+// ---- grouped form (round 3).  batched_nms offsets the boxes of class / level g by g * (max coordinate + 1) (rpn_head.py:233,
+// mmcv batched_nms): boxes of different groups never overlap, so the greedy scan over the score-sorted list is the union of the
+// scans of the groups' sub-lists -- same boxes, same IoU arithmetic (the OFFSET boxes are compared, as in the reference), same
+// result.  The single scan walks ceil(n / 64) = 138 dependent steps for the RPN's 8780 candidates (142 us, one workgroup per image)
+// and the mask is 138^2 blocks; five level lists of <= 2000 are 32 steps each, side by side, and 5 x 32^2 mask blocks.
+//   partition: sorted position i -> (group, rank in its group), stable;   mask / reduce per (image, group);
+//   finalize: flags back in sorted order, the first max_num kept positions (the callers slice dets[:max_per_img]).
+constexpr int NMS_G = 8;
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+struct NmsGroupWs { int32_t* gcount; int32_t* pk; int32_t* glist; uint8_t* gkeep; uint64_t* mask; int32_t* gkept; };
+
+__global__ __launch_bounds__(1024) void nms_group_partition_kernel(const int32_t* __restrict__ order, const int64_t* __restrict__ idxs, int n,
+                                                                   int G, int gmax, int32_t* __restrict__ gcount, int32_t* __restrict__ pk,
+                                                                   int32_t* __restrict__ glist) {
+    __shared__ int wtot[NMS_G][16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    order += (size_t)b * n; idxs += (size_t)b * n; pk += (size_t)b * n;
+    glist += (size_t)b * G * gmax; gcount += (size_t)b * G;
+    const int per = (n + 1023) / 1024, i0 = t * per, i1 = min(n, i0 + per);
+    int cnt[NMS_G];
+#pragma unroll
+    for (int g = 0; g < NMS_G; ++g) cnt[g] = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int g = min(max((int)idxs[order[i]], 0), G - 1);
+#pragma unroll
+        for (int q = 0; q < NMS_G; ++q) cnt[q] += (q == g);
+    }
+    int start[NMS_G];
+#pragma unroll
+    for (int g = 0; g < NMS_G; ++g) {
+        const int incl = wave_incl_scan(cnt[g], lane);
+        if (lane == 63) wtot[g][wave] = incl;
+        start[g] = incl - cnt[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NMS_G; ++g) {
+        int base = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int v = wtot[g][w]; base += w < wave ? v : 0; tot += v; }
+        start[g] += base;
+        if (t == 0 && g < G) gcount[g] = min(tot, gmax);             // (a group larger than the caller's bound loses its tail: the caller's contract)
+    }
+    for (int i = i0; i < i1; ++i) {
+        const int g = min(max((int)idxs[order[i]], 0), G - 1);
+        int k = 0;
+#pragma unroll
+        for (int q = 0; q < NMS_G; ++q)
+            if (q == g) k = start[q]++;
+        pk[i] = (g << 20) | min(k, (1 << 20) - 1);
+        if (k < gmax) glist[(size_t)g * gmax + k] = i;
+    }
+}
+
+// grid (cbg, cbg, batch * G); as nms_mask_kernel, the boxes through the group's list
+__global__ __launch_bounds__(64) void nms_mask_grouped_kernel(const float4* __restrict__ boxes, int n, int G, int gmax, float thr, float off,
+                                                              const int32_t* __restrict__ gcount, const int32_t* __restrict__ glist,
+                                                              uint64_t* __restrict__ mask, int cbg) {
+    const int rb = blockIdx.y, cb = blockIdx.x, bz = blockIdx.z, b = bz / G, g = bz - b * G;
+    const int ng = gcount[bz];
+    if (cb < rb || cb * 64 >= ng) return;
+    boxes += (size_t)b * n;
+    glist += (size_t)bz * gmax;
+    mask += (size_t)bz * gmax * cbg;
+    __shared__ float4 cbox[64];
+    const int t = threadIdx.x;
+    const int ncol = min(64, ng - cb * 64);
+    if (t < ncol) cbox[t] = boxes[glist[cb * 64 + t]];
+    __syncthreads();
+    const int row = rb * 64 + t;
+    if (row >= ng) return;
+    const float4 me = boxes[glist[row]];
+    uint64_t bits = 0;
+    const int start = (rb == cb) ? t + 1 : 0;
+    for (int j = start; j < ncol; ++j)
+        if (iou_gt(me, cbox[j], off, thr)) bits |= 1ull << j;
+    mask[(size_t)row * cbg + cb] = bits;
+}
+
+__global__ __launch_bounds__(1024) void nms_group_finalize_kernel(const int32_t* __restrict__ pk, const uint8_t* __restrict__ gkeep, int n, int G,
+                                                                  int gmax, int max_num, uint8_t* __restrict__ keep, int32_t* __restrict__ num_kept,
+                                                                  int32_t* __restrict__ kept_pos, int kept_cap) {
+    __shared__ int wtot[16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    pk += (size_t)b * n; gkeep += (size_t)b * G * gmax; keep += (size_t)b * n;
+    if (kept_pos) kept_pos += (size_t)b * kept_cap;
+    const int per = (n + 1023) / 1024, i0 = t * per, i1 = min(n, i0 + per);
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int v = pk[i], g = v >> 20, k = v & ((1 << 20) - 1);
+        cnt += (k < gmax && gkeep[(size_t)g * gmax + k]) ? 1 : 0;
+    }
+    const int incl = wave_incl_scan(cnt, lane);
+    if (lane == 63) wtot[wave] = incl;
+    if (kept_pos) for (int i = t; i < kept_cap; i += 1024) kept_pos[i] = -1;     // fixed-size, -1 padded output
+    __syncthreads();
+    int r = incl - cnt, tot = 0;
+    for (int w = 0; w < 16; ++w) { const int v = wtot[w]; r += w < wave ? v : 0; tot += v; }
+    const int lim = max_num > 0 ? max_num : 0x7fffffff;
+    for (int i = i0; i < i1; ++i) {
+        const int v = pk[i], g = v >> 20, k = v & ((1 << 20) - 1);
+        const bool f = k < gmax && gkeep[(size_t)g * gmax + k];
+        const bool kp = f && r < lim;
+        keep[i] = kp ? 1 : 0;
+        if (kp && kept_pos && r < kept_cap) kept_pos[r] = i;
+        r += f ? 1 : 0;
+    }
+    if (t == 0) num_kept[b] = min(tot, lim);
+}
+
+static NmsGroupWs nms_group_carve(void* workspace, int batch, int64_t n, int G, int gmax) {
+    const int cbg = (gmax + 63) / 64;
+    char* p = (char*)workspace;
+    auto take = [&](size_t bytes) { char* q = p; p += (bytes + 255) / 256 * 256; return q; };
+    NmsGroupWs w;
+    w.gcount = (int32_t*)take((size_t)batch * G * 4);
+    w.gkept = (int32_t*)take((size_t)batch * G * 4);
+    w.pk = (int32_t*)take((size_t)batch * n * 4);
+    w.glist = (int32_t*)take((size_t)batch * G * gmax * 4);
+    w.gkeep = (uint8_t*)take((size_t)batch * G * gmax);
+    w.mask = (uint64_t*)take((size_t)batch * G * gmax * cbg * 8);
+    return w;
+}
+
+extern "C" int64_t nms_grouped_workspace_bytes(int batch, int64_t n, int groups, int gmax) {
+    if (batch <= 0 || n <= 0 || groups <= 0 || gmax <= 0) return 256;
+    const int64_t cbg = (gmax + 63) / 64;
+    const int64_t parts[6] = {(int64_t)batch * groups * 4, (int64_t)batch * groups * 4, (int64_t)batch * n * 4, (int64_t)batch * groups * gmax * 4,
+                              (int64_t)batch * groups * gmax, (int64_t)batch * groups * gmax * cbg * 8};
+    int64_t tot = 0;
+    for (int64_t v : parts) tot += (v + 255) / 256 * 256;
+    return tot;
+}
+
+// boxes_sorted (batch, n, 4): the OFFSET boxes in score order and order (batch, n): their source indices (nms_prepare_sorted_batch);
+// idxs (batch, n) int64 in [0, groups): the class / level of source box i; no group larger than gmax (the caller's bound: per-level
+// candidate counts); groups <= 8, n < 2^20, iou_threshold > 0.  Outputs as nms_sorted_batch.
+extern "C" int nms_sorted_batch_grouped(const float* boxes_sorted, const int32_t* order, const int64_t* idxs, int batch, int64_t n, int groups,
+                                        int gmax, float iou_threshold, int offset, int max_num, uint8_t* keep_flags, int32_t* num_kept,
+                                        int32_t* kept_pos, int kept_cap, void* workspace, void* stream) {
+    if (batch <= 0 || n <= 0 || !boxes_sorted || !order || !idxs || !keep_flags || !num_kept || !workspace) return SWIN_ERR_BAD_ARG;
+    if (groups < 1 || groups > NMS_G || gmax < 1 || n >= (1 << 20) || !(iou_threshold > 0.f) || batch * groups > 65535) return SWIN_ERR_UNSUPPORTED;
+    if (gmax > n) gmax = (int)n;
+    const int cbg = (gmax + 63) / 64;
+    if ((size_t)cbg * 8 > 60000) return SWIN_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const NmsGroupWs w = nms_group_carve(workspace, batch, n, groups, gmax);
+    nms_group_partition_kernel<<<batch, 1024, 0, s>>>(order, idxs, (int)n, groups, gmax, w.gcount, w.pk, w.glist);
+    nms_mask_grouped_kernel<<<dim3(cbg, cbg, batch * groups), 64, 0, s>>>((const float4*)boxes_sorted, (int)n, groups, gmax, iou_threshold,
+                                                                          (float)offset, w.gcount, w.glist, w.mask, cbg);
+    // one reduction per (image, group): row stride gmax, the group's own count from device memory (gcount[image * groups + group])
+    nms_reduce_kernel<<<batch * groups, NMS_RT, (size_t)cbg * 8, s>>>(w.mask, gmax, cbg, w.gkeep, w.gkept, max_num, nullptr, 0, w.gcount);
+    nms_group_finalize_kernel<<<batch, 1024, 0, s>>>(w.pk, w.gkeep, (int)n, groups, gmax, max_num, keep_flags, num_kept, kept_pos, kept_cap);
     return swin_launch_status();
 }
 

@@ -29,7 +29,12 @@ __global__ __launch_bounds__(WAVES * 64) void ts_linear_kernel(const bf16* __res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t tok = (int64_t)blockIdx.x * (WAVES * 32) + wave * 32 + r;
     const int64_t tokc = tok < T ? tok : T - 1;
-    const int nch = N / CH;
+    // blockIdx.y takes an equal share of the N / CH output chunks (few tokens, wide layers: stage 3 has 8000 tokens = 32 blocks of
+    // 256, the grid's second dimension fills the chip)
+    const int nch_all = N / CH;
+    const int jb = (int)((int64_t)nch_all * blockIdx.y / gridDim.y), nch = (int)((int64_t)nch_all * (blockIdx.y + 1) / gridDim.y) - jb;
+    if (nch <= 0) return;
+    W += (int64_t)jb * CH * C;
     dma_image<CH, C, WAVES>(W, C, smem, wave, lane);
     for (int i = tid; i < N; i += WAVES * 64) bs[i] = bias ? (float)bias[i] : 0.f;
     bf16x8 xf[KS];
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(WAVES * 64) void ts_linear_kernel(const bf16* __res
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
             f32x16 a;
-            const int n0 = j * CH + 32 * t;
+            const int n0 = (jb + j) * CH + 32 * t;
 #pragma unroll
             for (int q = 0; q < 16; ++q) a[q] = bs[n0 + tile_ch(q, h)];
             const bf16* wrow = Ws + (32 * t + pr) * I::RS + 8 * h;
@@ -162,7 +167,11 @@ int launch_linear(const void* x, const void* w, const void* bias, void* y, int64
         attr_set[dev] = true;
     }
     const unsigned blocks = (unsigned)((T + WAVES * 32 - 1) / (WAVES * 32));
-    kern<<<blocks, WAVES * 64, lds, s>>>((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)y, T, N, relu);
+    // one block per CU (LDS: two chunk images): with fewer token blocks than CUs the output chunks are dealt over blockIdx.y
+    unsigned ny = blocks >= 256 ? 1u : 256u / blocks;
+    if (ny > (unsigned)(N / CH)) ny = (unsigned)(N / CH);
+    if (ny < 1) ny = 1;
+    kern<<<dim3(blocks, ny), WAVES * 64, lds, s>>>((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)y, T, N, relu);
     return swin_launch_status();
 }
 
@@ -186,7 +195,7 @@ int launch_proj(const void* o, const void* w, const void* bias, const void* x, c
 
 }  // namespace
 
-// y (T, N) = [relu](x (T, C) w (N, C)^T + bias (N; 16-bit, may be NULL)).  C in {96, 128, 192, 256}, N a multiple of 64 (of 96 / 128 at
+// y (T, N) = [relu](x (T, C) w (N, C)^T + bias (N; 16-bit, may be NULL)).  C in {96, 128, 192, 256, 384}, N a multiple of 64 (of 96 / 128 at
 // C = 96, 192 / 128 the whole-chunk variants are used: the qkv projection's 3C); else SWIN_ERR_UNSUPPORTED.
 extern "C" int swin_ts_linear_bf16(const void* x, const void* w, const void* bias, void* y, int64_t T, int N, int C, int relu, void* stream) {
     if (T == 0) return SWIN_OK;
@@ -197,6 +206,7 @@ extern "C" int swin_ts_linear_bf16(const void* x, const void* w, const void* bia
         case 128: return N % 128 == 0 ? launch_linear<128, 8, 128>(x, w, bias, y, T, N, relu, s) : launch_linear<128, 8, 64>(x, w, bias, y, T, N, relu, s);
         case 192: return N % 96 == 0 ? launch_linear<192, 8, 96>(x, w, bias, y, T, N, relu, s) : launch_linear<192, 8, 64>(x, w, bias, y, T, N, relu, s);
         case 256: return launch_linear<256, 8, 64>(x, w, bias, y, T, N, relu, s);
+        case 384: return launch_linear<384, 8, 64>(x, w, bias, y, T, N, relu, s);      // stage 3 of Swin-T / -S: 96 fragment registers per lane
         default: return SWIN_ERR_UNSUPPORTED;
     }
 }

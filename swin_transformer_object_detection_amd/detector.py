@@ -633,7 +633,8 @@ class RPNHead(nn.Module):
             anchors_cat = self.anchor_generator.grid_anchors_cat(sizes, cls_all.device)
             scores, props, ids = ops.rpn_topk_decode(cls_all, reg_all, anchors_cat, [a.size(0) for a in mlvl_anchors], nms_pre,
                                                      self.means, self.stds, img_shapes[0])
-            dets, valid = ops.batched_nms_static_multi(props, scores, ids, cfg['nms']['iou_threshold'], cfg['max_per_img'])
+            dets, valid = ops.batched_nms_static_multi(props, scores, ids, cfg['nms']['iou_threshold'], cfg['max_per_img'],
+                                                       group_sizes=[min(a.size(0), nms_pre) for a in mlvl_anchors])
             return [(dets[i], valid[i]) for i in range(B)]
         s_all, d_all = cls_all.detach().float().sigmoid(), reg_all.detach().float()
         off = 0

@@ -593,7 +593,7 @@ _MIN_T = int(os.environ.get("SWIN_LINEAR_MIN_T", "1024"))   # rows below which n
 _DIRECT_GEMM = os.environ.get("SWIN_TORCH_GEMM") != "1"      # A/B switch (development): 1 = torch.nn.functional.linear / mm
 
 
-_TS_K = (96, 128, 192, 256)
+_TS_K = (96, 128, 192, 256, 384)
 
 
 def gemm_bf16(a, b, bias=None, b_is_kn=False, out_shape=None, relu=False):

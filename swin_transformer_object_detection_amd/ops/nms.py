@@ -115,10 +115,13 @@ def batched_nms_static(boxes, scores, idxs, iou_threshold, max_num):
     return torch.where(valid[:, None], dets, torch.zeros_like(dets)), valid
 
 
-def batched_nms_static_multi(boxes, scores, idxs, iou_threshold, max_num):
+def batched_nms_static_multi(boxes, scores, idxs, iou_threshold, max_num, group_sizes=None):
     """batched_nms_static for a BATCH of images with the same candidate count, in one set of launches:
     boxes (B,n,4), scores (B,n), idxs (B,n) -> (dets (B,max_num,5), valid (B,max_num)).  Per image identical to
-    batched_nms_static (same per-image coordinate offset, stable descending sort, greedy suppression)."""
+    batched_nms_static (same per-image coordinate offset, stable descending sort, greedy suppression).
+    ``group_sizes``: the caller's promise that idxs takes the values 0 .. len(group_sizes) - 1 with at most group_sizes[g] members
+    per image (the RPN's per-level candidate counts) -- the suppression scans of the ids then run side by side
+    (nms_sorted_batch_grouped); same result."""
     if not boxes.is_cuda:
         raise SwinHipError("nms: HIP path needs GPU tensors (no CPU fallback)")
     boxes, scores = boxes.float(), scores.float()
@@ -127,7 +130,8 @@ def batched_nms_static_multi(boxes, scores, idxs, iou_threshold, max_num):
         return boxes.new_zeros((B, max_num, 5)), torch.zeros((B, max_num), dtype=torch.bool, device=boxes.device)
     boxes, scores, idxs = boxes.contiguous(), scores.contiguous(), idxs.contiguous()
     dev = boxes.device
-    ws = torch.empty(B * lib().swin_nms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    grouped = group_sizes is not None and 1 < len(group_sizes) <= 8 and iou_threshold > 0 and n <= 16384 and idxs.dtype == torch.int64
+    ws = None if grouped else torch.empty(B * lib().swin_nms_workspace_bytes(n), dtype=torch.uint8, device=dev)
     flags = torch.empty((B, n), dtype=torch.uint8, device=dev)
     cnt = torch.empty(B, dtype=torch.int32, device=dev)
     pos = torch.empty((B, max_num), dtype=torch.int32, device=dev)
@@ -138,8 +142,14 @@ def batched_nms_static_multi(boxes, scores, idxs, iou_threshold, max_num):
         order = torch.empty((B, n), dtype=torch.int32, device=dev)
         pws = torch.empty(lib().nms_prepare_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
         call("nms_prepare_sorted_batch", _p(boxes), _p(scores), _p(idxs), B, n, _p(bs), _p(order), _p(pws), _s())
-        call("nms_sorted_batch", _p(bs), B, n, float(iou_threshold), 0, int(max_num), _p(flags), _p(cnt), _p(pos), int(max_num), _p(ws),
-             _s())
+        if group_sizes is not None and 1 < len(group_sizes) <= 8 and iou_threshold > 0 and n < (1 << 20):
+            G, gmax = len(group_sizes), int(max(group_sizes))
+            gws = torch.empty(lib().nms_grouped_workspace_bytes(B, n, G, gmax), dtype=torch.uint8, device=dev)
+            call("nms_sorted_batch_grouped", _p(bs), _p(order), _p(idxs), B, n, G, gmax, float(iou_threshold), 0, int(max_num), _p(flags),
+                 _p(cnt), _p(pos), int(max_num), _p(gws), _s())
+        else:
+            call("nms_sorted_batch", _p(bs), B, n, float(iou_threshold), 0, int(max_num), _p(flags), _p(cnt), _p(pos), int(max_num), _p(ws),
+                 _s())
         dets = torch.empty((B, max_num, 5), dtype=torch.float32, device=dev)
         valid = torch.empty((B, max_num), dtype=torch.bool, device=dev)
         call("nms_gather_dets", _p(boxes), _p(scores), _p(order), _p(pos), B, n, int(max_num), _p(dets), _p(valid), _s())

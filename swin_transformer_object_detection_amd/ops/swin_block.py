@@ -400,7 +400,7 @@ class _SwinBlockFn(torch.autograd.Function):
             mixed.side_mark(dev)
         w2t = None if getattr(ctx, 'fused_mlp', False) or C % 64 != 0 else mixed.linear_t_weight(m_w2, w2)
         # narrow stages: the proj data gradient on the token-stationary kernel (csrc/ts_linear.hip) needs the transposed weight
-        wpt = mixed.linear_t_weight(m_wproj, wproj) if C in (96, 128, 192, 256) else None
+        wpt = mixed.linear_t_weight(m_wproj, wproj) if C in (96, 128, 192, 256, 384) else None
         ptrs = (ctypes.c_void_p * 58)(
             _ptr(n1), _ptr(qkv), _ptr(bias_exp), _ptr(lse), _ptr(o), _ptr(x1), _ptr(mean2), _ptr(rstd2), _ptr(n2), _ptr(hpre),
             _ptr(h), _ptr(x2), _ptr(mean3), _ptr(rstd3), _ptr(dp0), _ptr(dp1), _ptr(wqkv), _ptr(wproj), _ptr(w1), _ptr(w2),

@@ -131,6 +131,36 @@ def test_mlp_gelu_epilogue_gemms_vs_oracle(fn, T, C):
     assert bool((h2[same] == h[same]).all())                                               # same pre-activation -> same GELU bits
 
 
+@pytest.mark.parametrize("C,T", [(384, 8000), (384, 37), (384, 2 * 50 * 80 + 3), (192, 32000), (96, 700)])
+def test_token_stationary_linear_chunk_split_and_stage3_width(C, T):
+    """swin_ts_linear_bf16 with the output chunks dealt over blockIdx.y (fewer token blocks than CUs: stage 2 / stage 3 of the
+    BASELINE geometry) and at C = 384 (stage 3: qkv, proj and the proj data gradient of swin_block_fwd / _bwd), against swin_gemm_bf16:
+    same rounding points, at most an ulp apart."""
+    from swin_transformer_object_detection_amd import _lib
+    from swin_transformer_object_detection_amd.ops import functional as Fn
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    H = _lib.half_dtype()
+    g = torch.Generator().manual_seed(C + T)
+    dev = torch.device("cuda", 0)
+    x = torch.randn(T, C, generator=g).to(dev, H)
+    ws = torch.empty(_lib.lib().swin_gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+    for N, relu, with_bias in ((3 * C, 0, True), (C, 0, True), (C, 0, False), (256, 1, True), (4 * C, 0, True)):
+        w = (torch.randn(N, C, generator=g) * C ** -0.5).to(dev, H)
+        b = (torch.randn(N, generator=g) * 0.1).to(dev, H) if with_bias else None
+        y0 = torch.empty(T, N, device=dev, dtype=H)
+        y1 = torch.full_like(y0, float("nan"))
+        Fn.call("swin_gemm_bf16", Fn._p(x), Fn._p(w), Fn._p(b), Fn._p(y0), T, N, C, 0, Fn._p(ws), Fn._s())
+        Fn.call("swin_ts_linear_bf16", Fn._p(x), Fn._p(w), Fn._p(b), Fn._p(y1), T, N, C, relu, Fn._s())
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y1.float()).all()), N
+        ref = torch.relu(y0) if relu else y0
+        a, r = y1.float(), ref.float()
+        tol = 2.0 ** (-10 if H == torch.float16 else -7) * r.abs().clamp(min=2.0 ** -6)
+        bad = (a - r).abs() > tol
+        assert float(bad.float().mean()) <= 2e-3 and float(((a - r).abs() / tol).max()) <= 2.01, (N, int(bad.sum()))
+
+
 @pytest.mark.parametrize("C", [96, 128, 192, 256])
 @pytest.mark.parametrize("T", [1, 37, 1000, 2 * 25 * 40 + 5])
 def test_token_stationary_qkv_and_proj_ln_equal_the_library_chain(C, T):

@@ -1062,6 +1062,38 @@ def test_batched_nms_static_multi_equals_per_image(ops):
         assert torch.equal(valid[i], v1) and torch.equal(dets[i], d1)
 
 
+@pytest.mark.parametrize("case", ["rpn", "dense", "tiny", "one_big_group", "early_stop"])
+def test_batched_nms_grouped_scans_equal_the_single_scan(ops, case):
+    """nms_sorted_batch_grouped (the suppression scans of the level / class ids side by side) == the single scan over the whole
+    score-sorted list (nms_sorted_batch, itself checked against the oracle), bit for bit: kept boxes, their order, the validity mask
+    and the max_num cut -- at the RPN's geometry (five levels of <= 2000 candidates, 1000 kept), with heavy overlap, with groups of
+    very different sizes (an empty one included), and when max_num stops the scan early."""
+    rng = np.random.RandomState({"rpn": 1, "dense": 2, "tiny": 3, "one_big_group": 4, "early_stop": 5}[case])
+    if case == "rpn":
+        B, sizes, m, span, wh = 2, [2000, 2000, 2000, 2000, 780], 1000, 1200.0, 220.0
+    elif case == "dense":
+        B, sizes, m, span, wh = 3, [700, 650, 90, 1200], 900, 120.0, 90.0          # most boxes suppressed
+    elif case == "tiny":
+        B, sizes, m, span, wh = 1, [3, 0, 70], 50, 60.0, 40.0
+    elif case == "one_big_group":
+        B, sizes, m, span, wh = 2, [4100, 5, 64, 0, 1, 129, 63, 2], 2000, 900.0, 100.0
+    else:
+        B, sizes, m, span, wh = 2, [1500, 1500, 1500], 40, 2000.0, 30.0             # almost nothing suppressed: the cut decides
+    n = sum(sizes)
+    ids = np.concatenate([np.full(k, g) for g, k in enumerate(sizes)])
+    idxs = torch.from_numpy(np.stack([ids for _ in range(B)])).long().cuda()
+    xy = rng.rand(B, n, 2).astype(np.float32) * span
+    boxes = torch.from_numpy(np.concatenate([xy, xy + rng.rand(B, n, 2).astype(np.float32) * wh + 1], 2)).cuda()
+    scores = torch.from_numpy(rng.rand(B, n).astype(np.float32))
+    kt = (n - 1) // 7
+    scores[:, 0:7 * kt:7] = scores[:, 1:7 * kt:7]                                  # ties: the stable order decides
+    scores = scores.cuda()
+    d0, v0 = ops.batched_nms_static_multi(boxes, scores, idxs, 0.7, m)
+    d1, v1 = ops.batched_nms_static_multi(boxes, scores, idxs, 0.7, m, group_sizes=sizes)
+    assert int(v0.sum()) > 0
+    assert torch.equal(v0, v1) and torch.equal(d0, d1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_rpn_flatten_kernel(ops, dtype):
     """det_rpn_flatten == slicing + concatenating the per-level head outputs with torch (anchor_head.py:474-486 order),

@@ -18,7 +18,8 @@ def timeit(fn, n=20, warm=3):
 
 ws = torch.empty(_lib.lib().swin_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
 for M, N, K, name in ((128000, 288, 96, "qkv s1"), (32000, 576, 192, "qkv s2"), (128000, 96, 96, "proj s1"), (32000, 192, 192, "proj s2"),
-                      (128000, 256, 96, "lateral 0"), (32000, 256, 192, "lateral 1"), (50176, 1024, 256, "deconv"), (131072, 384, 128, "qkv swin-b s1")):
+                      (128000, 256, 96, "lateral 0"), (32000, 256, 192, "lateral 1"), (50176, 1024, 256, "deconv"), (131072, 384, 128, "qkv swin-b s1"),
+                      (8000, 1152, 384, "qkv s3"), (8000, 384, 384, "proj s3"), (8000, 1536, 384, "fc1 s3"), (8000, 256, 384, "lateral 2")):
     a = torch.randn(M, K, device="cuda").bfloat16()
     w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
     b = torch.randn(N, device="cuda").bfloat16()
