@@ -8,6 +8,8 @@
 //                       coalesced read, and the backward's fp32 atomics are 256-byte contiguous per wave
 // Features may be fp32 or bf16 (converted on load, which is what the reference's force_fp32 does);
 // output and all arithmetic are fp32.  Gradient w.r.t. features is fp32 (atomics), caller zeroes it.
+#include <algorithm>
+
 #include "common.h"
 
 struct RoiGeom {
@@ -78,34 +80,107 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nchw(const T* __restrict__ 
     }
 }
 
-// NCHW forward with ONE WAVE per output bin: the lanes share the bin's sampling grid (adjacent lanes = adjacent sample
-// columns, <= 1 px apart: coalesced) and the partial sums are folded with a wave reduction.  For few outputs with large
-// adaptive grids -- the mask targets (mask_target.py:66-122: 28x28 bins over RoIs hundreds of pixels wide on the
-// full-resolution 1-channel gt mask), where a thread per bin would walk hundreds of samples serially.
+// NCHW forward for few outputs with large adaptive grids -- the mask targets (mask_target.py:66-122: 28x28 bins over RoIs hundreds
+// of pixels wide on the full-resolution 1-channel gt mask), where a thread per bin would walk hundreds of samples serially.
+// Round 2 gave every bin a wave (lanes = samples): 152 us per step, VALU-bound -- every wave instruction of the per-bin set-up costs a
+// full issue slot, and 196 samples x (set-up + 4 loads) per bin.  Round 3: the sum is SEPARABLE.  A bin's value is the sum over its
+// sampling grid of bilinear interpolations; the bilinear weight of pixel (r, c) for sample (y, x) is wy(y, r) * wx(x, c) and the validity
+// test is per axis, so   out[i][j] = sum_ix [ wl(x) V_i[lo(x)] + wh(x) V_i[hi(x)] ] / count,   V_i[c] = sum_r WY_i[r] P[r][c],
+// WY_i[r] = sum over bin-row i's y samples of wy(y, r).  One wave per (RoI, channel, bin-row i): WY_i once (lanes = y samples),
+// V_i over the RoI's columns (lanes = columns, rows in the loop), then lanes = the row's pw bins walking their x samples.  ~30 wave
+// instructions per bin instead of ~400.  Same clamping rules as bilin_setup (roi_align_cuda_kernel.cuh:28-70 bilinear_interpolate);
+// fp32 sums in a different order (tests: 1e-4).  Rows whose footprint exceeds the LDS vectors (> 64 pixel rows per bin, > 1408
+// columns per RoI) take the sample-by-sample loop.
+struct Axis1 { int lo, hi; float wl, wh; bool valid; };
+__device__ __forceinline__ Axis1 axis_setup(int n, float v) {
+    Axis1 a;
+    a.valid = !(v < -1.0f || v > (float)n);
+    if (v <= 0.f) v = 0.f;
+    int lo = (int)v, hi;
+    if (lo >= n - 1) { hi = lo = n - 1; v = (float)lo; } else hi = lo + 1;
+    a.lo = lo; a.hi = hi;
+    a.wh = v - (float)lo; a.wl = 1.f - a.wh;
+    return a;
+}
+
+constexpr int RA_VMAX = 1408;
+
 template <typename T>
-__global__ __launch_bounds__(256) void roi_align_fwd_nchw_wave(const T* __restrict__ in, const float* __restrict__ rois,
-                                                               float* __restrict__ out, int C, int H, int W, int64_t total,
+__global__ __launch_bounds__(256) void roi_align_fwd_nchw_rows(const T* __restrict__ in, const float* __restrict__ rois,
+                                                               float* __restrict__ out, int C, int H, int W, int tasks,
                                                                int ph, int pw, float scale, int sr, int aligned) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); idx < total; idx += (int64_t)gridDim.x * 4) {
-        int j = (int)(idx % pw), i = (int)((idx / pw) % ph);
-        int c = (int)((idx / pw / ph) % C);
-        int64_t k = idx / pw / ph / C;
-        RoiGeom g = roi_geom(rois + 5 * k, scale, aligned, ph, pw, sr);
+    __shared__ float wy_s[4][64];
+    __shared__ float v_s[4][RA_VMAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* WY = wy_s[wv];
+    float* V = v_s[wv];
+    for (unsigned task = blockIdx.x * 4u + wv; task < (unsigned)tasks; task += gridDim.x * 4u) {
+        const unsigned q1 = task / (unsigned)ph, k = q1 / (unsigned)C;
+        const int i = (int)(task - q1 * ph), c = (int)(q1 - k * C);
+        const RoiGeom g = roi_geom(rois + 5 * k, scale, aligned, ph, pw, sr);
         const T* p = in + ((int64_t)g.batch * C + c) * H * W;
-        float acc = 0.f;
-        const int ns = g.grid_h * g.grid_w;
-        for (int s = lane; s < ns; s += 64) {
-            const int iy = s / g.grid_w, ix = s - iy * g.grid_w;
-            float y = g.start_h + (float)i * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
-            float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
-            Bilin b = bilin_setup(H, W, y, x);
-            if (!b.valid) continue;
-            acc += b.w1 * Elt<T>::ld(p + b.yl * W + b.xl) + b.w2 * Elt<T>::ld(p + b.yl * W + b.xh) +
-                   b.w3 * Elt<T>::ld(p + b.yh * W + b.xl) + b.w4 * Elt<T>::ld(p + b.yh * W + b.xh);
+        float* o = out + (((int64_t)k * C + c) * ph + i) * pw;
+        const float ys = g.bin_h / (float)g.grid_h, xs = g.bin_w / (float)g.grid_w;
+        const float y_base = g.start_h + (float)i * g.bin_h;
+        const int r0 = axis_setup(H, y_base + .5f * ys).lo, r1 = axis_setup(H, y_base + ((float)(g.grid_h - 1) + .5f) * ys).hi;
+        const int c0 = axis_setup(W, g.start_w + .5f * xs).lo;
+        const int c1 = axis_setup(W, g.start_w + (float)(pw - 1) * g.bin_w + ((float)(g.grid_w - 1) + .5f) * xs).hi;
+        const int R = r1 - r0 + 1, Cs = c1 - c0 + 1;
+        if (g.grid_h < 1 || g.grid_w < 1) {                          // degenerate RoI: no samples (count = 1)
+            if (lane < pw) o[lane] = 0.f;
+            continue;
         }
-        acc = wave_sum(acc);
-        if (lane == 0) out[idx] = acc / g.count;
+        if (R > 64 || Cs > RA_VMAX || R < 1 || Cs < 1) {              // (wave-uniform) sample by sample, a bin at a time
+            for (int j = 0; j < pw; ++j) {
+                float acc = 0.f;
+                const int ns = g.grid_h * g.grid_w;
+                for (int s = lane; s < ns; s += 64) {
+                    const int iy = s / g.grid_w, ix = s - iy * g.grid_w;
+                    const float y = y_base + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+                    const float x = g.start_w + (float)j * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                    const Bilin b = bilin_setup(H, W, y, x);
+                    if (!b.valid) continue;
+                    acc += b.w1 * Elt<T>::ld(p + b.yl * W + b.xl) + b.w2 * Elt<T>::ld(p + b.yl * W + b.xh) +
+                           b.w3 * Elt<T>::ld(p + b.yh * W + b.xl) + b.w4 * Elt<T>::ld(p + b.yh * W + b.xh);
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) o[j] = acc / g.count;
+            }
+            continue;
+        }
+        // ---- WY: lanes = y samples of bin-row i
+        WY[lane] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        for (int iy = lane; iy < g.grid_h; iy += 64) {
+            const Axis1 a = axis_setup(H, y_base + ((float)iy + .5f) * g.bin_h / (float)g.grid_h);
+            if (a.valid) { atomicAdd(&WY[a.lo - r0], a.wl); atomicAdd(&WY[a.hi - r0], a.wh); }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- V[c] = sum_r WY[r] P[r0 + r][c0 + c]: lanes = columns (coalesced rows), four rows in flight
+        for (int cc = lane; cc < Cs; cc += 64) {
+            const T* q = p + (int64_t)r0 * W + c0 + cc;
+            float acc = 0.f;
+            int r = 0;
+            for (; r + 4 <= R; r += 4) {
+                const float va = Elt<T>::ld(q + (int64_t)r * W), vb = Elt<T>::ld(q + (int64_t)(r + 1) * W);
+                const float vc = Elt<T>::ld(q + (int64_t)(r + 2) * W), vd = Elt<T>::ld(q + (int64_t)(r + 3) * W);
+                acc += WY[r] * va; acc += WY[r + 1] * vb; acc += WY[r + 2] * vc; acc += WY[r + 3] * vd;
+            }
+            for (; r < R; ++r) acc += WY[r] * Elt<T>::ld(q + (int64_t)r * W);
+            V[cc] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lanes = bins of the row: their x samples against V
+        for (int j = lane; j < pw; j += 64) {
+            float acc = 0.f;
+            const float x_base = g.start_w + (float)j * g.bin_w;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const Axis1 a = axis_setup(W, x_base + ((float)ix + .5f) * g.bin_w / (float)g.grid_w);
+                if (a.valid) acc += a.wl * V[a.lo - c0] + a.wh * V[a.hi - c0];
+            }
+            o[j] = acc / g.count;
+        }
+        __builtin_amdgcn_wave_barrier();                              // everyone is done with WY / V before the next task rewrites them
     }
 }
 
@@ -435,12 +510,13 @@ extern "C" int roi_align_fwd(const void* input, const float* rois, float* output
         const bool wave = sampling_ratio <= 0 && total <= (1 << 18);      // few bins, adaptive grid: wave per bin
         if (in_dtype != SWIN_F32 && in_dtype != SWIN_BF16) return SWIN_ERR_UNSUPPORTED;
         if (wave) {
-            int blocks = (int)((total + 3) / 4);
+            const int tasks = K * C * ph;                               // a wave per (RoI, channel, bin-row)
+            int blocks = std::min((tasks + 3) / 4, 256 * 8);
             if (in_dtype == SWIN_F32)
-                roi_align_fwd_nchw_wave<float><<<blocks, 256, 0, s>>>((const float*)input, rois, output, C, H, W, total, ph, pw,
+                roi_align_fwd_nchw_rows<float><<<blocks, 256, 0, s>>>((const float*)input, rois, output, C, H, W, tasks, ph, pw,
                                                                       spatial_scale, sampling_ratio, aligned);
             else
-                roi_align_fwd_nchw_wave<bf16><<<blocks, 256, 0, s>>>((const bf16*)input, rois, output, C, H, W, total, ph, pw,
+                roi_align_fwd_nchw_rows<bf16><<<blocks, 256, 0, s>>>((const bf16*)input, rois, output, C, H, W, tasks, ph, pw,
                                                                      spatial_scale, sampling_ratio, aligned);
         } else if (in_dtype == SWIN_F32)
             roi_align_fwd_nchw<float><<<ra_blocks(total), 256, 0, s>>>((const float*)input, rois, output, C, H, W, total, ph, pw,

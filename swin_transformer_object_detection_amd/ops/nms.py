@@ -142,7 +142,7 @@ def batched_nms_static_multi(boxes, scores, idxs, iou_threshold, max_num, group_
         order = torch.empty((B, n), dtype=torch.int32, device=dev)
         pws = torch.empty(lib().nms_prepare_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
         call("nms_prepare_sorted_batch", _p(boxes), _p(scores), _p(idxs), B, n, _p(bs), _p(order), _p(pws), _s())
-        if group_sizes is not None and 1 < len(group_sizes) <= 8 and iou_threshold > 0 and n < (1 << 20):
+        if grouped:
             G, gmax = len(group_sizes), int(max(group_sizes))
             gws = torch.empty(lib().nms_grouped_workspace_bytes(B, n, G, gmax), dtype=torch.uint8, device=dev)
             call("nms_sorted_batch_grouped", _p(bs), _p(order), _p(idxs), B, n, G, gmax, float(iou_threshold), 0, int(max_num), _p(flags),

@@ -789,6 +789,33 @@ def test_roi_align_nchw_thread_per_bin_path(ops):
     close(out, torch.from_numpy(ref), ATOL32)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_roi_align_nchw_separable_rows_path(ops, dtype):
+    """The NCHW forward of the mask targets (csrc/roi_align.hip roi_align_fwd_nchw_rows: a wave per bin-row, the bilinear sums
+    taken separably) against the oracle's sample-by-sample sums, at the mask targets' geometry (28 x 28 bins, adaptive grids of up
+    to 20 x 20 samples on a 1-channel full-resolution map) and on the corners of its rules: RoIs hanging over every border (samples
+    beyond -1 / H are dropped, those in between clamp), a RoI far outside, zero-size and inverted RoIs under aligned=True (no samples),
+    not-aligned RoIs narrower than a pixel, and two bins per axis over a 200-pixel RoI (footprint > 64 rows: the sample loop)."""
+    rng = np.random.RandomState(12)
+    H, W = 300, 420
+    inp = (rng.rand(3, 1, H, W) > 0.5).astype(np.float32)                       # binary instance masks
+    rois = _rand_rois(rng, 40, 3, W, H)
+    rois[0, 1:] = [-30.5, -12.25, 90.0, 75.5]                                     # over the top-left corner
+    rois[1, 1:] = [350.2, 250.7, 460.0, 333.3]                                    # over the bottom-right corner
+    rois[2, 1:] = [-500, -500, -400, -420]                                        # nowhere near the map
+    rois[3, 1:] = [50, 60, 50, 60]                                                # zero size
+    rois[4, 1:] = [120, 90, 100, 70]                                              # inverted
+    rois[5, 1:] = [10.3, 20.6, 10.9, 21.1]                                        # narrower than a pixel
+    rois[6, 1:] = [0, 0, W, H]                                                    # the whole map
+    rois[7, 1:] = [5, 5, 414.5, 295.5]
+    x = torch.from_numpy(inp).cuda().to(dtype)
+    for out_size, aligned in ((28, True), (28, False), (2, True), (7, True)):
+        ref = D.roi_align_c(inp, rois, out_size, 1.0, 0, aligned)
+        assert ref.size <= (1 << 18)
+        out = ops.roi_align(x, torch.from_numpy(rois).cuda(), out_size, 1.0, 0, 'avg', aligned)
+        close(out.float(), torch.from_numpy(ref), ATOL32, msg=f"out_size={out_size} aligned={aligned}")
+
+
 @pytest.mark.parametrize("M,N,K", [(5000, 288, 96), (1024, 1024, 12544), (2000, 768, 3072), (130, 88, 1024)])
 def test_gemm_bf16_direct(ops, M, N, K):
     """swin_gemm_bf16 (hipBLASLt with cached plans) == fp32 matmul of the same bf16 operands, both layouts, with bias;
