@@ -464,6 +464,106 @@ __global__ __launch_bounds__(256) void roi_align_ml_fwd_nhwc(MLFeats F, const fl
     }
 }
 
+// The same forward, separably, for C = 256 (the FPN's width: the 64 four-channel threads of a bin are exactly one wave; round 3).
+// In the kernel above all 64 lanes of a bin run the identical bilinear set-up for each of its grid_h x grid_w samples (about half of
+// the instructions) and load 4 pixels per sample.  A bin's value is sum_r sum_c WY[r] WX[c] P[r][c] with WY / WX the summed 1-D
+// weights of its y / x samples (validity and clamping are per axis: see roi_align_fwd_nchw_rows): the wave builds the two weight
+// vectors once (lanes = samples) and walks the (bin_h + 2) x (bin_w + 2) pixel footprint -- 81 loads instead of 256 for an 8 x 8 grid,
+// one multiply per pixel instead of a set-up per sample.  fp32 sums in a different order than sample by sample (tests: 1e-4).
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void roi_align_ml_fwd_nhwc_sep(MLFeats F, const float* __restrict__ rois, const int* __restrict__ lvl,
+                                                                 TO* __restrict__ out, int bins, int ph, int pw, int sr, int aligned) {
+    constexpr int C = 256;
+    __shared__ float wts[4][2][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c4 = lane * 4;
+    float* WY = wts[wv][0];
+    float* WX = wts[wv][1];
+    for (unsigned bin = blockIdx.x * 4u + wv; bin < (unsigned)bins; bin += gridDim.x * 4u) {
+        const unsigned q1 = bin / (unsigned)pw, k = q1 / (unsigned)ph;
+        const int j = (int)(bin - q1 * pw), i = (int)(q1 - k * ph);
+        const int l = lvl[k];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float cnt = 1.f;
+        if (l >= 0) {
+            const int H = F.H[l], W = F.W[l];
+            const RoiGeom g = roi_geom(rois + 5 * k, F.scale[l], aligned, ph, pw, sr);
+            cnt = g.count;
+            const T* p = (const T*)F.p[l] + (int64_t)g.batch * H * W * C + c4;
+            const float ys = g.bin_h / (float)g.grid_h, xs = g.bin_w / (float)g.grid_w;
+            const float y_base = g.start_h + (float)i * g.bin_h, x_base = g.start_w + (float)j * g.bin_w;
+            const int r0 = axis_setup(H, y_base + .5f * ys).lo, r1 = axis_setup(H, y_base + ((float)(g.grid_h - 1) + .5f) * ys).hi;
+            const int c0 = axis_setup(W, x_base + .5f * xs).lo, c1 = axis_setup(W, x_base + ((float)(g.grid_w - 1) + .5f) * xs).hi;
+            const int R = r1 - r0 + 1, Cn = c1 - c0 + 1;
+            if (g.grid_h < 1 || g.grid_w < 1) {
+                // no samples: zeros
+            } else if (R > 64 || Cn > 64 || R < 1 || Cn < 1) {           // (wave-uniform) sample by sample
+                for (int iy = 0; iy < g.grid_h; ++iy) {
+                    const float y = y_base + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+                    for (int ix = 0; ix < g.grid_w; ++ix) {
+                        const float x = x_base + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                        const Bilin b = bilin_setup(H, W, y, x);
+                        if (!b.valid) continue;
+                        const T* p1 = p + ((int64_t)b.yl * W + b.xl) * C;
+                        const T* p2 = p + ((int64_t)b.yl * W + b.xh) * C;
+                        const T* p3 = p + ((int64_t)b.yh * W + b.xl) * C;
+                        const T* p4 = p + ((int64_t)b.yh * W + b.xh) * C;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[e] += b.w1 * Elt<T>::ld(p1 + e) + b.w2 * Elt<T>::ld(p2 + e) + b.w3 * Elt<T>::ld(p3 + e) +
+                                      b.w4 * Elt<T>::ld(p4 + e);
+                    }
+                }
+            } else {
+                WY[lane] = 0.f;
+                WX[lane] = 0.f;
+                __builtin_amdgcn_wave_barrier();
+                for (int iy = lane; iy < g.grid_h; iy += 64) {
+                    const Axis1 a = axis_setup(H, y_base + ((float)iy + .5f) * g.bin_h / (float)g.grid_h);
+                    if (a.valid) { atomicAdd(&WY[a.lo - r0], a.wl); atomicAdd(&WY[a.hi - r0], a.wh); }
+                }
+                for (int ix = lane; ix < g.grid_w; ix += 64) {
+                    const Axis1 a = axis_setup(W, x_base + ((float)ix + .5f) * g.bin_w / (float)g.grid_w);
+                    if (a.valid) { atomicAdd(&WX[a.lo - c0], a.wl); atomicAdd(&WX[a.hi - c0], a.wh); }
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int r = 0; r < R; ++r) {
+                    const float wy = WY[r];
+                    if (wy == 0.f) continue;                                  // wave-uniform
+                    const T* q = p + ((int64_t)(r0 + r) * W + c0) * C;
+                    for (int cc = 0; cc < Cn; cc += 4) {                       // four pixels in flight (a weight of zero: the pixel at cc again)
+                        float w[4];
+                        const T* qq[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool in = cc + u < Cn;
+                            w[u] = in ? wy * WX[cc + u] : 0.f;
+                            qq[u] = q + (int64_t)(in ? cc + u : cc) * C;
+                        }
+                        float v[4][4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[u][e] = Elt<T>::ld(qq[u] + e);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[e] += w[u] * v[u][e];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                              // the weights are read before the next bin zeroes them
+            }
+        }
+        const float4 o = float4{acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt};
+        const int64_t oi = ((int64_t)bin * 64 + lane) * 4;
+        if constexpr (sizeof(TO) == 4) {
+            *(float4*)(out + oi) = o;
+        } else {
+            bf16x4 ob = {(bf16)o.x, (bf16)o.y, (bf16)o.z, (bf16)o.w};
+            *(bf16x4*)(out + oi) = ob;
+        }
+    }
+}
+
 struct MLGrads { float* p[4]; int H[4], W[4]; float scale[4]; };
 
 template <typename TG>
@@ -564,6 +664,18 @@ extern "C" int roi_align_multilevel_fwd(const void* const* feats, const int* Hs,
     }
     hipStream_t s = (hipStream_t)stream;
     int64_t total = (int64_t)K * ph * pw * (C / 4);
+    if (C == 256 && (int64_t)K * ph * pw < ((int64_t)1 << 30)) {         // a wave per bin: the separable form
+        const int bins = K * ph * pw;
+        const int blocks = std::min((bins + 3) / 4, 256 * 16);
+        if (in_dtype == SWIN_F32 && out_dtype == SWIN_F32)
+            roi_align_ml_fwd_nhwc_sep<float, float><<<blocks, 256, 0, s>>>(F, rois, lvl, (float*)output, bins, ph, pw, sampling_ratio, aligned);
+        else if (in_dtype == SWIN_BF16 && out_dtype == SWIN_F32)
+            roi_align_ml_fwd_nhwc_sep<bf16, float><<<blocks, 256, 0, s>>>(F, rois, lvl, (float*)output, bins, ph, pw, sampling_ratio, aligned);
+        else if (in_dtype == SWIN_BF16 && out_dtype == SWIN_BF16)
+            roi_align_ml_fwd_nhwc_sep<bf16, bf16><<<blocks, 256, 0, s>>>(F, rois, lvl, (bf16*)output, bins, ph, pw, sampling_ratio, aligned);
+        else return SWIN_ERR_UNSUPPORTED;
+        return swin_launch_status();
+    }
     if (in_dtype == SWIN_F32 && out_dtype == SWIN_F32)
         roi_align_ml_fwd_nhwc<float, float><<<ra_blocks(total), 256, 0, s>>>(F, rois, lvl, (float*)output, C, total, ph, pw, sampling_ratio, aligned);
     else if (in_dtype == SWIN_BF16 && out_dtype == SWIN_F32)
