@@ -1,5 +1,6 @@
 // HBM-bound elementwise / gather kernels of the Swin block and the FPN top-down path.
 // All of them move 16 bytes per lane per access (coalesced dwordx4).
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -521,12 +522,66 @@ __global__ __launch_bounds__(256) void narrow_dgrad_gated_kernel(const bf16* __r
     }
 }
 
+// The same on the matrix cores (round 3), K in {16, 32}, C % 32 == 0: in the step the fp32-FMA form above ran 72 us on P2's 128 000
+// tokens -- 524 M multiply-adds plus 32 LDS reads per thread, VALU-bound -- for 134 MB of traffic (22 us at HBM speed).  A wave owns
+// 32 tokens: their dy rows are the B operand (one 16-byte load per lane and k-step), the weight columns the A operand (gathered
+// once per wave: 8 scalar loads per tile and k-step, L2-resident), the accumulator tile has the token on the lane and 16 channels in
+// the registers (csrc/ts_linear.hip), so the gate test and the store are two 16-byte pieces per tile.  fp32 accumulation in the MFMA's
+// order instead of k = 0 .. K-1: an output may differ by an ulp of the 16-bit type.
+template <int KS>
+__global__ __launch_bounds__(256) void narrow_dgrad_gated_mfma_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ w,
+                                                                      const bf16* __restrict__ gate, bf16* __restrict__ dx, int64_t T,
+                                                                      int C) {
+    constexpr int K = 16 * KS;
+    extern __shared__ __attribute__((aligned(16))) bf16 wt[];                  // w transposed: [C][K + 8] (row stride of an odd number of 16-byte slots)
+    constexpr int RS = K + 8;
+    for (int i = threadIdx.x; i < K * C; i += 256) { const int k = i / C, c = i - k * C; wt[c * RS + k] = w[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int pr = ((r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1));            // rows of the A operand in the order that puts channels
+    const int ct_n = C / 32;                                                   // 8 h + q / 16 + 8 h + (q - 8) into the registers
+    const int64_t groups = (T + 31) / 32;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < groups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t tok = grp * 32 + r, tokc = tok < T ? tok : T - 1;
+        bf16x8 xf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[s] = *(const bf16x8*)(dy + tokc * K + 16 * s + 8 * h);
+        for (int ct = 0; ct < ct_n; ++ct) {
+            const bf16* wrow = wt + (32 * ct + pr) * RS + 8 * h;               // this lane's weight column
+            f32x16 a = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a = SWIN_MFMA_32x32x16(*(const bf16x8*)(wrow + 16 * s), xf[s], a, 0, 0, 0);
+            if (tok < T) {
+                const int c0 = 32 * ct + 8 * h;
+                const bf16x8 g0 = *(const bf16x8*)(gate + tok * C + c0), g1 = *(const bf16x8*)(gate + tok * C + c0 + 16);
+                bf16x8 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o0[e] = (float)g0[e] > 0.f ? (bf16)a[e] : (bf16)0.f;
+                    o1[e] = (float)g1[e] > 0.f ? (bf16)a[8 + e] : (bf16)0.f;
+                }
+                *(bf16x8*)(dx + tok * C + c0) = o0;
+                *(bf16x8*)(dx + tok * C + c0 + 16) = o1;
+            }
+        }
+    }
+}
+
 // dy (T,K) bf16, w (K,C) bf16, gate (T,C) bf16 -> dx (T,C) bf16.  K % 8 == 0, K <= 64, C % 8 == 0, K*C*4 <= 64 KB.
 extern "C" int narrow_dgrad_gated_bf16(const void* dy, const void* w, const void* gate, void* dx, int64_t T, int K, int C,
                                        void* stream) {
     if (T == 0) return SWIN_OK;
     if (!dy || !w || !gate || !dx || T < 0 || K <= 0 || C <= 0) return SWIN_ERR_BAD_ARG;
     if (K % 8 != 0 || K > 64 || C % 8 != 0 || (size_t)K * C * sizeof(float) > 65536) return SWIN_ERR_UNSUPPORTED;
+    if ((K == 16 || K == 32) && C % 32 == 0) {
+        const int64_t groups = (T + 31) / 32;
+        const unsigned nb = (unsigned)std::min<int64_t>((groups + 3) / 4, 256 * 4);       // a block transposes the weights into LDS once
+        const size_t lds = (size_t)C * (K + 8) * 2;
+        if (lds > 65536) return SWIN_ERR_UNSUPPORTED;
+        if (K == 16) narrow_dgrad_gated_mfma_kernel<1><<<nb, 256, lds, (hipStream_t)stream>>>((const bf16*)dy, (const bf16*)w, (const bf16*)gate, (bf16*)dx, T, C);
+        else narrow_dgrad_gated_mfma_kernel<2><<<nb, 256, lds, (hipStream_t)stream>>>((const bf16*)dy, (const bf16*)w, (const bf16*)gate, (bf16*)dx, T, C);
+        return swin_launch_status();
+    }
     const int64_t total = ((T + 3) / 4) * (C / 8);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -328,15 +328,16 @@ def test_relu_backward_rides_in_the_producing_kernel(pkg):
     _close(fused[2], w1.grad, 0.02 * float(w1.grad.abs().max()), "dW of the lower conv")
 
     # the narrow head: dx = [gate > 0] * dy w
-    T, K, C = 5003, 16, 256
-    dy = torch.randn(T, K, device="cuda").bfloat16()
-    w = (torch.randn(K, C, device="cuda") * 0.1).bfloat16()
-    gate = torch.relu(torch.randn(T, C, device="cuda")).bfloat16()
-    dx = torch.full((T, C), 7.0, device="cuda", dtype=torch.bfloat16)
-    Fn.call("narrow_dgrad_gated_bf16", Fn._p(dy), Fn._p(w), Fn._p(gate), Fn._p(dx), T, K, C, Fn._s())
-    ref = (dy.float() @ w.float()) * (gate > 0)
-    _close(dx, ref, _bf16_tol(ref, 1.01), "narrow gated dgrad")
-    assert bool(((dx == 0) | (gate > 0)).all())
+    # (K = 16 / 32 with C % 32 == 0: the matrix-core form, a wave per 32 tokens; else the fp32-FMA form)
+    for T, K, C in ((5003, 16, 256), (77, 32, 96), (4096, 16, 64), (333, 24, 256), (1000, 16, 40)):
+        dy = torch.randn(T, K, device="cuda").bfloat16()
+        w = (torch.randn(K, C, device="cuda") * 0.1).bfloat16()
+        gate = torch.relu(torch.randn(T, C, device="cuda")).bfloat16()
+        dx = torch.full((T, C), 7.0, device="cuda", dtype=torch.bfloat16)
+        Fn.call("narrow_dgrad_gated_bf16", Fn._p(dy), Fn._p(w), Fn._p(gate), Fn._p(dx), T, K, C, Fn._s())
+        ref = (dy.float() @ w.float()) * (gate > 0)
+        _close(dx, ref, _bf16_tol(ref, 1.01), f"narrow gated dgrad {T}x{K}x{C}")
+        assert bool(((dx == 0) | (gate > 0)).all())
 
 
 # ------------------------------------------------------------------------------------- kernels at the bench's own sizes
