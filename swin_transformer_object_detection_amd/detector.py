@@ -569,7 +569,40 @@ class RPNHead(nn.Module):
         return self.get_bboxes(cls_scores, bbox_preds, [m['img_shape'] for m in img_metas], self.test_cfg)
 
     # ---- training targets + loss (anchor_head.py:175-493) ----
-    def loss(self, cls_scores, bbox_preds, gt_bboxes, img_shapes):
+    def _inside_flags(self, anchors, img_shapes, B):
+        ab = self.train_cfg.get('allowed_border', -1)
+        inside = [None] * B
+        if ab >= 0:                                 # anchor_inside_flags (core/anchor/utils.py:28-50), anchor_head.py:200-207
+            for i in range(B):
+                h, w = img_shapes[i][:2]
+                inside[i] = ((anchors[:, 0] >= -ab) & (anchors[:, 1] >= -ab) & (anchors[:, 2] < w + ab) & (anchors[:, 3] < h + ab))
+        return inside
+
+    def _sampled_targets(self, anchors, inside, gt_bboxes, device):
+        """assign -> sample -> encode per image (anchor_head.py:175-262 for the sampled anchors), device path"""
+        a_cfg, s_cfg = self.train_cfg['assigner'], self.train_cfg['sampler']
+        B, num = len(gt_bboxes), s_cfg['num']
+        inds = torch.empty(B, num, dtype=torch.long, device=device)
+        flags = torch.empty(B, num, dtype=torch.uint8, device=device)
+        tgts = torch.empty(B, num, 4, dtype=torch.float32, device=device)
+        for i in range(B):
+            assigned, _, _ = ops.max_iou_assign(anchors, gt_bboxes[i], a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'], a_cfg['min_pos_iou'],
+                                                a_cfg.get('match_low_quality', True), None, 0, inside[i])
+            ops.random_sample_raw(assigned, num, s_cfg['pos_fraction'], out=(inds[i], flags[i]))
+            ops.bbox_targets(anchors, inds[i], flags[i], assigned, gt_bboxes[i], self.means, self.stds, out_deltas=tgts[i])
+        return inds, flags, tgts
+
+    @torch.no_grad()
+    def early_targets(self, sizes, gt_bboxes, img_shapes, device):
+        """The anchor targets depend on the anchors and the ground truth only, not on the predictions: computed (on the second stream)
+        BEFORE the backbone runs, when the host is ahead of the GPU, instead of ~25 launches issued between proposal selection and the
+        RoI heads, where the main stream sat idle for 0.25 ms waiting for the host.  ``sizes``: the pyramid's feature-map sizes the
+        caller expects; ``loss`` recomputes the targets if the real ones differ.  Returns an opaque pair for ``loss(targets=...)``."""
+        anchors = self.anchor_generator.grid_anchors_cat(list(sizes), device)
+        inside = self._inside_flags(anchors, img_shapes, len(gt_bboxes))
+        return tuple(sizes), self._sampled_targets(anchors, inside, gt_bboxes, device)
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, img_shapes, targets=None):
         """Sampled-anchor form of AnchorHead.loss: the reference builds (B, 255780) label / weight / target arrays and
         multiplies the per-anchor losses by 0/1 weights; only the <= 256 sampled anchors per image have non-zero
         weight, so the same sums are taken over those anchors directly.  No host synchronisation."""
@@ -579,25 +612,15 @@ class RPNHead(nn.Module):
         anchors = self.anchor_generator.grid_anchors_cat(sizes, cls_scores[0].device)
         B = cls_scores[0].size(0)
         cls, reg = self._flattened(cls_scores, bbox_preds)
-        ab = cfg.get('allowed_border', -1)
-        inside = [None] * B
-        if ab >= 0:                                 # anchor_inside_flags (core/anchor/utils.py:28-50), anchor_head.py:200-207
-            for i in range(B):
-                h, w = img_shapes[i][:2]
-                inside[i] = ((anchors[:, 0] >= -ab) & (anchors[:, 1] >= -ab) & (anchors[:, 2] < w + ab) & (anchors[:, 3] < h + ab))
+        inside = self._inside_flags(anchors, img_shapes, B)
         beta = self.loss_bbox_beta
         if cls.is_cuda:
             # assign -> sample -> encode per image, each kernel writing its row of the batch-level tensors; then both losses, over
             # all images, in one forward and one backward launch (csrc/det_losses.hip)
-            num = s_cfg['num']
-            inds = torch.empty(B, num, dtype=torch.long, device=cls.device)
-            flags = torch.empty(B, num, dtype=torch.uint8, device=cls.device)
-            tgts = torch.empty(B, num, 4, dtype=torch.float32, device=cls.device)
-            for i in range(B):
-                assigned, _, _ = ops.max_iou_assign(anchors, gt_bboxes[i], a_cfg['pos_iou_thr'], a_cfg['neg_iou_thr'], a_cfg['min_pos_iou'],
-                                                    a_cfg.get('match_low_quality', True), None, 0, inside[i])
-                ops.random_sample_raw(assigned, num, s_cfg['pos_fraction'], out=(inds[i], flags[i]))
-                ops.bbox_targets(anchors, inds[i], flags[i], assigned, gt_bboxes[i], self.means, self.stds, out_deltas=tgts[i])
+            if targets is not None and targets[0] == tuple(sizes):
+                inds, flags, tgts = targets[1]
+            else:
+                inds, flags, tgts = self._sampled_targets(anchors, inside, gt_bboxes, cls.device)
             lc, lb = ops.rpn_loss(cls, reg, inds, flags, tgts, beta)
             return dict(loss_rpn_cls=_scaled(lc, self.loss_cls_weight), loss_rpn_bbox=_scaled(lb, self.loss_bbox_weight))
         samples = [assign_and_sample(anchors, gt_bboxes[i], a_cfg, s_cfg, self.means, self.stds, valid=inside[i]) for i in range(B)]
@@ -1446,7 +1469,39 @@ class MaskRCNN(nn.Module):
         x = self.backbone(img)
         return self.neck(x) if self.neck is not None else x
 
+    def _pyramid_sizes(self, img):
+        """feature-map sizes of the neck's outputs for this image size (patch embedding / PatchMerging pad to even sizes: ceil
+        halving from stride 4; the extra FPN levels are stride-2 subsamplings), or None when the configuration is not the plain one"""
+        try:
+            n_out = int(self.neck.num_outs)
+            n_in = len(self.neck.in_channels)
+            ps = self.backbone.patch_embed.patch_size
+            ps = int(ps[0] if isinstance(ps, (tuple, list)) else ps)
+            if getattr(self.neck, 'start_level', 0) != 0:
+                return None
+        except (AttributeError, TypeError):
+            return None
+        h, w = -(-img.shape[-2] // ps), -(-img.shape[-1] // ps)
+        sizes = []
+        oi = tuple(getattr(self.backbone, 'out_indices', (0, 1, 2, 3)))
+        if len(oi) != n_in or oi != tuple(range(oi[0], oi[0] + n_in)):
+            return None
+        for _ in range(oi[0]):
+            h, w = -(-h // 2), -(-w // 2)
+        for k in range(n_out):
+            sizes.append((h, w))
+            h, w = -(-h // 2), -(-w // 2)
+        return sizes
+
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_masks=None, proposals=None):
+        # the RPN's anchor targets first, on the second stream (RPNHead.early_targets)
+        early = None
+        if img.is_cuda and mixed.side_enabled() and hasattr(self.rpn_head, 'early_targets') and self.neck is not None:
+            sizes = self._pyramid_sizes(img)
+            if sizes is not None:
+                with mixed.on_side(img.device, *gt_bboxes) as side0:
+                    if side0 is not None:
+                        early = self.rpn_head.early_targets(sizes, gt_bboxes, [m['img_shape'] for m in img_metas], img.device)
         if self.neck is not None and hasattr(self.neck, 'defer_join'):
             # the small pyramid levels' convs run on the second stream (mixed.small_branch); here the RPN head, which continues
             # on that stream, joins -- a stand-alone extract_feat() joins at the end of the neck
@@ -1468,7 +1523,7 @@ class MaskRCNN(nn.Module):
         proposal_cfg = _cfg_get(self.train_cfg, 'rpn_proposal', _cfg_get(self.test_cfg, 'rpn'))
         proposal_list = self.rpn_head.get_bboxes(cls_scores, bbox_preds, img_shapes, proposal_cfg, static=True)
         with mixed.on_side(cls_scores[0].device, *cls_scores, *bbox_preds) as side:
-            rpn_losses = self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_shapes)
+            rpn_losses = self.rpn_head.loss(cls_scores, bbox_preds, gt_bboxes, img_shapes, targets=early if side is not None else None)
         if side is not None:
             for v in rpn_losses.values():
                 v.record_stream(torch.cuda.current_stream(v.device))

@@ -233,7 +233,8 @@ _WG_ENABLED = [0]     # > 0 while a reducer with gradient sinks is alive (someon
 _WG_PENDING = {}      # device index -> [problems, 128x128 tiles]
 _WG_KEEP = []
 _WG_FLUSH_TILES = int(os.environ.get("SWIN_WGRAD_GROUP_TILES", "600"))
-_WG_TAIL = os.environ.get("SWIN_WGRAD_TAIL_FLUSH", "0") != "0"   # 1: launch the narrow stages' gradients block by block (A/B: slower)
+_WG_TAIL = int(os.environ.get("SWIN_WGRAD_TAIL_FLUSH", "0"))      # 1: launch the narrow stages' gradients block by block (A/B: slower);
+                                                                    # 2: one extra launch at the stage 2 / stage 1 boundary
 
 
 def wgrad_group_active():
@@ -262,13 +263,14 @@ def wgrad_note(device, problems, tiles, *keep, tail=False):
     ``tail`` (with SWIN_WGRAD_TAIL_FLUSH=1 and the weight-gradient stream on): flush at once.  The blocks of the two narrow stages
     are the END of backward: nothing is left to hide their grouped launch behind and the optimizer waits for it (0.35 ms in the eager
     trace).  Launched block by block they do overlap the rest of backward -- but stage 1's backward and its weight gradients are both
-    HBM streams, so the overlap only shares the bandwidth: measured 9.91 ms per step against 9.73 with the grouped tail.  Off."""
+    HBM streams, so the overlap only shares the bandwidth: measured 9.91 ms per step against 9.73 with the grouped tail; one extra launch
+    at the stage 2 / stage 1 boundary (SWIN_WGRAD_TAIL_FLUSH=2, ``tail`` == 2): 9.99 against 9.89, twice.  Off."""
     i = _dev_index(device)
     ent = _WG_PENDING.setdefault(i, [0, 0])
     ent[0] += problems
     ent[1] += tiles
     _WG_KEEP.extend(t for t in keep if t is not None)
-    if ent[1] >= _WG_FLUSH_TILES or ent[0] >= 30 or (tail and _WG_TAIL and _SIDE_ON):
+    if ent[1] >= _WG_FLUSH_TILES or ent[0] >= 30 or (tail and _SIDE_ON and (_WG_TAIL == 1 or (_WG_TAIL == 2 and tail == 2))):
         wgrad_flush()
 
 

@@ -414,7 +414,8 @@ class _SwinBlockFn(torch.autograd.Function):
         call("swin_block_bwd", ptrs, iv, fv, _s())
         if record:
             t128 = lambda a_, b_: ((a_ + 127) // 128) * ((b_ + 127) // 128)      # noqa: E731
-            mixed.wgrad_note(dev, 4, t128(3 * C, C) + t128(C, C) + 2 * t128(4 * C, C), flat, n1, o, n2, h, dx2, dy2, tail=C <= 192)
+            mixed.wgrad_note(dev, 4, t128(3 * C, C) + t128(C, C) + 2 * t128(4 * C, C), flat, n1, o, n2, h, dx2, dy2,
+                             tail=(2 if (C in (192, 256) and shift == 0) else 1) if C <= 256 else 0)
         g_bq = f_bqkv()
         g_pad = f_bpad()
         if g_pad is not None:
