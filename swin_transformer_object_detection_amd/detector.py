@@ -1224,7 +1224,9 @@ def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cf
         mask_pred = mask_head.forward_rows(mask_feats) if rows_path else mask_head(mask_feats)
         with mixed.on_side(dev, buf.mask_rois, *gt_masks) as sd:
             if stacked:
-                m = (gt_masks[0] if nimg == 1 else torch.cat(list(gt_masks), 0)).to(_H())[:, None]     # 0/1 exact in bf16
+                m = _take_mask_stack(gt_masks) if sd is not None else None                              # stacked before the backbone ran
+                if m is None:
+                    m = (gt_masks[0] if nimg == 1 else torch.cat(list(gt_masks), 0)).to(_H())[:, None]  # 0/1 exact in bf16
                 tg = (ops.roi_align(m, buf.mask_rois, size, 1.0, 0, 'avg', True)[:, 0] >= 0.5).float()
             else:
                 mr = buf.mask_rois.view(nimg, km, 5)
@@ -1236,6 +1238,26 @@ def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cf
         loss_fn = mask_head.loss_rows if rows_path else mask_head.loss
         losses.update(loss_fn(mask_pred, tg, buf.mlabels, buf.mvalid))
     return losses, state
+
+
+# The stacked 16-bit copy of the ground-truth masks (a 16 MB concatenation and a cast) depends on the batch only: forward_train makes it
+# on the second stream before the backbone runs, the mask-target branch picks it up here instead of issuing it in front of its RoIAlign.
+_MASK_STACKS = {}
+
+
+def _mask_key(gt_masks):
+    return tuple((t.data_ptr(), tuple(t.shape)) for t in gt_masks)
+
+
+def _early_mask_stack(gt_masks):
+    if not gt_masks or not all(m_.size(0) > 0 and m_.shape[1:] == gt_masks[0].shape[1:] for m_ in gt_masks):
+        return
+    _MASK_STACKS.clear()
+    _MASK_STACKS[_mask_key(gt_masks)] = (gt_masks[0] if len(gt_masks) == 1 else torch.cat(list(gt_masks), 0)).to(_H())[:, None]
+
+
+def _take_mask_stack(gt_masks):
+    return _MASK_STACKS.pop(_mask_key(gt_masks), None)
 
 
 _ONES_BOOL = {}
@@ -1502,6 +1524,8 @@ class MaskRCNN(nn.Module):
                 with mixed.on_side(img.device, *gt_bboxes) as side0:
                     if side0 is not None:
                         early = self.rpn_head.early_targets(sizes, gt_bboxes, [m['img_shape'] for m in img_metas], img.device)
+                        if gt_masks is not None and getattr(self.roi_head, 'with_mask', True):
+                            _early_mask_stack(list(gt_masks))
         if self.neck is not None and hasattr(self.neck, 'defer_join'):
             # the small pyramid levels' convs run on the second stream (mixed.small_branch); here the RPN head, which continues
             # on that stream, joins -- a stand-alone extract_feat() joins at the end of the neck
