@@ -397,6 +397,10 @@ def main():
     # timed for a few steps and the faster one runs the measurement.
     eager_step = step
     launch_mode, graph_note, mode_trials = "eager", None, None
+    if os.environ.get("SWIN_BENCH_GC", "1") != "0":
+        for _ in range(2):
+            eager_step()                        # everything long-lived exists before it is frozen
+        mixed.host_gc_for_training()            # fewer interpreter garbage collections inside the eager step (mixed.host_gc_for_training)
 
     def time_steps(fn, n):
         fn(); barrier()

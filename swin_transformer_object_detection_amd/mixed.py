@@ -223,6 +223,20 @@ def fork_into(device, target, home=None):
             _SIDE_DIRTY.add(k)
 
 
+def host_gc_for_training(freeze=True):
+    """Host-side setting for an eager training loop, called once after warm-up: the step creates a few thousand short-lived Python
+    objects (tensors, ctypes arguments, autograd nodes), enough for a generation-0 collection every few launches and a full
+    collection over the whole model every few steps.  Freeze what exists (the model, the plans: never garbage) and raise the
+    thresholds; reference cycles are still collected, just less often.  Returns the previous thresholds."""
+    import gc
+    old = gc.get_threshold()
+    gc.collect()
+    if freeze and hasattr(gc, "freeze"):
+        gc.freeze()
+    gc.set_threshold(50000, 20, 100)
+    return old
+
+
 # ---- grouped Linear weight gradients (csrc/wgrad_dma.hip: swin_wgrad_record / swin_wgrad_flush) ----------------------------------
 # Inside a training step with gradient sinks (ddp.BucketedGradReducer) the Linear layers do not launch their weight-gradient GEMM in
 # their own backward: they RECORD it, and a stage's worth is launched as one grouped kernel -- hundreds of output tiles per launch, so
