@@ -347,10 +347,12 @@ def main():
     from swin_transformer_object_detection_amd.optim import FusedAdamW
     optim = FusedAdamW(build_param_groups(model, opt_cfg), lr=opt_cfg["lr"], betas=opt_cfg["betas"])      # one launch, refreshes the bf16 shadows
     scaler = mixed.LossScaler(optim, reducer) if dtype == torch.float16 else None      # apex O1's dynamic loss scaling, on the device
-    if world == 1 and os.environ.get("SWIN_EARLY_OPT", "0") == "1":
-        # one process: a bucket's gradients are final as soon as its parameters have arrived -- the optimizer can run for it right
-        # then, on the second stream, instead of for everything after the join at the end of backward.  Measured: no gain
-        # (11.64 / 11.69 ms with, 11.67 / 11.67 without, same box): the join then waits for that work instead.  Off by default.
+    if world == 1 and scaler is None and os.environ.get("SWIN_EARLY_OPT", "1") == "1":
+        # one process: a bucket's gradients are final as soon as its parameters have arrived -- the optimizer runs for it right then,
+        # on the second stream, instead of for everything after the join at the end of backward (not under dynamic loss scaling: the
+        # finite check needs every gradient first).  Round 2 measured no gain (the second stream's backlog was what the join waited
+        # for); with 3.3 ms of work left on that stream it takes the optimizer's 0.26 ms out of the tail: 9.78 -> 9.69 ms per step,
+        # twice (SWIN_EARLY_OPT=0: off).  A captured one-stream step ignores it.
         reducer.early_step = optim.step_partial
     batch = data.synthetic_batch(PER_GPU_BATCH, img_h, img_w, device, seed=rank)     # per-rank data
     torch.manual_seed(1000 + rank)             # per-rank sampling / DropPath randomness
