@@ -20,6 +20,7 @@ Everything between the kernels runs on the device: the reference's numpy round t
 ``mask_target`` are gone.
 """
 import contextlib
+import os
 import ctypes
 import math
 
@@ -1103,7 +1104,7 @@ def mask_target(pos_proposals_list, pos_assigned_gt_inds_list, gt_masks_list, ma
 
 
 def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox_roi_extractor, bbox_head, mask_roi_extractor,
-                     mask_head):
+                     mask_head, bbox_branch=False):
     """One R-CNN stage of training (standard_roi_head.py:70-131; cascade_roi_head.py:228-270 runs it per stage) with
     fixed-size samples.  ``proposal_list[i]`` is ``dets (n,4|5)`` (the reference's form) or ``(dets (max,4|5), valid (max,))``
     from the static RPN / refinement path.  Every tensor below has a shape known on the host (512 RoIs and 128 mask slots per
@@ -1116,7 +1117,7 @@ def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox
     num, npos_max = s['num'], int(s['num'] * s['pos_fraction'])
     if _PACKED_STAGE and nimg > 0 and x[0].is_cuda and all(gb.size(0) > 0 for gb in gt_bboxes):
         return _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox_roi_extractor, bbox_head,
-                                       mask_roi_extractor, mask_head)
+                                       mask_roi_extractor, mask_head, bbox_branch)
     roi_l, lab_l, tgt_l, pos_l, val_l, isgt_l = [], [], [], [], [], []
     m_roi, m_gt, m_lab, m_val = [], [], [], []
     for i in range(nimg):
@@ -1165,7 +1166,7 @@ def _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox
 
 
 def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cfg, bbox_roi_extractor, bbox_head,
-                            mask_roi_extractor, mask_head):
+                            mask_roi_extractor, mask_head, bbox_branch=False):
     """_roi_stage_train on the GPU: per image assign -> sample -> ONE pack launch (ops.roi_targets_pack) that writes the
     image's rows of every batch-level tensor of the stage -- RoIs with their image column, targets, labels, flags, the mask
     slots' feature RoIs and crop_and_resize rows -- instead of ~20 gathers / comparisons / clamps / concatenations."""
@@ -1207,8 +1208,16 @@ def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cf
         bbox_feats, mask_feats = bbox_roi_extractor.forward_with(mask_roi_extractor, feats, rois, valid, buf.feat_rois, buf.mvalid)
     else:
         bbox_feats = bbox_roi_extractor(feats, rois, valid=valid)
-    cls_score, bbox_pred = bbox_head(bbox_feats)
-    losses.update(bbox_head.loss(cls_score, bbox_pred, labels, buf.targets, buf.pos, valid, rois=rois, flags=buf.flags.view(-1)))
+    # bbox_branch (the standard RoI head, whose caller does not read the stage's box predictions): the box head and its loss -- two
+    # fully connected layers of 64 output tiles and a handful of small launches -- run on the sub-graph stream next to the mask
+    # head's convolutions (196 tiles of 256 CUs each): neither fills the chip.  Autograd runs their backward on that stream too.
+    with (mixed.on_side(dev, bbox_feats, labels, buf.targets, buf.pos, valid, rois, buf.flags, kind='branch')
+          if (bbox_branch and with_mask and _BBOX_BRANCH) else contextlib.nullcontext()) as bsd:
+        cls_score, bbox_pred = bbox_head(bbox_feats)
+        bl = bbox_head.loss(cls_score, bbox_pred, labels, buf.targets, buf.pos, valid, rois=rois, flags=buf.flags.view(-1))
+    if bsd is not None:
+        mixed.side_outputs(cls_score, bbox_pred, *bl.values())
+    losses.update(bl)
     rv = rois.view(nimg, num, 5)
     state = dict(rois=[rv[i, :, 1:] for i in range(nimg)], labels=labels, cls_score=cls_score, bbox_pred=bbox_pred,
                  valid=list(valid.view(nimg, num).unbind(0)), pos_is_gt=list(buf.is_gt.view(nimg, num).unbind(0)))
@@ -1260,6 +1269,7 @@ def _take_mask_stack(gt_masks):
     return _MASK_STACKS.pop(_mask_key(gt_masks), None)
 
 
+_BBOX_BRANCH = os.environ.get("SWIN_BBOX_BRANCH", "1") != "0"       # 0: the box head on the main stream (A/B)
 _ONES_BOOL = {}
 _PACKED_STAGE = True          # False: _roi_stage_train's per-op body also on the GPU (A/B, tests)
 
@@ -1292,7 +1302,7 @@ class StandardRoIHead(nn.Module):
     def forward_train(self, x, proposal_list, gt_bboxes, gt_labels, gt_masks):
         """standard_roi_head.py:70-131 with fixed-size samples (see _roi_stage_train)."""
         losses, _ = _roi_stage_train(x, proposal_list, gt_bboxes, gt_labels, gt_masks, self.train_cfg, self.bbox_roi_extractor,
-                                     self.bbox_head, self.mask_roi_extractor, self.mask_head)
+                                     self.bbox_head, self.mask_roi_extractor, self.mask_head, bbox_branch=True)
         return losses
 
 
