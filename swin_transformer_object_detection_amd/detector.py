@@ -1211,16 +1211,25 @@ def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cf
     # bbox_branch (the standard RoI head, whose caller does not read the stage's box predictions): the box head and its loss -- two
     # fully connected layers of 64 output tiles and a handful of small launches -- run on the sub-graph stream next to the mask
     # head's convolutions (196 tiles of 256 CUs each): neither fills the chip.  Autograd runs their backward on that stream too.
-    with (mixed.on_side(dev, bbox_feats, labels, buf.targets, buf.pos, valid, rois, buf.flags, kind='branch')
-          if (bbox_branch and with_mask and _BBOX_BRANCH) else contextlib.nullcontext()) as bsd:
-        cls_score, bbox_pred = bbox_head(bbox_feats)
-        bl = bbox_head.loss(cls_score, bbox_pred, labels, buf.targets, buf.pos, valid, rois=rois, flags=buf.flags.view(-1))
-    if bsd is not None:
-        mixed.side_outputs(cls_score, bbox_pred, *bl.values())
-    losses.update(bl)
-    rv = rois.view(nimg, num, 5)
-    state = dict(rois=[rv[i, :, 1:] for i in range(nimg)], labels=labels, cls_score=cls_score, bbox_pred=bbox_pred,
-                 valid=list(valid.view(nimg, num).unbind(0)), pos_is_gt=list(buf.is_gt.view(nimg, num).unbind(0)))
+    # (not inside a stream capture: the branch's outputs cross streams through Tensor.record_stream, which a captured graph's private
+    # pool does not honour -- test_graph_replay_equals_eager_steps, which captures WITH the auxiliary streams, caught it)
+    branch = bool(bbox_branch and with_mask and _BBOX_BRANCH and mixed.side_enabled() and not torch.cuda.is_current_stream_capturing())
+    state = {}
+
+    def run_bbox():
+        with (mixed.on_side(dev, bbox_feats, labels, buf.targets, buf.pos, valid, rois, buf.flags, kind='branch')
+              if branch else contextlib.nullcontext()) as bsd:
+            cls_score, bbox_pred = bbox_head(bbox_feats)
+            bl = bbox_head.loss(cls_score, bbox_pred, labels, buf.targets, buf.pos, valid, rois=rois, flags=buf.flags.view(-1))
+        if bsd is not None:
+            mixed.side_outputs(cls_score, bbox_pred, *bl.values())
+        losses.update(bl)
+        rv = rois.view(nimg, num, 5)
+        state.update(rois=[rv[i, :, 1:] for i in range(nimg)], labels=labels, cls_score=cls_score, bbox_pred=bbox_pred,
+                     valid=list(valid.view(nimg, num).unbind(0)), pos_is_gt=list(buf.is_gt.view(nimg, num).unbind(0)))
+
+    if not branch:
+        run_bbox()
     if with_mask:
         if mask_feats is None:
             mask_feats = mask_roi_extractor(x[:mask_roi_extractor.num_inputs], buf.feat_rois, valid=buf.mvalid)
@@ -1231,6 +1240,8 @@ def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cf
         # (the mask head is enqueued first: issuing the branch takes the host ~100 us, which the main stream spends computing)
         rows_path = hasattr(mask_head, 'forward_rows') and mask_feats.size(0) > 0
         mask_pred = mask_head.forward_rows(mask_feats) if rows_path else mask_head(mask_feats)
+        if branch:
+            run_bbox()                        # issued behind the mask head: the host's ~0.25 ms for it no longer idle the main stream
         with mixed.on_side(dev, buf.mask_rois, *gt_masks) as sd:
             if stacked:
                 m = _take_mask_stack(gt_masks) if sd is not None else None                              # stacked before the backbone ran

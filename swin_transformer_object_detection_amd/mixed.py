@@ -246,6 +246,7 @@ _WG_ON = os.environ.get("SWIN_WGRAD_GROUP", "1") != "0"      # 0: every weight g
 _WG_ENABLED = [0]     # > 0 while a reducer with gradient sinks is alive (someone flushes before the gradients are read)
 _WG_PENDING = {}      # device index -> [problems, 128x128 tiles]
 _WG_KEEP = []
+_WG_STREAMS = {}      # device index -> raw handles of the streams the recorded operands were produced on
 _WG_FLUSH_TILES = int(os.environ.get("SWIN_WGRAD_GROUP_TILES", "600"))
 _WG_TAIL = int(os.environ.get("SWIN_WGRAD_TAIL_FLUSH", "0"))      # 1: launch the narrow stages' gradients block by block (A/B: slower);
                                                                     # 2: one extra launch at the stage 2 / stage 1 boundary
@@ -284,6 +285,10 @@ def wgrad_note(device, problems, tiles, *keep, tail=False):
     ent[0] += problems
     ent[1] += tiles
     _WG_KEEP.extend(t for t in keep if t is not None)
+    # the operands come from the stream this backward node runs on: the main stream, or the sub-graph stream for the box head
+    # (detector._roi_stage_train_packed) -- the grouped launch must wait for every one of them, not only for the stream that
+    # happens to trigger the flush (found by test_graph_replay_equals_eager_steps)
+    _WG_STREAMS.setdefault(i, set()).add(_raw_current(i))
     if ent[1] >= _WG_FLUSH_TILES or ent[0] >= 30 or (tail and _SIDE_ON and (_WG_TAIL == 1 or (_WG_TAIL == 2 and tail == 2))):
         wgrad_flush()
 
@@ -299,11 +304,16 @@ def wgrad_flush():
         dev = torch.device("cuda", i)
         with torch.cuda.device(i):
             sp = fork_to_side(dev)                       # None: feature off -> the current stream
-            call("swin_wgrad_flush", ctypes.c_void_p(sp if sp is not None else _raw_current(i)))
+            target = sp if sp is not None else _raw_current(i)
+            for h in _WG_STREAMS.get(i, ()):             # producers on other streams than the one the fork came from
+                if h != target and h != _raw_current(i):
+                    call("swin_fork_stream", ctypes.c_void_p(h), ctypes.c_void_p(target))
+            call("swin_wgrad_flush", ctypes.c_void_p(target))
         if sp is not None:
             side_keep(*_WG_KEEP)                         # the side stream reads them: alive until the next join
     _WG_PENDING.clear()
     _WG_KEEP.clear()
+    _WG_STREAMS.clear()
 
 
 def side_join():

@@ -602,19 +602,23 @@ def gemm_bf16(a, b, bias=None, b_is_kn=False, out_shape=None, relu=False):
     M, K = a.shape
     N = b.shape[1] if b_is_kn else b.shape[0]
     dev = a.device
-    ws = _GEMM_WS.get(dev)
+    # one workspace per STREAM: the library's split-K algorithms write it, and the box head's GEMMs run on the sub-graph stream next
+    # to the main stream's (detector._roi_stage_train_packed) -- a shared buffer was a race (test_graph_replay_equals_eager_steps)
+    stream = _s()
+    key = (dev, stream.value)
+    ws = _GEMM_WS.get(key)
     if ws is None:
-        ws = _GEMM_WS[dev] = torch.empty(_lib.lib().swin_gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+        ws = _GEMM_WS[key] = torch.empty(_lib.lib().swin_gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
     c = torch.empty((M, N) if out_shape is None else out_shape, dtype=_H(), device=dev)   # not a view
     if not b_is_kn and K in _TS_K and M >= 4096 and N % 32 == 0:
         # narrow contraction, long token axis (qkv / proj of stages 1-2, the FPN laterals of those stages, the mask head's
         # deconvolution as a GEMM): HBM-bound -- the token-stationary kernel (csrc/ts_linear.hip) instead of the library
-        rc = _lib.lib().swin_ts_linear_bf16(_p(a), _p(b), _p(bias), _p(c), M, N, K, 1 if relu else 0, _s())
+        rc = _lib.lib().swin_ts_linear_bf16(_p(a), _p(b), _p(bias), _p(c), M, N, K, 1 if relu else 0, stream)
         if rc == 0:
             return c
         if rc != 2:                                            # 2 = SWIN_ERR_UNSUPPORTED: this N has no chunking -> library
             raise SwinHipError(f"swin_ts_linear_bf16 failed with status {rc}")
-    call("swin_gemm_bf16", _p(a), _p(b), _p(bias), _p(c), M, N, K, 1 if b_is_kn else 0, _p(ws), _s())
+    call("swin_gemm_bf16", _p(a), _p(b), _p(bias), _p(c), M, N, K, 1 if b_is_kn else 0, _p(ws), stream)
     return c.relu_() if relu else c
 
 

@@ -1,5 +1,7 @@
-"""One training step out of a rocprofv3 kernel TRACE (development aid): the launches between two consecutive adamw_kernel
-launches, by category -- exact per-step counts and times (the kernel_stats.csv summary also holds bench.py's warm-up and its
+"""One training step out of a rocprofv3 kernel TRACE (development aid): one period of the step -- the launches between two
+consecutive launches of a kernel that runs once per step (nms_segsort_kernel, in the forward pass; with AdamW applied per gradient
+bucket there are several adamw_kernel launches per step, so that kernel no longer delimits it; traces without an RPN fall back to
+it) -- by category -- exact per-step counts and times (the kernel_stats.csv summary also holds bench.py's warm-up and its
 live roofline measurements).  usage: step_trace.py kernel_trace.csv [which_step_from_the_end=2] [top=40]"""
 import collections
 import csv
@@ -14,10 +16,18 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-idx = [i for i, r in enumerate(rows) if 'adamw_kernel' in r['Kernel_Name']]
-a, b = idx[-back - 1], idx[-back]
-step = rows[a + 1:b + 1]
-t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
+idx = [i for i, r in enumerate(rows) if 'nms_segsort_kernel' in r['Kernel_Name']]
+if len(idx) > back:
+    a, b = idx[-back - 1], idx[-back]
+    step = rows[a:b]                     # one period, starting in the forward pass
+    t0, t1 = int(step[0]['Start_Timestamp']), int(rows[b]['Start_Timestamp'])
+    what = "one period of the step (nms_segsort_kernel to nms_segsort_kernel)"
+else:
+    idx = [i for i, r in enumerate(rows) if 'adamw_kernel' in r['Kernel_Name']]
+    a, b = idx[-back - 1], idx[-back]
+    step = rows[a + 1:b + 1]
+    t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
+    what = "from the first launch to the end of adamw_kernel"
 streams = collections.Counter(r['Stream_Id'] if 'Stream_Id' in r else r['Queue_Id'] for r in step)
 main = streams.most_common(1)[0][0]
 d = collections.defaultdict(lambda: [0.0, 0, 0.0, 0])
@@ -39,7 +49,7 @@ for s, e in iv[1:]:
     else:
         cur_e = max(cur_e, e)
 cov += cur_e - cur_s
-print(f"one step: {len(step)} launches, {(t1 - t0) / 1e6:.3f} ms from the first launch to the end of adamw_kernel "
+print(f"one step: {len(step)} launches, {(t1 - t0) / 1e6:.3f} ms {what} "
       f"(under the profiler); some kernel running for {cov / 1e6:.3f} ms of it")
 print("kernel time per stream (ms): " + ", ".join(f"{k}: {v / 1e6:.3f} ({streams[k]} launches)" for k, v in sorted(busy.items(), key=lambda kv: -kv[1])))
 print(f"{'category':26s} {'ms':>8s} {'launches':>9s} {'of which on the 2nd stream (ms, launches)':>44s}")

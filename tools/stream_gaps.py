@@ -7,8 +7,12 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 thr = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 15000
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'adamw_kernel' in r['Kernel_Name']]
-step = rows[idx[-2] + 1: idx[-1] + 1]
+idx = [i for i, r in enumerate(rows) if 'nms_segsort_kernel' in r['Kernel_Name']]     # once per step (forward); AdamW may run per bucket
+if len(idx) >= 3:
+    step = rows[idx[-3]: idx[-2]]
+else:
+    idx = [i for i, r in enumerate(rows) if 'adamw_kernel' in r['Kernel_Name']]
+    step = rows[idx[-2] + 1: idx[-1] + 1]
 t0 = int(step[0]['Start_Timestamp'])
 streams = collections.Counter(r['Stream_Id'] for r in step)
 main = max(streams, key=streams.get)
