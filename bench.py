@@ -229,7 +229,7 @@ def gemm_rooflines(device, steps=18):
         ("conv_halo_kernel<4> (3x3 conv forward / data gradient, P2 2x200x320x256, halo-staged)", "conv_halo_kernel", "conv_halo@P2", conv_flops,
          conv_fwd, "cold"),
         (f"wgrad96_kernel (the Linear weight gradients of stage 3 in one grouped launch, as in the step: 24 problems, T={T}, C={C3}; "
-         "96x96 pieces per wave, groups of eight blocks per XCD)", "wgrad96_kernel", None, lin_flops, lin_wgrad, f"cold ({lin_mb:.0f} MB of operands)"),
+         "96x96 pieces per wave, groups of eight blocks per XCD)", "wgrad96_kernel", "wgrad96@stage3", lin_flops, lin_wgrad, f"cold ({lin_mb:.0f} MB of operands)"),
         (f"ts_mlp_bwd_kernel (fused MLP data gradient with fc1 recompute, stage 1: T={Tm}, C={Cm})", "ts_mlp_bwd_kernel", None, 24.0 * Tm * Cm * Cm,
          lambda: Fn.call("swin_mlp_bwd_bf16", Fn._p(mx), Fn._p(mdy), Fn._p(mw1), Fn._p(mb1), Fn._p(mw2), Fn._p(my), Fn._p(mh),
                          Fn._p(mdh), Tm, Cm, Fn._s()), "warm"),

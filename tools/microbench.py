@@ -155,6 +155,23 @@ def wgradn():
               f"{nbytes / med / 1e6:5.2f} TB/s  {flops / med / 1e6:6.1f} TFLOP/s")
 
 
+def wgradn3():
+    """stage 3's grouped Linear weight gradients only, few launches (counter passes: tools/pmc_run.sh ... wgrad96_kernel)"""
+    T, C = 8000, 384
+    probs = []
+    for _ in range(6):
+        for (N1, N2) in ((3 * C, C), (C, C), (4 * C, C), (C, 4 * C)):
+            probs.append(((torch.randn(T, N1, device="cuda") * 0.1).bfloat16(), torch.randn(T, N2, device="cuda").bfloat16(),
+                          torch.zeros(N1, N2, device="cuda"), torch.zeros(N1, device="cuda")))
+
+    def run():
+        for dy, x, dw, db in probs:
+            Fn.call("swin_wgrad_record", Fn._p(dy), Fn._p(x), Fn._p(dw), Fn._p(db), T, dy.shape[1], x.shape[1])
+        Fn.call("swin_wgrad_flush", Fn._s())
+    med, mn = timeit(run, n=5, warm=2)
+    print(f"wgrad group stage 3: {med:7.1f} us (min {mn:.1f})")
+
+
 def rooflinep():
     """the two kernels bench.py prices against the MFMA roofline, at the P2 geometry and in bench.py's cache regime (launches rotate over
     three operand sets, 3 x 131 MB > the 256 MB Infinity Cache): the conv weight gradient (wgrad2_kernel<ConvSrc>) and the halo-staged
