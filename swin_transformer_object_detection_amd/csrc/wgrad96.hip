@@ -259,7 +259,9 @@ __device__ __forceinline__ void segment(char* lds, const NProb& q, const int til
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
             if (do_compute) mma(cur);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
         if (do_compute) read_frags(f0, 0, 0);
