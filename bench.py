@@ -159,14 +159,19 @@ def pmc_traffic(key):
 
 
 def _time_launches(fn, steps):
+    """(average, median) launch duration in ms, HIP events on the launch stream.  The launches are enqueued back to back behind three
+    warm-up launches, an event between every two: the host runs ahead of the GPU, so an interval is one launch's duration and a host
+    hiccup between two enqueues (seen on one box: a 10x outlier that dragged a per-launch start/stop average down to 0.02 of peak)
+    does not idle the GPU inside the timed region."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     for _ in range(3):
         fn()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    for s_, e_ in ev:
-        s_.record(); fn(); e_.record()
+    ev[0].record()
+    for i in range(steps):
+        fn(); ev[i + 1].record()
     torch.cuda.synchronize()
-    ms = sorted(s_.elapsed_time(e_) for s_, e_ in ev)
-    return sum(ms) / len(ms), ms[len(ms) // 2]
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    return ev[0].elapsed_time(ev[steps]) / steps, ms[len(ms) // 2]
 
 
 def gemm_rooflines(device, steps=18):
