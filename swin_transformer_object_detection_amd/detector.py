@@ -1213,7 +1213,11 @@ def _roi_stage_train_packed(x, proposal_list, gt_bboxes, gt_labels, gt_masks, cf
     # head's convolutions (196 tiles of 256 CUs each): neither fills the chip.  Autograd runs their backward on that stream too.
     # (not inside a stream capture: the branch's outputs cross streams through Tensor.record_stream, which a captured graph's private
     # pool does not honour -- test_graph_replay_equals_eager_steps, which captures WITH the auxiliary streams, caught it)
-    branch = bool(bbox_branch and with_mask and _BBOX_BRANCH and mixed.side_enabled() and not torch.cuda.is_current_stream_capturing())
+    # (and one process only: with an overlapped gradient all-reduce a bucket is launched behind the stream its LAST gradient arrived on,
+    # and nothing marks the sub-graph stream as busy during backward -- not rehearsed, so not enabled)
+    branch = bool(bbox_branch and with_mask and _BBOX_BRANCH and mixed.side_enabled() and not torch.cuda.is_current_stream_capturing()
+                  and not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                           and torch.distributed.get_world_size() > 1))
     state = {}
 
     def run_bbox():
